@@ -1,0 +1,350 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference, which never travels to the
+GPU box).  Nothing from the reference is copied: this script calls the reference's
+public functions on seeded inputs and stores inputs + outputs as small .npz/.json
+fixtures.  The fixtures pin `oracle/` (tests/test_oracle_golden.py); the HIP path is
+then compared with the oracle and with these fixtures (tests/test_gpu_*.py).
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Import-time stubs (none of them is arithmetic on the hot path):
+cv2, lpips, skimage.metrics, torchvision.{utils,transforms.functional}.  The only
+stub with behaviour is torchvision.utils.make_grid(t, nrow, padding=0), which with
+padding 0 is pure tiling (reference call site: deeplens/optics.py:1025).
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("AADFF_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+
+import numpy as np
+import torch
+
+
+def _install_stubs():
+    cv2 = types.ModuleType("cv2")
+    sys.modules["cv2"] = cv2
+    sys.modules["lpips"] = types.ModuleType("lpips")
+    sk = types.ModuleType("skimage")
+    skm = types.ModuleType("skimage.metrics")
+    skm.peak_signal_noise_ratio = lambda *a, **k: 0.0
+    skm.structural_similarity = lambda *a, **k: 0.0
+    sk.metrics = skm
+    sys.modules["skimage"] = sk
+    sys.modules["skimage.metrics"] = skm
+
+    tv = types.ModuleType("torchvision")
+    tvu = types.ModuleType("torchvision.utils")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional")
+
+    def make_grid(tensor, nrow=8, padding=0, pad_value=0.0, **kw):
+        # torchvision semantics for a 4-D batch with padding=0: tile row-major,
+        # nrow images per row; 1-channel inputs are repeated to 3 channels.
+        assert padding == 0
+        if tensor.dim() == 4 and tensor.shape[1] == 1:
+            tensor = torch.cat((tensor, tensor, tensor), 1)
+        n, c, h, w = tensor.shape
+        xmaps = min(nrow, n)
+        ymaps = int(np.ceil(float(n) / xmaps))
+        grid = tensor.new_full((c, h * ymaps, w * xmaps), pad_value)
+        k = 0
+        for yy in range(ymaps):
+            for xx in range(xmaps):
+                if k >= n:
+                    break
+                grid[:, yy * h:(yy + 1) * h, xx * w:(xx + 1) * w] = tensor[k]
+                k += 1
+        return grid
+
+    tvu.make_grid = make_grid
+    tvu.save_image = lambda *a, **k: None
+    tv.utils = tvu
+    tvt.functional = tvf
+    tv.transforms = tvt
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.utils"] = tvu
+    sys.modules["torchvision.transforms"] = tvt
+    sys.modules["torchvision.transforms.functional"] = tvf
+
+
+_install_stubs()
+sys.path.insert(0, REF)
+from deeplens.optics import Lensgroup  # noqa: E402
+from deeplens.basics import Ray, Material, WAVE_RGB, DEFAULT_WAVE, GEO_SPP  # noqa: E402
+from deeplens.monte_carlo import forward_integral  # noqa: E402
+import importlib  # noqa: E402
+ref_render = importlib.import_module("deeplens.render_psf")  # the package re-exports a same-named function
+from deeplens.psfnet import PSFNet, ThinLens  # noqa: E402
+from deeplens.psfnet_arch import MLP  # noqa: E402
+
+CPU = torch.device("cpu")
+sys.path.insert(0, os.path.join(REPO, "aberration-aware-depth-from-focus_amd"))
+from aadff.synth import synth_rgb, synth_depth_mm, mlp_state_dict  # noqa: E402  (shared seeded inputs)
+
+
+def restate_lens_json(name):
+    """Write the lens prescription (data, not code) in the reference's JSON schema,
+    keeping only the keys `read_lens_json` consumes (deeplens/optics.py:2045-2070)."""
+    src = json.load(open(f"{REF}/lenses/{name}/lens.json"))
+    out = {"r_last": src["r_last"], "d_sensor": src["d_sensor"], "surfaces": []}
+    for s in src["surfaces"]:
+        t = {"type": s["type"], "r": s["r"], "c": s["c"], "d": s["d"],
+             "mat1": s["mat1"], "mat2": s["mat2"]}
+        if s["type"] == "Aspheric":
+            t["k"] = s["k"]
+            t["ai"] = s["ai"]
+        out["surfaces"].append(t)
+    os.makedirs(f"{REPO}/lenses/{name}", exist_ok=True)
+    with open(f"{REPO}/lenses/{name}/lens.json", "w") as f:
+        json.dump(out, f, indent=1)
+
+
+def lens_scalars(lens):
+    return dict(d_sensor=float(lens.d_sensor), hfov=float(lens.hfov), foclen=float(lens.foclen),
+                fnum=float(lens.fnum), aper_idx=int(lens.aper_idx), pixel_size=float(lens.pixel_size),
+                sensor_size=[float(v) for v in lens.sensor_size], r_last=float(lens.r_last))
+
+
+def g1_scalars():
+    out = {}
+    for name, res in (("rf50mm", (1024, 1024)), ("rf50mm", (480, 640)), ("50mm_f2.8", (1024, 1024))):
+        lens = Lensgroup(filename=f"{REF}/lenses/{name}/lens.json", sensor_res=res, device=CPU)
+        rec = {"load": lens_scalars(lens)}
+        rec["entrance_pupil"] = [float(v) for v in lens.entrance_pupil()]
+        rec["exit_pupil"] = [float(v) for v in lens.exit_pupil()]
+        rec["entrance_pupil_shrunk"] = [float(v) for v in lens.entrance_pupil(shrink_pupil=True)]
+        rec["exit_pupil_shrunk"] = [float(v) for v in lens.exit_pupil(shrink_pupil=True)]
+        mats = sorted({s.mat1.name for s in lens.surfaces} | {s.mat2.name for s in lens.surfaces})
+        rec["ior"] = {m: [float(Material(m).ior(w)) for w in WAVE_RGB] for m in mats}
+        rec["refocus"] = {}
+        for f in (-500., -1000., -2000., -5000., -20000.):
+            lens = Lensgroup(filename=f"{REF}/lenses/{name}/lens.json", sensor_res=res, device=CPU)
+            torch.manual_seed(0)
+            lens.refocus(f)
+            rec["refocus"][str(int(f))] = lens_scalars(lens)
+        out[f"{name}@{res[0]}x{res[1]}"] = rec
+    with open(f"{HERE}/g1_scalars.json", "w") as f:
+        json.dump(out, f, indent=1)
+
+
+def g2_g3_trace_and_splat():
+    """Per-surface ray states, sensor hits, chief-ray centres and splatted PSFs."""
+    lens = Lensgroup(filename=f"{REF}/lenses/rf50mm/lens.json", sensor_res=(1024, 1024), device=CPU)
+    torch.manual_seed(0)
+    lens.refocus(-2000.)
+    ks, spp = 11, 256
+    pts = lens.point_source_grid(depth=-1500., grid=11).reshape(-1, 3)
+    # object-space points exactly as psf_diff builds them (deeplens/optics.py:953-959)
+    scale = lens.calc_scale_pinhole(pts[:, 2])
+    pobj = pts.clone()
+    pobj[..., 0] = pts[..., 0] * scale * lens.sensor_size[1] / 2
+    pobj[..., 1] = pts[..., 1] * scale * lens.sensor_size[0] / 2
+
+    gen_state = torch.get_rng_state()
+    u_theta = torch.rand(spp)
+    u_r = torch.rand(spp)
+    torch.set_rng_state(gen_state)
+    ray = lens.sample_from_points(o=pobj, spp=spp, wvln=0.589)
+    o0, d0 = ray.o.clone(), ray.d.clone()
+
+    # per-surface states for a 64-ray subset (samples 0..7 x points {0,12,60,61,108,120,5,115})
+    psel = [0, 12, 60, 61, 108, 120, 5, 115]
+    sub = Ray(o0[:8][:, psel].clone(), d0[:8][:, psel].clone(), wvln=0.589, device=CPU)
+    states_o, states_d, states_ra = [], [], []
+    for s in lens.surfaces:
+        sub = s.ray_reaction(sub)
+        states_o.append(sub.o.clone().numpy())
+        states_d.append(sub.d.clone().numpy())
+        states_ra.append(sub.ra.clone().numpy())
+
+    ray = lens.trace2sensor(ray)
+    # chief-ray centres with their own stored draws
+    gen_state = torch.get_rng_state()
+    c_theta = torch.rand(GEO_SPP)
+    c_r = torch.rand(GEO_SPP)
+    torch.set_rng_state(gen_state)
+    centre = lens.psf_center(pobj)
+    psf_raw = forward_integral(ray, ps=lens.pixel_size, ks=ks, pointc_ref=centre)
+    psf = psf_raw / psf_raw.sum(-1).sum(-1).unsqueeze(-1).unsqueeze(-1)
+
+    # backward case: the 32 entrance-pupil rays through the front group (deeplens/optics.py:1333-1366)
+    M = 32
+    aper = lens.surfaces[lens.aper_idx]
+    phi = torch.arange(-0.5, 0.5, 1.0 / M)
+    bo = torch.tensor([[aper.r, 0, aper.d.item()]]).repeat(M, 1).to(torch.float32)
+    bd = torch.stack((torch.sin(phi), torch.zeros_like(phi), -torch.cos(phi)), axis=-1)
+    bray = Ray(bo, bd, device=CPU)
+    bray, _, _ = lens.trace(bray, lens_range=range(0, lens.aper_idx))
+
+    np.savez_compressed(
+        f"{HERE}/g2_g3_trace_splat.npz",
+        d_sensor=np.float64(lens.d_sensor), hfov=np.float64(lens.hfov), pixel_size=np.float64(lens.pixel_size),
+        points=pts.numpy(), points_obj=pobj.numpy(), u_theta=u_theta.numpy(), u_r=u_r.numpy(),
+        ray_o0=o0[:8][:, psel].numpy(), ray_d0=d0[:8][:, psel].numpy(), psel=np.array(psel),
+        states_o=np.stack(states_o), states_d=np.stack(states_d), states_ra=np.stack(states_ra),
+        sensor_xy=ray.o[..., :2].numpy(), sensor_ra=ray.ra.numpy().astype(np.uint8),
+        final_d=ray.d.numpy().astype(np.float32),
+        c_theta=c_theta.numpy(), c_r=c_r.numpy(), centre=centre.numpy(),
+        psf_raw=psf_raw.numpy(), psf=psf.numpy(),
+        back_o=bray.o.numpy(), back_d=bray.d.numpy(), back_ra=bray.ra.numpy(),
+    )
+
+
+def g4_psf_map():
+    out = {}
+    for name, res, foc, depth, spp in (("rf50mm", (1024, 1024), -2000., -1500., 2048),
+                                       ("50mm_f2.8", (256, 256), -1000., -1250., 512)):
+        lens = Lensgroup(filename=f"{REF}/lenses/{name}/lens.json", sensor_res=res, device=CPU)
+        torch.manual_seed(0)
+        lens.refocus(foc)
+        st = torch.get_rng_state()
+        draws = []
+        for _ in WAVE_RGB:                      # RNG order: SURVEY.md Appendix B
+            draws += [torch.rand(spp), torch.rand(spp), torch.rand(GEO_SPP), torch.rand(GEO_SPP)]
+        torch.set_rng_state(st)
+        pm = lens.psf_map(depth=depth, grid=11, ks=11, spp=spp)
+        key = name.replace(".", "_")
+        out[f"{key}_psf_map"] = pm.numpy()
+        out[f"{key}_draws_main"] = np.stack([torch.stack((draws[4 * i], draws[4 * i + 1])).numpy() for i in range(3)])
+        out[f"{key}_draws_chief"] = np.stack([torch.stack((draws[4 * i + 2], draws[4 * i + 3])).numpy() for i in range(3)])
+        out[f"{key}_d_sensor"] = np.float64(lens.d_sensor)
+        out[f"{key}_hfov"] = np.float64(lens.hfov)
+    # single-point / list-input forms of psf() (deeplens/optics.py:945-951,980-981)
+    lens = Lensgroup(filename=f"{REF}/lenses/rf50mm/lens.json", sensor_res=(480, 640), device=CPU)
+    torch.manual_seed(3)
+    out["single_point_psf"] = lens.psf([0.3, -0.4, -1200.], ks=11, spp=1024).numpy()
+    torch.manual_seed(3)
+    out["nocenter_psf"] = lens.psf(torch.tensor([[0.3, -0.4, -1200.], [0., 0., -3000.]]), ks=11, spp=1024, center=False).numpy()
+    np.savez_compressed(f"{HERE}/g4_psf_map.npz", **out)
+
+
+def g5_conv():
+    out = {}
+    rng = np.random.Generator(np.random.PCG64(99))
+
+    def rnd(*shape):
+        return torch.from_numpy(rng.random(shape, dtype=np.float32))
+
+    def psfmap(c, g, ks):
+        p = rnd(c, g, g, ks, ks)
+        p = p / p.sum((-1, -2), keepdim=True)
+        return p.permute(0, 1, 3, 2, 4).reshape(c, g * ks, g * ks).contiguous()
+
+    # small full-tensor cases, incl. H/W not divisible by grid, B>1, ks 3/5/11/21
+    for tag, (b, c, h, w, g, ks) in {"a": (2, 3, 50, 50, 5, 11), "b": (1, 3, 37, 53, 4, 5),
+                                      "c": (1, 3, 12, 12, 3, 3), "d": (1, 3, 64, 48, 7, 21),
+                                      "e": (1, 1, 40, 40, 1, 11)}.items():
+        img, pm = rnd(b, c, h, w), psfmap(c, g, ks)
+        out[f"map_{tag}_img"], out[f"map_{tag}_psf"], out[f"map_{tag}_grid"] = img.numpy(), pm.numpy(), np.int64(g)
+        out[f"map_{tag}_out"] = ref_render.render_psf_map(img, pm, g).numpy()
+    for tag, (b, c, h, w, ks) in {"a": (2, 3, 40, 56, 11), "b": (1, 3, 16, 16, 7)}.items():
+        img = rnd(b, c, h, w)
+        p = rnd(c, ks, ks)
+        p = p / p.sum((-1, -2), keepdim=True)
+        out[f"uni_{tag}_img"], out[f"uni_{tag}_psf"] = img.numpy(), p.numpy()
+        out[f"uni_{tag}_out"] = ref_render.render_psf(img, p).numpy()
+    for tag, (b, c, h, w, ks) in {"a": (2, 3, 14, 20, 11), "b": (1, 3, 12, 12, 5), "c": (1, 1, 20, 9, 3)}.items():
+        img = rnd(b, c, h, w)
+        p = rnd(b, h, w, ks, ks)
+        p = p / p.sum((-1, -2), keepdim=True)
+        out[f"loc_{tag}_img"], out[f"loc_{tag}_psf"] = img.numpy(), p.numpy()
+        out[f"loc_{tag}_out"] = ref_render.local_psf_render(img, p, kernel_size=ks).numpy()
+    # 3-D input is auto-unsqueezed (deeplens/render_psf.py:89-90)
+    img3 = rnd(3, 12, 14)
+    p3 = rnd(1, 12, 14, 5, 5)
+    out["loc_3d_img"], out["loc_3d_psf"] = img3.numpy(), p3.numpy()
+    out["loc_3d_out"] = ref_render.local_psf_render(img3, p3, kernel_size=5).numpy()
+    # tiled variant without halo -> seams (deeplens/render_psf.py:110-127): one 2x2-tile case
+    img = rnd(1, 3, 26, 36)
+    p = rnd(1, 26, 36, 11, 11)
+    p = p / p.sum((-1, -2), keepdim=True)
+    out["hr_img"], out["hr_psf"] = img.numpy(), p.numpy()
+    out["hr_out"] = ref_render.local_psf_render_high_res(img, p, patch_size=[16, 20], kernel_size=11).numpy()
+    np.savez_compressed(f"{HERE}/g5_conv_small.npz", **out)
+
+    # 1024^2 procedural image, grid 11, ks 11: store crops at patch seams + fp64 sums
+    img = torch.from_numpy(synth_rgb(1024, 1024))[None]
+    pm = psfmap(3, 11, 11)
+    res = ref_render.render_psf_map(img, pm, 11)[0].numpy()
+    crops = {}
+    for (y, x) in ((0, 0), (61, 61), (900, 340), (960, 960), (433, 715)):
+        crops[f"{y}_{x}"] = res[:, y:y + 64, x:x + 64]
+    np.savez_compressed(f"{HERE}/g5_conv_1024.npz", psf_map=pm.numpy(),
+                        sums=res.astype(np.float64).sum((1, 2)), abs_sums=np.abs(res).astype(np.float64).sum((1, 2)),
+                        **{f"crop_{k}": v for k, v in crops.items()})
+
+
+def g6_g7_psfnet():
+    sd = mlp_state_dict(seed=4321)
+    net = MLP(in_features=4, out_features=121, hidden_features=256, hidden_layers=8)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    rng = np.random.Generator(np.random.PCG64(7))
+    x = rng.random((1024, 4), dtype=np.float32)
+    x[:, :2] = x[:, :2] * 2 - 1
+    with torch.no_grad():
+        y = net(torch.from_numpy(x)).numpy()
+    out = {"mlp_in": x, "mlp_out": y}
+
+    # G7: PSFNet.render on a 64x64 RGB-D, 5 focus distances; 4-D and 3-D image branches
+    lens = PSFNet(filename=f"{REF}/lenses/rf50mm/lens.json", sensor_res=(64, 64), kernel_size=11, device="cpu")
+    lens.psfnet.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    img = torch.from_numpy(synth_rgb(64, 64, seed=11))[None]
+    depth = -torch.from_numpy(synth_depth_mm(64, 64, seed=12))[None, None]
+    fds = [-500., -800., -1500., -3000., -5000.]
+    outs = [lens.render(img, depth, torch.tensor([f])).numpy() for f in fds]
+    out["render_fds"] = np.array(fds, dtype=np.float32)
+    out["render_out"] = np.concatenate(outs, 0)
+    out["render3d_out"] = lens.render(img[0], depth[0, 0], -1500.).numpy()
+    # batched 4-D branch, two images with different focus distances
+    img2 = torch.cat((img, torch.flip(img, [-1])), 0)
+    depth2 = torch.cat((depth, torch.flip(depth, [-2])), 0)
+    out["render_b2_out"] = lens.render(img2, depth2, torch.tensor([-700., -2500.])).numpy()
+
+    # ThinLens baseline (deeplens/psfnet.py:489-570), 4-D branch
+    thin = ThinLens(foc_len=50.0, fnum=1.8, kernel_size=11, sensor_size=[24.0, 24.0], sensor_res=(64, 64))
+    out["thin_out"] = thin.render(img, depth, torch.tensor([-1500.])).numpy()
+    out["thin_coc"] = thin.coc(depth, torch.full_like(depth, -1500.)).numpy()
+    np.savez_compressed(f"{HERE}/g6_g7_psfnet.npz", **out)
+
+
+def g8_focal_stack_m1():
+    """Config-0 scale M1 stack: 256^2, 5 slices, seed 0: per slice refocus -> psf_map -> render_psf_map."""
+    H = W = 256
+    lens = Lensgroup(filename=f"{REF}/lenses/rf50mm/lens.json", sensor_res=(H, W), device=CPU)
+    img = torch.from_numpy(synth_rgb(H, W))[None]
+    depth = synth_depth_mm(H, W)
+    dbar = -float(depth.mean())
+    fds = -np.linspace(depth.min(), depth.max(), 5)
+    torch.manual_seed(0)
+    slices, maps, dsens = [], [], []
+    for f in fds:
+        lens.refocus(float(f))
+        pm = lens.psf_map(depth=dbar, grid=11, ks=11, spp=GEO_SPP)
+        slices.append(ref_render.render_psf_map(img, pm, 11))
+        maps.append(pm.numpy())
+        dsens.append(lens.d_sensor)
+    stack = torch.stack(slices, dim=2)[0].numpy()      # [3,S,H,W]
+    np.savez_compressed(f"{HERE}/g8_stack_m1.npz", fds=fds, dbar=np.float64(dbar), d_sensor=np.array(dsens),
+                        psf_maps=np.stack(maps), centre_f16=stack[:, :, 64:192, 64:192].astype(np.float16),
+                        crop=stack[:, :, 96:160, 96:160], sums=stack.astype(np.float64).sum((2, 3)))
+
+
+if __name__ == "__main__":
+    for n in ("rf50mm", "50mm_f2.8"):
+        restate_lens_json(n)
+    g1_scalars(); print("G1 done")
+    g2_g3_trace_and_splat(); print("G2/G3 done")
+    g4_psf_map(); print("G4 done")
+    g5_conv(); print("G5 done")
+    g6_g7_psfnet(); print("G6/G7 done")
+    g8_focal_stack_m1(); print("G8 done")
+    os.system(f"ls -la {HERE}")
