@@ -1,0 +1,121 @@
+"""ctypes binding of the C ABI declared in include/aadff.h (libaadff.so, HIP/gfx950).
+
+There is NO CPU fallback: every compute entry point needs the HIP library and a GPU and
+raises RuntimeError otherwise.  torch is imported first so that libaadff.so resolves
+`libamdhip64.so.7` to the runtime instance torch already loaded (streams and device
+pointers are then shared).
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libaadff.so")
+
+MAX_GRID, MAX_KS, MAX_SURF, MAX_AI = 64, 31, 32, 8
+SURF_STOP, SURF_SPHERIC, SURF_ASPHERIC = 0, 1, 2
+
+
+class Surface(C.Structure):
+    _fields_ = [("d", C.c_float), ("c", C.c_float), ("k", C.c_float), ("r", C.c_float),
+                ("r2", C.c_float), ("r2_shape", C.c_float), ("d_plus_roc", C.c_float),
+                ("eta_fwd", C.c_float), ("eta_fwd2", C.c_float), ("eta_bwd", C.c_float), ("eta_bwd2", C.c_float),
+                ("kind", C.c_int), ("n_ai", C.c_int), ("refract_fwd", C.c_int), ("refract_bwd", C.c_int),
+                ("k_gt_m1", C.c_int), ("ai", C.c_float * MAX_AI)]
+
+
+class LensState(C.Structure):
+    _fields_ = [("d_sensor", C.c_float), ("hfov", C.c_float), ("tan_hfov", C.c_float), ("foclen", C.c_float),
+                ("fnum", C.c_float), ("n_focus_rays", C.c_int), ("flags", C.c_int), ("pad", C.c_int)]
+
+
+class LensConst(C.Structure):
+    _fields_ = [("n_surf", C.c_int), ("r_last", C.c_float), ("sensor_w", C.c_float), ("sensor_h", C.c_float),
+                ("pixel_size", C.c_float), ("enp_z", C.c_float), ("enp_r", C.c_float), ("enp_r2", C.c_float),
+                ("enp_r2_shrunk", C.c_float), ("exp_z", C.c_float), ("exp_r_shrunk", C.c_float),
+                ("first_d", C.c_float), ("first_r2", C.c_float)]
+
+
+assert C.sizeof(Surface) == 96 and C.sizeof(LensState) == 32 and C.sizeof(LensConst) == 52
+
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+
+# name -> argtypes; every function returns int (0 = ok).  Kept in one table so the
+# symbol-export test can walk it (tests/test_abi_symbols.py).
+PROTOTYPES = {
+    "aadff_render_psf_map": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "aadff_render_psf_map_stack": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "aadff_render_psf": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "aadff_local_psf_render": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "aadff_trace_rays": [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P],
+    "aadff_trace_points": [_P, _I, _P, _P, _I, _F, _F, _P, _I, _P, _P, _P, _P, _P],
+    "aadff_psf_splat": [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P],
+    "aadff_psf_points": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "aadff_refocus": [_P, _I, _P, _I, _P, LensConst, _P, _P],
+    "aadff_post_computation": [_I, _P, LensConst, _P, _P],
+}
+OTHER_SYMBOLS = ["aadff_abi_version", "aadff_last_error", "aadff_device_info"]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libaadff.so and set prototypes; loud failure if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"aadff: HIP library not found at {p}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C aberration-aware-depth-from-focus_amd/csrc`. There is no CPU fallback.")
+    lib = C.CDLL(p)
+    for name, args in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.aadff_abi_version.restype = C.c_int
+    lib.aadff_last_error.restype = C.c_char_p
+    lib.aadff_device_info.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]
+    lib.aadff_device_info.restype = C.c_int
+    if lib.aadff_abi_version() != 1:
+        raise RuntimeError(f"aadff: ABI version mismatch: library {lib.aadff_abi_version()} != binding 1")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("aadff: no HIP device visible. This package runs its hot path on MI355X only; "
+                           "there is no CPU fallback (the CPU restatement under oracle/ is test infrastructure).")
+    return load_library()
+
+
+def call(name, *args):
+    """Invoke an ABI function; raise with the library's message on failure."""
+    lib = require_gpu()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.aadff_last_error().decode(errors="replace")
+        if rc == -1 and ("should be" in msg or "Input image" in msg):
+            raise AssertionError(msg)     # the reference raises AssertionError for these (render_psf.py:43-53)
+        raise RuntimeError(f"{name} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "aadff ABI needs contiguous device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def f32c(t, device):
+    """`.contiguous().float()` on the target device (SURVEY.md §8b ownership row)."""
+    return t.to(device=device, dtype=torch.float32).contiguous()

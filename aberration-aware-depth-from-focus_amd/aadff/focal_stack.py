@@ -1,0 +1,114 @@
+"""Focal-stack rendering: the whole stack in three kernel launches, sharded over GPUs.
+
+Mode M1 (north-star path): per slice refocus(f_k) -> psf_map(depth plane) ->
+render_psf_map, i.e. the loop of 2_aber_aware_dff_aif.py:104-114 with the grid renderer
+(deeplens/optics.py:779-783) — here as ONE refocus launch over the S focus distances,
+ONE fused PSF launch over S x 3 wavelengths x g^2 field points and ONE stack-fused
+convolution; the S lens states stay on the device in between.
+Mode M2: the per-pixel-PSF path the training scripts call (PSFNet.render per slice).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from deeplens.basics import DEFAULT_WAVE, GEO_SPP, WAVE_RGB
+
+
+def select_focus_dist(depth, num, mode="linear"):
+    """`num` focus distances between the min and max VALID (>0) depth of each sample
+    (reference: dff/utils.py:4-50, 'linear' rule).  depth [B,1,H,W] -> [B,num], sorted."""
+    assert num > 3, "Focal stack size is too small"
+    if mode != "linear":
+        raise NotImplementedError("only the 'linear' rule is used by the training scripts")
+    dmax = torch.amax(depth, dim=(1, 2, 3))
+    big = torch.where(depth > 0, depth, torch.full_like(depth, float("inf")))
+    dmin = torch.amin(big, dim=(1, 2, 3))
+    f = torch.stack([dmin + i * (dmax - dmin) / (num - 1) for i in range(num)], dim=1)
+    return torch.sort(f, dim=-1)[0]
+
+
+def draw_stack_uniforms(sampler, S, spp, L=3, spp_chief=GEO_SPP, spp_focus=GEO_SPP):
+    """Uniforms for an S-slice M1 stack in the reference's host-RNG order (SURVEY.md
+    Appendix B): per slice refocus (theta, r), then per wavelength main (theta, r) and
+    chief (theta, r).  Returns host tensors (u_focus [S,2,spp_focus], u_main [S,L,2,spp],
+    u_chief [S,L,2,spp_chief])."""
+    per = [spp_focus, spp_focus] + [spp, spp, spp_chief, spp_chief] * L
+    flat = sampler.rand_block(per * S).reshape(S, -1)
+    u_focus = flat[:, :2 * spp_focus].reshape(S, 2, spp_focus)
+    rest = flat[:, 2 * spp_focus:].reshape(S, L, 2 * spp + 2 * spp_chief)
+    u_main = rest[:, :, :2 * spp].reshape(S, L, 2, spp)
+    u_chief = rest[:, :, 2 * spp:].reshape(S, L, 2, spp_chief)
+    return u_focus.contiguous(), u_main.contiguous(), u_chief.contiguous()
+
+
+class StackPlan:
+    """Pre-allocated device buffers + cached tables for repeated M1 stacks of one shape."""
+
+    def __init__(self, lens, S, H, W, B=1, C_=3, grid=11, ks=11, spp=GEO_SPP):
+        dev = lens._gpu()
+        self.lens, self.S, self.grid, self.ks, self.spp, self.dev = lens, S, grid, ks, spp, dev
+        self.states = torch.zeros(S * C.sizeof(_abi.LensState), dtype=torch.uint8, device=dev)
+        self.psf_maps = torch.empty((S, 3, grid * ks, grid * ks), dtype=torch.float32, device=dev)
+        self.out = torch.empty((B, C_, S, H, W), dtype=torch.float32, device=dev)
+        self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.tab_rgb = lens._table(WAVE_RGB)
+        self.tab_green = lens._table([DEFAULT_WAVE])
+        self.lc = lens._lens_const()
+        self.pts_xy = lens.point_source_grid(depth=0.0, grid=grid).reshape(-1, 3)
+        self.conv_events = None      # optional (start, end) torch.cuda.Event pair around the conv launch
+
+
+@torch.no_grad()
+def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, spp=GEO_SPP, plan=None,
+                          return_maps=False, update_lens=True):
+    """[B,C,S,H,W] aberrated focal stack of `img` [B,C,H,W] for S focus distances (mm < 0),
+    all scene points on one depth plane (mm < 0).  No host synchronisation inside."""
+    focus = [float(f) for f in np.asarray(focus_mm, dtype=np.float64).reshape(-1)]
+    S = len(focus)
+    B, C_, H, W = img.shape
+    assert list(lens.sensor_res) == [H, W] or tuple(lens.sensor_res) == (H, W), "lens.sensor_res must match the image"
+    if plan is None:
+        plan = StackPlan(lens, S, H, W, B, C_, grid, ks, spp)
+    dev = plan.dev
+    u_focus, u_main, u_chief = draw_stack_uniforms(lens.sampler, S, spp)
+    u_focus, u_main, u_chief = (u.to(dev, non_blocking=True) for u in (u_focus, u_main, u_chief))
+    dep = torch.tensor(focus, dtype=torch.float32).to(dev, non_blocking=True)
+    pts = plan.pts_xy.clone()
+    pts[:, 2] = float(depth_plane_mm)
+    pts = pts.unsqueeze(0).repeat(S, 1, 1).contiguous().to(dev, non_blocking=True)
+    x = _abi.f32c(img, dev)
+    N = grid * grid
+    with torch.cuda.device(dev):
+        st = _abi.stream_ptr(dev)
+        _abi.call("aadff_refocus", _abi.ptr(dep), S, _abi.ptr(u_focus), GEO_SPP, _abi.ptr(plan.tab_green), plan.lc,
+                  _abi.ptr(plan.states), st)
+        _abi.call("aadff_psf_points", _abi.ptr(pts), S, N, 3, _abi.ptr(plan.tab_rgb), _abi.ptr(plan.tab_green),
+                  plan.lc, _abi.ptr(plan.states), _abi.ptr(u_main), spp, _abi.ptr(u_chief), GEO_SPP, ks, 1, 1,
+                  _abi.ptr(plan.psf_maps), None, _abi.ptr(plan.flags), st)
+        if plan.conv_events is not None:
+            plan.conv_events[0].record()
+        _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(plan.psf_maps), _abi.ptr(plan.out), B, C_, S,
+                  H, W, grid, ks, st)
+        if plan.conv_events is not None:
+            plan.conv_events[1].record()
+    if update_lens:      # the reference leaves the lens focused at the last distance
+        nb = C.sizeof(_abi.LensState)
+        lens._state_device().copy_(plan.states[(S - 1) * nb:S * nb])
+        lens._state_stale = True
+    return (plan.out, plan.psf_maps) if return_maps else plan.out
+
+
+@torch.no_grad()
+def render_focal_stack_m2(lens, img, depth_m, n_stack):
+    """[B,C,S,H,W] stack with per-pixel PSFs: depth in metres (> 0 valid), focus distances by
+    the 'linear' rule, slices via lens.render(img, -depth*1e3, -f*1e3)
+    (reference: 2_aber_aware_dff_aif.py:104-114)."""
+    fds = select_focus_dist(depth_m, n_stack)
+    return torch.stack([lens.render(img, -depth_m * 1e3, -fds[:, i] * 1e3) for i in range(n_stack)], dim=2), fds
+
+
+def shard_units(n_units, rank, world):
+    """Round-robin unit ownership u = rank (mod world)."""
+    return list(range(rank, n_units, world))

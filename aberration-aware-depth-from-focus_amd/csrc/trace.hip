@@ -1,0 +1,567 @@
+// Ray tracing through the lens surfaces, PSF accumulation and refocus for gfx950.
+//
+// One thread per ray; the surface table is wave-uniform (scalar loads, SGPR operands),
+// so every branch on the surface kind is uniform.  Newton's loop exits per WAVE
+// (`__any`), which mirrors the reference's batch-wide `while (...).any()`
+// (deeplens/surfaces.py:547) at wave granularity: extra steps on converged rays are the
+// same arithmetic the reference performs.  Semantics: SURVEY.md Appendix A.1/A.2,
+// citations per function below (paths relative to the reference repo).
+#include <cmath>
+#include "common.h"
+
+namespace aadff {
+
+constexpr float kEps = 1e-9f;            // deeplens/basics.py:34
+constexpr float kMaxT = 1e5f;            // deeplens/basics.py:32
+constexpr int kNewtonMaxIter = 10;       // deeplens/surfaces.py:26
+constexpr float kTolTight = 10e-6f;      // deeplens/surfaces.py:27
+constexpr float kTolLoose = 50e-6f;      // deeplens/surfaces.py:28
+constexpr float kStepBound = 5.f;        // deeplens/surfaces.py:29
+constexpr float kTwoPiHi = 3.14159274101257324f;   // (float)np.pi
+
+struct Ray {
+    float ox, oy, oz, dx, dy, dz, ra;
+};
+
+// ---- even-asphere sag and d(sag)/d(r^2): deeplens/surfaces.py:787-830 ----
+__device__ __forceinline__ float sag_r2(const aadff_surface_t& s, float r2) {
+    float z = r2 * s.c / (1.f + sqrtf(1.f - (1.f + s.k) * r2 * (s.c * s.c)));
+    if (s.n_ai > 0) {
+        float p = r2;
+        for (int j = 0; j < s.n_ai; ++j) {
+            z += s.ai[j] * p;
+            p *= r2;
+        }
+    }
+    return z;
+}
+
+__device__ __forceinline__ float dsag_dr2(const aadff_surface_t& s, float r2) {
+    const float a = (1.f + s.k) * r2 * (s.c * s.c);
+    const float sf = sqrtf(1.f - a);
+    float g = (1.f + sf + a / 2.f / sf) * s.c / ((1.f + sf) * (1.f + sf));
+    if (s.n_ai > 0) {
+        float p = 1.f;
+        for (int j = 0; j < s.n_ai; ++j) {
+            g += (float)(j + 1) * s.ai[j] * p;
+            p *= r2;
+        }
+    }
+    return g;
+}
+
+// ---- validity masks: deeplens/surfaces.py:724-743 ----
+__device__ __forceinline__ bool valid_strict(const aadff_surface_t& s, float r2) {
+    return s.k_gt_m1 ? (r2 < s.r2 && r2 < s.r2_shape) : (r2 < s.r2);
+}
+__device__ __forceinline__ bool valid_loose(const aadff_surface_t& s, float r2) {
+    return s.k_gt_m1 ? (r2 < s.r2_shape) : (r2 > 0.f);
+}
+
+// ---- Newton intersection: deeplens/surfaces.py:523-586.  Called by alive lanes only. ----
+template <bool STRICT>
+__device__ __forceinline__ float newton_step(const aadff_surface_t& s, const Ray& r, float dxy2, float od, float& t) {
+    const float px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t;
+    float r2 = px * px + py * py;
+    const bool m = STRICT ? valid_strict(s, r2) : valid_loose(s, r2);
+    r2 = m ? r2 : 0.f;                                   // x*valid, y*valid
+    const float ft = sag_r2(s, r2) + s.d - pz;
+    const float dr2dt = 2.f * (dxy2 * t + od);
+    const float dfdt = dsag_dr2(s, r2) * dr2dt - r.dz;
+    float step = ft / (dfdt + kEps);
+    step = fminf(fmaxf(step, -kStepBound), kStepBound);
+    t -= step;
+    return ft;
+}
+
+__device__ __forceinline__ void newton(const aadff_surface_t& s, const Ray& r, float& t_out, bool& valid_out, int& nan_flag) {
+    const float dxy2 = r.dx * r.dx + r.dy * r.dy;
+    const float od = r.dx * r.ox + r.dy * r.oy;
+    const float t0 = (s.d - r.oz) / r.dz;
+    float t = t0;
+    float ft = kMaxT;
+    for (int it = 0; it < kNewtonMaxIter; ++it) {
+        if (!__any(fabsf(ft) > kTolLoose)) break;
+        ft = newton_step<false>(s, r, dxy2, od, t);
+        if (ft != ft) nan_flag = 1;
+    }
+    const float t1 = t - t0;
+    t = t0 + t1;                                         // surfaces.py:565-569 (not an fp32 identity)
+    ft = newton_step<true>(s, r, dxy2, od, t);
+    const float px = r.ox + r.dx * t, py = r.oy + r.dy * t;
+    valid_out = valid_strict(s, px * px + py * py) && (fabsf(ft) < kTolTight) && (t > 0.f);
+    t_out = t;
+}
+
+// ---- vector Snell refraction with the surface normal: deeplens/surfaces.py:589-679 ----
+__device__ __forceinline__ void refract(const aadff_surface_t& s, Ray& r, bool forward) {
+    float nx, ny, nz;
+    if (s.kind == AADFF_SURF_STOP) {
+        nx = 0.f; ny = 0.f; nz = -1.f;
+    } else if (s.kind == AADFF_SURF_SPHERIC) {
+        if (s.c > 0.f) {
+            nx = 2.f * r.ox; ny = 2.f * r.oy; nz = 2.f * r.oz - 2.f * s.d_plus_roc;
+        } else {
+            nx = -2.f * r.ox; ny = -2.f * r.oy; nz = -2.f * r.oz + 2.f * s.d_plus_roc;
+        }
+    } else {
+        const float g = dsag_dr2(s, r.ox * r.ox + r.oy * r.oy);
+        nx = g * 2.f * r.ox; ny = g * 2.f * r.oy; nz = -1.f;
+    }
+    const float inv = 1.f / fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-12f);   // F.normalize
+    nx *= inv; ny *= inv; nz *= inv;
+    if (forward) { nx = -nx; ny = -ny; nz = -nz; }
+    const float eta = forward ? s.eta_fwd : s.eta_bwd;
+    const float eta2 = forward ? s.eta_fwd2 : s.eta_bwd2;
+    const float cosi = r.dx * nx + r.dy * ny + r.dz * nz;
+    const float sin2 = eta2 * (1.f - cosi * cosi);
+    const bool valid = (cosi * cosi > 0.1f) && (sin2 < 1.f);
+    if (valid) {
+        const float sr = sqrtf(1.f - sin2);
+        r.dx = sr * nx + eta * (r.dx - cosi * nx);
+        r.dy = sr * ny + eta * (r.dy - cosi * ny);
+        r.dz = sr * nz + eta * (r.dz - cosi * nz);
+    } else {
+        r.ra = 0.f;
+    }
+}
+
+// ---- one surface interaction: deeplens/surfaces.py:391-520 (dead rays are untouched) ----
+__device__ __forceinline__ void react(const aadff_surface_t& s, Ray& r, bool forward, int& nan_flag) {
+    if (!(r.ra > 0.f)) return;
+    if (s.kind == AADFF_SURF_STOP) {
+        const float t = (s.d - r.oz) / r.dz;
+        const float px = r.ox + t * r.dx, py = r.oy + t * r.dy, pz = r.oz + t * r.dz;
+        if (sqrtf(px * px + py * py) <= s.r) {
+            r.ox = px; r.oy = py; r.oz = pz;
+            if (forward ? s.refract_fwd : s.refract_bwd) refract(s, r, forward);
+        } else {
+            r.ra = 0.f;
+        }
+        return;
+    }
+    float t;
+    bool nvalid;
+    newton(s, r, t, nvalid, nan_flag);
+    const float px = r.ox + t * r.dx, py = r.oy + t * r.dy, pz = r.oz + t * r.dz;
+    bool valid;
+    if (s.kind == AADFF_SURF_SPHERIC)
+        valid = (px * px + py * py <= s.r2) && (t >= 0.f);      // Newton's own mask is discarded (:466)
+    else
+        valid = nvalid;
+    if (valid) {
+        r.ox = px; r.oy = py; r.oz = pz;
+        refract(s, r, forward);
+    } else {
+        r.ra = 0.f;
+    }
+}
+
+__device__ __forceinline__ void trace_range(const aadff_surface_t* __restrict__ surf, int first, int last, bool forward,
+                                            Ray& r, int& nan_flag) {
+    if (forward)
+        for (int i = first; i < last; ++i) react(surf[i], r, true, nan_flag);
+    else
+        for (int i = last - 1; i >= first; --i) react(surf[i], r, false, nan_flag);
+}
+
+__device__ __forceinline__ void propagate_to(Ray& r, float z) {      // deeplens/basics.py:255-273 (all rays)
+    const float t = (z - r.oz) / r.dz;
+    r.ox += r.dx * t; r.oy += r.dy * t; r.oz += r.dz * t;
+}
+
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
+    const float inv = 1.f / fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
+    x *= inv; y *= inv; z *= inv;
+}
+
+// pupil / disc sample from two raw uniforms: deeplens/optics.py:480-485, surfaces.py:192-195
+__device__ __forceinline__ void disc_sample(float u_theta, float u_r, float R2, float& x, float& y) {
+    const float theta = u_theta * 2.f * kTwoPiHi;
+    const float rr = sqrtf(u_r * R2);
+    x = rr * cosf(theta);
+    y = rr * sinf(theta);
+}
+
+__device__ __forceinline__ Ray ray_to(float px, float py, float pz, float tx, float ty, float tz) {
+    Ray r;
+    r.ox = px; r.oy = py; r.oz = pz;
+    r.dx = tx - px; r.dy = ty - py; r.dz = tz - pz;
+    normalize3(r.dx, r.dy, r.dz);
+    r.ra = 1.f;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------
+// generic kernels
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void trace_rays_kernel(const float* o_in, const float* d_in, const float* ra_in,
+                                                          float* o_out, float* d_out, float* ra_out, int n,
+                                                          const aadff_surface_t* __restrict__ surf, int first, int last,
+                                                          int forward, const aadff_lens_state_t* __restrict__ state,
+                                                          int* flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    r.ox = o_in[3 * i]; r.oy = o_in[3 * i + 1]; r.oz = o_in[3 * i + 2];
+    r.dx = d_in[3 * i]; r.dy = d_in[3 * i + 1]; r.dz = d_in[3 * i + 2];
+    r.ra = ra_in ? ra_in[i] : 1.f;
+    int nan_flag = 0;
+    trace_range(surf, first, last, forward != 0, r, nan_flag);
+    if (state) propagate_to(r, state->d_sensor);
+    o_out[3 * i] = r.ox; o_out[3 * i + 1] = r.oy; o_out[3 * i + 2] = r.oz;
+    d_out[3 * i] = r.dx; d_out[3 * i + 1] = r.dy; d_out[3 * i + 2] = r.dz;
+    ra_out[i] = r.ra;
+    if (nan_flag && flags) atomicOr(flags, 1);
+}
+
+__global__ __launch_bounds__(256) void trace_points_kernel(const float* __restrict__ pts, int N,
+                                                            const float* __restrict__ u_theta,
+                                                            const float* __restrict__ u_r, int spp, float pupil_z,
+                                                            float pupil_r2, const aadff_surface_t* __restrict__ surf,
+                                                            int n_surf, const aadff_lens_state_t* __restrict__ state,
+                                                            float* o_out, float* d_out, float* ra_out) {
+    // x: sample (fastest across the wave so a wave shares one object point), y: point
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.y;
+    if (i >= spp) return;
+    float x2, y2;
+    disc_sample(u_theta[i], u_r[i], pupil_r2, x2, y2);
+    Ray r = ray_to(pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], x2, y2, pupil_z);
+    int nan_flag = 0;
+    trace_range(surf, 0, n_surf, true, r, nan_flag);
+    propagate_to(r, state->d_sensor);
+    const size_t e = (size_t)i * N + n;
+    o_out[3 * e] = r.ox; o_out[3 * e + 1] = r.oy; o_out[3 * e + 2] = r.oz;
+    d_out[3 * e] = r.dx; d_out[3 * e + 1] = r.dy; d_out[3 * e + 2] = r.dz;
+    ra_out[e] = r.ra;
+}
+
+// ------------------------------------------------------------------------------------
+// PSF histogram: deeplens/monte_carlo.py:9-121
+// ------------------------------------------------------------------------------------
+struct SplatGeom {
+    float lo, hi, lim, den_row, den_col;   // all float64 -> fp32 once
+    int ks;
+};
+
+__host__ __device__ inline SplatGeom make_splat_geom(float pixel_size, int ks) {
+    const double ps = (double)pixel_size;
+    const double lo = (-ks / 2.0 + 0.5) * ps, hi = (ks / 2.0 - 0.5) * ps;
+    SplatGeom g;
+    g.lo = (float)lo; g.hi = (float)hi;
+    g.lim = (float)(hi - 0.01 * ps);
+    g.den_row = (float)(lo - hi);
+    g.den_col = (float)(hi - lo);
+    g.ks = ks;
+    return g;
+}
+
+// hit (ox,oy) on the sensor -> 4 bilinear taps into hist[ks*ks] (LDS), weight ra
+__device__ __forceinline__ void splat_hit(float* hist, const SplatGeom& g, float ox, float oy, float ra, float cx, float cy) {
+    float X = -ox - cx, Y = -oy - cy;                 // image flip, then centre
+    const bool in = (fabsf(X) < g.lim) && (fabsf(Y) < g.lim) && (ra > 0.f);
+    if (!in) return;                                   // zero-weight taps at the centre bin are skipped
+    const float rowf = ((Y - g.hi) / g.den_row) * (float)(g.ks - 1);
+    const float colf = ((X - g.lo) / g.den_col) * (float)(g.ks - 1);
+    const float fr = floorf(rowf), fc = floorf(colf);
+    const float wb = rowf - fr, wr = colf - fc;
+    const int r0 = (int)fr, c0 = (int)fc;
+    const int r1 = (int)floorf(rowf + 1.f), c1 = (int)floorf(colf + 1.f);
+    const int ks = g.ks;
+    atomicAdd(&hist[r0 * ks + c0], (1.f - wb) * (1.f - wr) * ra);
+    atomicAdd(&hist[r0 * ks + c1], (1.f - wb) * wr * ra);
+    atomicAdd(&hist[r1 * ks + c0], wb * (1.f - wr) * ra);
+    atomicAdd(&hist[(r0 + 1) * ks + (c0 + 1)], wb * wr * ra);
+}
+
+__global__ __launch_bounds__(256) void psf_splat_kernel(const float* __restrict__ o, const float* __restrict__ ra,
+                                                         const float* __restrict__ centre, int spp, int N,
+                                                         SplatGeom g, float* psf_raw, float* psf) {
+    __shared__ float hist[AADFF_MAX_KS * AADFF_MAX_KS];
+    __shared__ float red[4];
+    const int n = blockIdx.x, kk = g.ks * g.ks;
+    for (int e = threadIdx.x; e < kk; e += blockDim.x) hist[e] = 0.f;
+    __syncthreads();
+    const float cx = centre[2 * n], cy = centre[2 * n + 1];
+    for (int i = threadIdx.x; i < spp; i += blockDim.x) {
+        const size_t e = (size_t)i * N + n;
+        splat_hit(hist, g, o[3 * e], o[3 * e + 1], ra[e], cx, cy);
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int e = threadIdx.x; e < kk; e += blockDim.x) part += hist[e];
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const float total = red[0] + red[1] + red[2] + red[3];
+    for (int e = threadIdx.x; e < kk; e += blockDim.x) {
+        if (psf_raw) psf_raw[(size_t)n * kk + e] = hist[e];
+        psf[(size_t)n * kk + e] = hist[e] / total;        // 0/0 -> NaN as in deeplens/optics.py:978
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Fused PSF kernel: workgroup = (point n, wavelength l, focus state s).
+//   phase 1  chief-ray centre (shrunk pupil, chief table): deeplens/optics.py:888-913
+//   phase 2  main rays -> LDS histogram                    deeplens/optics.py:933-976
+//   phase 3  normalise, write (optionally in psf_map tiling, optics.py:1025)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict__ points, int N, int L,
+                                                          const aadff_surface_t* __restrict__ surf_main,
+                                                          const aadff_surface_t* __restrict__ surf_chief,
+                                                          aadff_lens_const_t lc,
+                                                          const aadff_lens_state_t* __restrict__ states,
+                                                          const float* __restrict__ u_main, int spp,
+                                                          const float* __restrict__ u_chief, int spp_chief,
+                                                          SplatGeom g, int centre_mode, int map_grid, float* psf,
+                                                          float* centre_out, int* flags) {
+    __shared__ float hist[AADFF_MAX_KS * AADFF_MAX_KS];
+    __shared__ float red[3 * 4];
+    const int n = blockIdx.x, l = blockIdx.y, s = blockIdx.z;
+    const int tid = threadIdx.x, kk = g.ks * g.ks;
+    const aadff_lens_state_t st = states[s];
+    for (int e = tid; e < kk; e += 256) hist[e] = 0.f;
+
+    // object-space point: deeplens/optics.py:953-959 with calc_scale_pinhole (:1286-1290)
+    const float* pt = points + ((size_t)s * N + n) * 3;
+    const float xn = pt[0], yn = pt[1], depth = pt[2];
+    const float scale = (-depth) * st.tan_hfov / lc.r_last;
+    const float px = xn * scale * lc.sensor_w / 2.f;
+    const float py = yn * scale * lc.sensor_h / 2.f;
+    int nan_flag = 0;
+
+    float cx, cy;
+    if (centre_mode == 1) {
+        const float* ut = u_chief + ((size_t)(s * L + l) * 2) * spp_chief;
+        const float* ur = ut + spp_chief;
+        float sx = 0.f, sy = 0.f, sw = 0.f;
+        for (int i = tid; i < spp_chief; i += 256) {
+            float x2, y2;
+            disc_sample(ut[i], ur[i], lc.enp_r2_shrunk, x2, y2);
+            Ray r = ray_to(px, py, depth, x2, y2, lc.enp_z);
+            trace_range(surf_chief, 0, lc.n_surf, true, r, nan_flag);
+            propagate_to(r, st.d_sensor);
+            sx += r.ox * r.ra; sy += r.oy * r.ra; sw += r.ra;
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy); sw = wave_sum(sw);
+        if ((tid & 63) == 0) {
+            red[(tid >> 6) * 3] = sx; red[(tid >> 6) * 3 + 1] = sy; red[(tid >> 6) * 3 + 2] = sw;
+        }
+        __syncthreads();
+        sx = red[0] + red[3] + red[6] + red[9];
+        sy = red[1] + red[4] + red[7] + red[10];
+        sw = red[2] + red[5] + red[8] + red[11];
+        cx = -(sx / (sw + kEps));
+        cy = -(sy / (sw + kEps));
+        if (sw == 0.f && tid == 0 && flags) atomicOr(flags, 2);      // "No sampled rays is valid." (optics.py:901)
+    } else {
+        cx = xn * (lc.sensor_w / 2.f);                               // optics.py:972-974
+        cy = yn * (lc.sensor_h / 2.f);
+        __syncthreads();
+    }
+    if (centre_out && tid == 0) {
+        float* co = centre_out + ((size_t)(s * L + l) * N + n) * 2;
+        co[0] = cx; co[1] = cy;
+    }
+
+    const aadff_surface_t* tab = surf_main + (size_t)l * lc.n_surf;
+    const float* ut = u_main + ((size_t)(s * L + l) * 2) * spp;
+    const float* ur = ut + spp;
+    for (int i = tid; i < spp; i += 256) {
+        float x2, y2;
+        disc_sample(ut[i], ur[i], lc.enp_r2, x2, y2);
+        Ray r = ray_to(px, py, depth, x2, y2, lc.enp_z);
+        trace_range(tab, 0, lc.n_surf, true, r, nan_flag);
+        propagate_to(r, st.d_sensor);
+        splat_hit(hist, g, r.ox, r.oy, r.ra, cx, cy);
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int e = tid; e < kk; e += 256) part += hist[e];
+    part = wave_sum(part);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    const float total = red[0] + red[1] + red[2] + red[3];
+    const int ks = g.ks;
+    for (int e = tid; e < kk; e += 256) {
+        const float v = hist[e] / total;
+        if (map_grid > 0) {
+            const int gi = n / map_grid, gj = n - gi * map_grid, u = e / ks, w = e - u * ks;
+            const int G = map_grid * ks;
+            psf[((size_t)(s * L + l) * G + gi * ks + u) * G + gj * ks + w] = v;
+        } else {
+            psf[(((size_t)s * N + n) * L + l) * kk + e] = v;
+        }
+    }
+    if (nan_flag && flags) atomicOr(flags, 1);
+}
+
+// ------------------------------------------------------------------------------------
+// Refocus + post_computation: workgroup per focus state.
+//   deeplens/optics.py:1155-1180 (refocus), :1187-1217 (calc_fov), :178-187, :1097-1102
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void refocus_kernel(const float* __restrict__ depth, const float* __restrict__ u,
+                                                       int spp, const aadff_surface_t* __restrict__ surf,
+                                                       aadff_lens_const_t lc, aadff_lens_state_t* states,
+                                                       int do_refocus) {
+    __shared__ float red[2 * 4];
+    __shared__ float s_dsensor;
+    __shared__ int s_count;
+    const int s = blockIdx.x, tid = threadIdx.x;
+    int nan_flag = 0;
+    int flags = 0;
+    if (do_refocus) {
+        const float* ut = u + (size_t)s * 2 * spp;
+        const float* ur = ut + spp;
+        const float dep = depth[s];
+        float sum = 0.f, cnt = 0.f;
+        for (int i = tid; i < spp; i += 256) {
+            float x2, y2;
+            disc_sample(ut[i], ur[i], lc.first_r2, x2, y2);
+            Ray r;
+            r.ox = x2; r.oy = y2; r.oz = lc.first_d;
+            r.dx = x2; r.dy = y2; r.dz = lc.first_d - dep;           // o - (0,0,depth)
+            normalize3(r.dx, r.dy, r.dz);
+            r.ra = 1.f;
+            trace_range(surf, 0, lc.n_surf, true, r, nan_flag);
+            float t = (r.dx * r.ox + r.dy * r.oy) / (r.dx * r.dx + r.dy * r.dy);
+            t = t * r.ra;
+            const float fd = r.oz - r.dz * t;
+            if (r.ra > 0.f && fd == fd && fd > 0.f) { sum += fd; cnt += 1.f; }
+        }
+        sum = wave_sum(sum); cnt = wave_sum(cnt);
+        if ((tid & 63) == 0) { red[(tid >> 6) * 2] = sum; red[(tid >> 6) * 2 + 1] = cnt; }
+        __syncthreads();
+        if (tid == 0) {
+            const float ts = red[0] + red[2] + red[4] + red[6], tc = red[1] + red[3] + red[5] + red[7];
+            s_dsensor = ts / tc;
+            s_count = (int)tc;
+        }
+        __syncthreads();
+    } else {
+        if (tid == 0) { s_dsensor = states[s].d_sensor; s_count = states[s].n_focus_rays; }
+        __syncthreads();
+    }
+    const float d_sensor = s_dsensor;
+
+    // calc_fov: M=100 rays from the sensor corner through the shrunk exit pupil, traced backward
+    constexpr int M = 100;
+    float tsum = 0.f, wsum = 0.f;
+    if (tid < M) {
+        const float start = -lc.exp_r_shrunk, end = lc.exp_r_shrunk;
+        const float step = (end - start) / (float)(M - 1);
+        const float x2 = tid < M / 2 ? start + step * (float)tid : end - step * (float)(M - 1 - tid);   // torch.linspace
+        Ray r = ray_to(lc.r_last, 0.f, d_sensor, x2, 0.f, lc.exp_z);
+        trace_range(surf, 0, lc.n_surf, false, r, nan_flag);
+        tsum = (r.dx / r.dz) * r.ra;
+        wsum = r.ra;
+    }
+    tsum = wave_sum(tsum); wsum = wave_sum(wsum);
+    __syncthreads();
+    if ((tid & 63) == 0) { red[(tid >> 6) * 2] = tsum; red[(tid >> 6) * 2 + 1] = wsum; }
+    __syncthreads();
+    const int any_nan = __syncthreads_or(nan_flag);
+    if (tid == 0) {
+        if (any_nan) flags |= 1;
+        const float ts = red[0] + red[2] + red[4] + red[6], tw = red[1] + red[3] + red[5] + red[7];
+        float hfov = atanf(ts / tw);
+        if (hfov != hfov) { hfov = 0.5f; flags |= 2; }
+        const double th = tan((double)hfov);
+        const double foclen = (double)lc.r_last / th;
+        aadff_lens_state_t o;
+        o.d_sensor = d_sensor;
+        o.hfov = hfov;
+        o.tan_hfov = (float)th;
+        o.foclen = (float)foclen;
+        o.fnum = (float)(foclen / (double)lc.enp_r / 2.0);
+        o.n_focus_rays = s_count;
+        o.flags = flags;
+        o.pad = 0;
+        states[s] = o;
+    }
+}
+
+}  // namespace aadff
+
+using namespace aadff;
+
+extern "C" {
+
+int aadff_trace_rays(const float* o_in, const float* d_in, const float* ra_in, float* o_out, float* d_out,
+                     float* ra_out, int n, const aadff_surface_t* surf, int first, int last, int forward,
+                     const aadff_lens_state_t* state_or_null, int* flags_or_null, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(o_in && d_in && o_out && d_out && ra_out && surf, "trace_rays: NULL pointer");
+    AADFF_CHECK_ARG(n >= 0 && first >= 0 && first <= last && last <= AADFF_MAX_SURF, "trace_rays: bad range [%d,%d) or n=%d", first, last, n);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(trace_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, o_in, d_in, ra_in,
+                       o_out, d_out, ra_out, n, surf, first, last, forward, state_or_null, flags_or_null);
+    AADFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int aadff_trace_points(const float* points_obj, int N, const float* u_theta, const float* u_r, int spp, float pupil_z,
+                       float pupil_r, const aadff_surface_t* surf, int n_surf, const aadff_lens_state_t* state,
+                       float* o_out, float* d_out, float* ra_out, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(points_obj && u_theta && u_r && surf && state && o_out && d_out && ra_out, "trace_points: NULL pointer");
+    AADFF_CHECK_ARG(N > 0 && N <= 65535 && spp > 0 && n_surf > 0 && n_surf <= AADFF_MAX_SURF, "trace_points: bad sizes N=%d spp=%d n_surf=%d", N, spp, n_surf);
+    const float r2 = (float)((double)pupil_r * (double)pupil_r);
+    hipLaunchKernelGGL(trace_points_kernel, dim3((spp + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, points_obj, N,
+                       u_theta, u_r, spp, pupil_z, r2, surf, n_surf, state, o_out, d_out, ra_out);
+    AADFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int aadff_psf_splat(const float* o, const float* ra, const float* centre, int spp, int N, float pixel_size, int ks,
+                    float* psf_raw_or_null, float* psf, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(o && ra && centre && psf, "psf_splat: NULL pointer");
+    AADFF_CHECK_ARG(spp > 0 && N > 0 && ks >= 1 && ks <= AADFF_MAX_KS, "psf_splat: bad sizes spp=%d N=%d ks=%d", spp, N, ks);
+    hipLaunchKernelGGL(psf_splat_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, o, ra, centre, spp, N,
+                       make_splat_geom(pixel_size, ks), psf_raw_or_null, psf);
+    AADFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int aadff_psf_points(const float* points, int S, int N, int L, const aadff_surface_t* surf_main,
+                     const aadff_surface_t* surf_chief, aadff_lens_const_t lc, const aadff_lens_state_t* states,
+                     const float* u_main, int spp, const float* u_chief, int spp_chief, int ks, int centre_mode,
+                     int map_layout, float* psf, float* centre_out_or_null, int* flags_or_null,
+                     aadff_stream_t stream) {
+    AADFF_CHECK_ARG(points && surf_main && states && u_main && psf, "psf_points: NULL pointer");
+    AADFF_CHECK_ARG(centre_mode == 0 || (surf_chief && u_chief && spp_chief > 0), "psf_points: chief-ray centre needs surf_chief/u_chief");
+    AADFF_CHECK_ARG(S > 0 && S <= 65535 && N > 0 && L > 0 && L <= 65535 && spp > 0, "psf_points: bad sizes S=%d N=%d L=%d spp=%d", S, N, L, spp);
+    AADFF_CHECK_ARG(ks >= 1 && ks <= AADFF_MAX_KS, "psf_points: ks %d outside [1,%d]", ks, AADFF_MAX_KS);
+    AADFF_CHECK_ARG(lc.n_surf > 0 && lc.n_surf <= AADFF_MAX_SURF, "psf_points: n_surf %d", lc.n_surf);
+    int map_grid = 0;
+    if (map_layout) {
+        map_grid = (int)lround(std::sqrt((double)N));
+        AADFF_CHECK_ARG(map_grid * map_grid == N, "psf_points: psf_map layout needs N = g*g, got %d", N);
+    }
+    hipLaunchKernelGGL(psf_points_kernel, dim3(N, L, S), dim3(256), 0, (hipStream_t)stream, points, N, L, surf_main,
+                       surf_chief, lc, states, u_main, spp, u_chief, spp_chief, make_splat_geom(lc.pixel_size, ks),
+                       centre_mode, map_grid, psf, centre_out_or_null, flags_or_null);
+    AADFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int aadff_refocus(const float* depth, int S, const float* u, int spp, const aadff_surface_t* surf_green,
+                  aadff_lens_const_t lc, aadff_lens_state_t* states, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(depth && u && surf_green && states, "refocus: NULL pointer");
+    AADFF_CHECK_ARG(S > 0 && spp > 0 && lc.n_surf > 0 && lc.n_surf <= AADFF_MAX_SURF, "refocus: bad sizes S=%d spp=%d", S, spp);
+    hipLaunchKernelGGL(refocus_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, depth, u, spp, surf_green, lc, states, 1);
+    AADFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int aadff_post_computation(int S, const aadff_surface_t* surf_green, aadff_lens_const_t lc, aadff_lens_state_t* states,
+                           aadff_stream_t stream) {
+    AADFF_CHECK_ARG(surf_green && states, "post_computation: NULL pointer");
+    AADFF_CHECK_ARG(S > 0 && lc.n_surf > 0 && lc.n_surf <= AADFF_MAX_SURF, "post_computation: bad sizes S=%d", S);
+    hipLaunchKernelGGL(refocus_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr,
+                       (const float*)nullptr, 0, surf_green, lc, states, 0);
+    AADFF_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

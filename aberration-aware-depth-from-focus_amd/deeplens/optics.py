@@ -1,0 +1,431 @@
+"""Lensgroup for the MI355X build: the reference's lens-as-PSF-generator API
+(deeplens/optics.py: psf* :887-1026, sample_from_points :457, trace* :598-714, refocus
+:1155, calc_fov :1187, pupils :1312-1403, read_lens_json :2045) on HIP kernels.
+
+Design: the focus-dependent scalars (d_sensor, hfov, foclen, fnum) live in
+a 32-byte `aadff_lens_state_t` ON THE DEVICE; refocus / post_computation write it with a
+kernel and every PSF kernel reads it, so a whole focal stack runs without a host round
+trip.  The Python attributes of the same names are properties that read it back lazily.
+Entrance/exit pupils depend only on the surfaces in front of / behind the stop and are
+cached per lens geometry.  Pupil samples come from the HOST torch generator in the
+reference's call order so results are comparable sample for sample.
+"""
+import ctypes as C
+import json
+import logging
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy import stats
+
+from aadff import _abi
+from aadff.sampling import HostSampler
+from .basics import *            # noqa: F401,F403  (star re-exports are part of the API surface)
+from .basics import DEFAULT_WAVE, DEPTH, DEVICE, EPSILON, GEO_SPP, WAVE_RGB, DeepObj, Material, Ray
+from .monte_carlo import *       # noqa: F401,F403
+from .render_psf import *        # noqa: F401,F403
+from .render_psf import render_psf_map
+from .surfaces import *          # noqa: F401,F403
+from .surfaces import Aspheric, pack_table, trace_ray_object
+from .utils import *             # noqa: F401,F403
+
+
+class Lensgroup(DeepObj):
+    def __init__(self, filename=None, sensor_res=(1024, 1024), use_roc=False, post_computation=True, device=DEVICE):
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        self.sampler = HostSampler()
+        self._table_cache = {}
+        self._pupil_cache = {}
+        self._state_dev = None
+        self._state_host = _abi.LensState()
+        self._state_stale = False
+        self.surfaces, self.materials = [], []
+        self.sensor_res = sensor_res
+        if filename is not None:
+            self.lens_name = filename
+            self.load_file(filename, use_roc, sensor_res, post_computation)
+
+    # ------------------------------------------------------------------ loading
+    def load_file(self, filename, use_roc=False, sensor_res=(1024, 1024), post_computation=True):
+        if filename[-5:] == ".json":
+            self.read_lens_json(filename)
+        else:
+            raise Exception("File format not supported.")      # reference: optics.py:135
+        self.find_aperture()
+        self.prepare_sensor(sensor_res)
+        if post_computation:
+            self.post_computation()
+
+    def read_lens_json(self, filename="./test.json"):
+        """reference: optics.py:2045-2070 — every surface type becomes an `Aspheric`."""
+        self.surfaces, self.materials = [], []
+        with open(filename, "r") as f:
+            data = json.load(f)
+        for sd in data["surfaces"]:
+            kw = dict(r=sd["r"], d=sd["d"], c=sd["c"], mat1=sd["mat1"], mat2=sd["mat2"], device="cpu")
+            if sd["type"] == "Aspheric":
+                s = Aspheric(k=sd["k"], ai=sd["ai"], **kw)
+            elif sd["type"] in ("Stop", "Spheric"):
+                s = Aspheric(**kw)
+            else:
+                raise Exception("Surface type not implemented.")
+            self.surfaces.append(s)
+            self.materials.append(Material(sd["mat1"]))
+        self.materials.append(Material(sd["mat2"]))
+        self.r_last = data["r_last"]
+        self.d_sensor = data["d_sensor"]
+        self.invalidate()
+
+    def write_lens_json(self, filename="./test.json"):
+        data = {"foclen": self.foclen, "fnum": self.fnum, "r_last": self.r_last, "d_sensor": self.d_sensor,
+                "sensor_size": [float(v) for v in self.sensor_size], "surfaces": []}
+        for i, s in enumerate(self.surfaces):
+            sd = s.surf_dict()
+            nxt = self.surfaces[i + 1].d.item() if i < len(self.surfaces) - 1 else self.d_sensor
+            sd["d_next"] = nxt - s.d.item()
+            data["surfaces"].append(sd)
+        with open(filename, "w") as f:
+            json.dump(data, f, indent=4)
+
+    def to(self, device=DEVICE):
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        self._state_sync()
+        self._state_dev = None
+        self._table_cache.clear()
+        return self
+
+    def invalidate(self):
+        """Call after editing surface parameters in place: drops packed tables and pupils."""
+        self._table_cache.clear()
+        self._pupil_cache.clear()
+
+    def find_aperture(self):
+        """First surface with air on both sides (reference: optics.py:190-198)."""
+        self.aper_idx = None
+        for i in range(len(self.surfaces) - 1):
+            if self.surfaces[i].mat1.A < 1.0003 and self.surfaces[i].mat2.A < 1.0003:
+                self.aper_idx = i
+                return
+
+    def prepare_sensor(self, sensor_res=[512, 512], sensor_size=None):
+        """reference: optics.py:153-175."""
+        sensor_res = [sensor_res, sensor_res] if isinstance(sensor_res, int) else sensor_res
+        self.sensor_res = sensor_res
+        H, W = sensor_res
+        if sensor_size is None:
+            diag = np.sqrt(H ** 2 + W ** 2)
+            self.sensor_size = [2 * self.r_last * H / diag, 2 * self.r_last * W / diag]
+        else:
+            self.sensor_size = sensor_size
+            self.r_last = np.sqrt(sensor_size[0] ** 2 + sensor_size[1] ** 2) / 2
+        assert self.sensor_size[0] / self.sensor_size[1] == H / W, "Pixel is not square."
+        self.pixel_size = self.sensor_size[0] / sensor_res[0]
+
+    # ------------------------------------------------------------------ device state
+    def _gpu(self):
+        _abi.require_gpu()
+        if self.device.type != "cuda":
+            return torch.device("cuda", torch.cuda.current_device())
+        return self.device
+
+    def _state_device(self):
+        """Device copy of the lens state, uploading pending host edits."""
+        dev = self._gpu()
+        if self._state_dev is None or self._state_dev.device != dev:
+            self._state_dev = torch.empty(C.sizeof(_abi.LensState), dtype=torch.uint8, device=dev)
+            self._state_upload()
+        return self._state_dev
+
+    def _state_upload(self):
+        host = torch.frombuffer(bytearray(bytes(self._state_host)), dtype=torch.uint8)
+        self._state_dev.copy_(host)
+        self._state_stale = False
+
+    def _state_sync(self):
+        """Host view of the state; reads the device copy back if a kernel rewrote it."""
+        if self._state_stale and self._state_dev is not None:
+            raw = bytes(self._state_dev.cpu().numpy().tobytes())
+            self._state_host = _abi.LensState.from_buffer_copy(raw)
+            self._state_stale = False
+            if self._state_host.flags & 1:
+                raise FloatingPointError("found nan in ft in non-diff newton method.")   # reference exits: surfaces.py:555-558
+            assert self._state_host.d_sensor > 0, "sensor position is negative."          # optics.py:1176
+        return self._state_host
+
+    def _state_set(self, name, value):
+        self._state_sync()
+        setattr(self._state_host, name, float(value))
+        if name == "hfov":
+            self._state_host.tan_hfov = float(np.tan(float(value)))
+        if self._state_dev is not None:
+            self._state_upload()
+
+    d_sensor = property(lambda self: float(self._state_sync().d_sensor), lambda self, v: self._state_set("d_sensor", v))
+    hfov = property(lambda self: float(self._state_sync().hfov), lambda self, v: self._state_set("hfov", v))
+    foclen = property(lambda self: float(self._state_sync().foclen), lambda self, v: self._state_set("foclen", v))
+    fnum = property(lambda self: float(self._state_sync().fnum), lambda self, v: self._state_set("fnum", v))
+
+    def _table(self, wvlns):
+        key = (tuple(float(w) for w in wvlns), str(self._gpu()))
+        if key not in self._table_cache:
+            self._table_cache[key] = pack_table(self.surfaces, list(key[0]), self._gpu())
+        return self._table_cache[key]
+
+    def _lens_const(self):
+        enp_z, enp_r = self.entrance_pupil()
+        exp_z, exp_r = self.exit_pupil()
+        lc = _abi.LensConst()
+        lc.n_surf = len(self.surfaces)
+        lc.r_last = self.r_last
+        lc.sensor_h, lc.sensor_w = self.sensor_size[0], self.sensor_size[1]
+        lc.pixel_size = self.pixel_size
+        lc.enp_z, lc.enp_r = enp_z, enp_r
+        lc.enp_r2, lc.enp_r2_shrunk = enp_r ** 2, (enp_r * 0.5) ** 2
+        lc.exp_z, lc.exp_r_shrunk = exp_z, exp_r * 0.5
+        lc.first_d = self.surfaces[0].d.item()
+        lc.first_r2 = self.surfaces[0].r ** 2
+        return lc
+
+    # ------------------------------------------------------------------ derived quantities
+    def post_computation(self):
+        """hfov, foclen, fnum for the current d_sensor (reference: optics.py:178-187)."""
+        self.find_aperture()
+        st, lc = self._state_device(), self._lens_const()
+        with torch.cuda.device(st.device):
+            _abi.call("aadff_post_computation", 1, _abi.ptr(self._table([DEFAULT_WAVE])), lc, _abi.ptr(st),
+                      _abi.stream_ptr(st.device))
+        self._state_stale = True
+
+    def calc_fov(self):
+        self.post_computation()
+        return self.hfov
+
+    def calc_efl(self):
+        return self.r_last / np.tan(self.hfov)
+
+    def calc_scale_pinhole(self, depth):
+        return -depth * np.tan(self.hfov) / self.r_last
+
+    @torch.no_grad()
+    def refocus(self, depth=DEPTH):
+        """Move the sensor to the green-light focus of an on-axis point at `depth` (mm < 0)
+        and refresh hfov/foclen/fnum (reference: optics.py:1155-1180).  One kernel, no
+        host sync; host RNG order = surface_sample: theta then r (surfaces.py:192-193)."""
+        st, lc = self._state_device(), self._lens_const()
+        u = torch.stack((self.sampler.rand(GEO_SPP), self.sampler.rand(GEO_SPP))).to(st.device)
+        dep = torch.tensor([float(depth)], dtype=torch.float32).to(st.device)
+        with torch.cuda.device(st.device):
+            _abi.call("aadff_refocus", _abi.ptr(dep), 1, _abi.ptr(u), GEO_SPP, _abi.ptr(self._table([DEFAULT_WAVE])),
+                      lc, _abi.ptr(st), _abi.stream_ptr(st.device))
+        self._state_stale = True
+
+    # ------------------------------------------------------------------ pupils
+    @torch.no_grad()
+    def exit_pupil(self, shrink_pupil=False):
+        return self.entrance_pupil(entrance=False, shrink_pupil=shrink_pupil)
+
+    @torch.no_grad()
+    def entrance_pupil(self, M=32, entrance=True, shrink_pupil=False):
+        """(z, radius) of the stop's image through the front (entrance) or rear (exit)
+        group: M edge rays traced on the GPU, pairwise x-z intersections and the 10%
+        trimmed mean on the host (reference: optics.py:1320-1403).  Cached per geometry."""
+        if self.aper_idx is None:
+            s = self.surfaces[0] if entrance else self.surfaces[-1]
+            return s.d.item(), s.r
+        key = (M, entrance)
+        if key not in self._pupil_cache:
+            aper = self.surfaces[self.aper_idx]
+            aper_z, aper_r = aper.d.item(), aper.r
+            o = torch.tensor([[aper_r, 0, aper_z]]).repeat(M, 1).to(torch.float32)
+            phi = torch.arange(-0.5, 0.5, 1.0 / M)
+            dz = -torch.cos(phi) if entrance else torch.cos(phi)
+            d = torch.stack((torch.sin(phi), torch.zeros_like(phi), dz), axis=-1)
+            rng = range(0, self.aper_idx) if entrance else range(self.aper_idx + 1, len(self.surfaces))
+            ray, _, _ = self.trace(Ray(o, d, device=self._gpu()), lens_range=rng)
+            ro, rd, ra = ray.o.cpu().numpy(), ray.d.cpu().numpy(), ray.ra.cpu().numpy()
+            ii, jj = np.triu_indices(M, 1)
+            keep = (ra[ii] != 0) & (ra[jj] != 0)
+            ii, jj = ii[keep], jj[keep]
+            d1x, d1z, d2x, d2z = rd[ii, 0], rd[ii, 2], rd[jj, 0], rd[jj, 2]
+            o1x, o1z, o2x, o2z = ro[ii, 0], ro[ii, 2], ro[jj, 0], ro[jj, 2]
+            det = -d1x * d2z + d2x * d1z
+            b1 = -d1z * o1x + d1x * o1z
+            b2 = -d2z * o2x + d2x * o2z
+            oz = (-b1 * d2z + b2 * d1z) / det
+            ox = (b2 * d1x - b1 * d2x) / det
+            if len(ox) == 0:
+                px, pz = aper_r, 0
+            else:
+                px = float(stats.trim_mean(ox.astype(np.float64), 0.1))
+                pz = float(stats.trim_mean(oz.astype(np.float64), 0.1))
+                if np.abs(pz) < EPSILON:
+                    pz = 0
+            self._pupil_cache[key] = (pz, px)
+        pz, px = self._pupil_cache[key]
+        return (pz, px * 0.5) if shrink_pupil else (pz, px)
+
+    # ------------------------------------------------------------------ ray sampling / tracing
+    @torch.no_grad()
+    def sample_from_points(self, o=[[0, 0, -10000]], spp=256, wvln=DEFAULT_WAVE, shrink_pupil=False, normalized=False):
+        """Rays [spp,N,3] from object points through the entrance pupil; ONE pupil sample
+        set shared by all points (reference: optics.py:457-491)."""
+        if not torch.is_tensor(o):
+            o = torch.tensor(o)
+        o = o.float().unsqueeze(0).repeat(spp, 1, 1)
+        pupilz, pupilr = self.entrance_pupil(shrink_pupil=shrink_pupil)
+        theta = self.sampler.rand(spp) * 2 * np.pi
+        r = torch.sqrt(self.sampler.rand(spp) * pupilr ** 2)
+        o2 = torch.stack((r * torch.cos(theta), r * torch.sin(theta), torch.full_like(r, pupilz)), 1)
+        return Ray(o, o2.unsqueeze(1) - o.cpu(), wvln=wvln, device=self.device)
+
+    def trace(self, ray, lens_range=None, record=False):
+        """Ray in, (ray_out, valid, oss) out; direction from the first ray's d_z
+        (reference: optics.py:598-624)."""
+        if record:
+            raise NotImplementedError("record=True is a plotting aid outside the hot path")
+        is_forward = bool(ray.d.reshape(-1, 3)[0, 2] > 0)
+        rng = range(0, len(self.surfaces)) if lens_range is None else lens_range
+        first, last = (rng.start, rng.stop) if len(rng) else (0, 0)
+        out = trace_ray_object(ray, self.surfaces, first, last, is_forward, None, table=self._table([ray.wvln]))
+        return out, (out.ra == 1), None
+
+    def trace2sensor(self, ray, record=False, ignore_invalid=False):
+        """trace + propagate every ray to z = d_sensor (reference: optics.py:635-661)."""
+        if record:
+            raise NotImplementedError("record=True is a plotting aid outside the hot path")
+        is_forward = bool(ray.d.reshape(-1, 3)[0, 2] > 0)
+        return trace_ray_object(ray, self.surfaces, 0, len(self.surfaces), is_forward, self._state_device(),
+                                table=self._table([ray.wvln]))
+
+    def trace2obj(self, ray, depth=DEPTH):
+        ray, _, _ = self.trace(ray)
+        return ray.propagate_to(depth)
+
+    # ------------------------------------------------------------------ PSFs
+    def point_source_grid(self, depth, grid=9, normalized=True, quater=False, center=False):
+        """[grid,grid,3] field points, x in linspace(-.98,.98), y in linspace(.98,-.98)
+        (reference: optics.py:813-860)."""
+        if grid == 1:
+            x, y = torch.tensor([[0.]]), torch.tensor([[0.]])
+            assert not quater, "Quater should be False when grid is 1."
+        elif center:
+            hb = 1 / 2 / (grid - 1)
+            x, y = torch.meshgrid(torch.linspace(-1 + hb, 1 - hb, grid), torch.linspace(1 - hb, -1 + hb, grid), indexing="xy")
+        else:
+            x, y = torch.meshgrid(torch.linspace(-0.98, 0.98, grid), torch.linspace(0.98, -0.98, grid), indexing="xy")
+        pts = torch.stack([x, y, torch.full((grid, grid), depth)], dim=-1)
+        if quater:
+            bi = grid // 2 if grid % 2 == 0 else grid // 2 + 1
+            pts = pts[0:bi, grid // 2:, :]
+        if not normalized:
+            scale = self.calc_scale_pinhole(depth)
+            pts[..., 0] *= scale * self.sensor_size[0] / 2
+            pts[..., 1] *= scale * self.sensor_size[1] / 2
+        return pts
+
+    def _object_points(self, points):
+        scale = self.calc_scale_pinhole(points[:, 2])
+        pobj = points.clone()
+        pobj[..., 0] = points[..., 0] * scale * self.sensor_size[1] / 2
+        pobj[..., 1] = points[..., 1] * scale * self.sensor_size[0] / 2
+        return pobj
+
+    @torch.no_grad()
+    def psf_center(self, point, method="chief_ray"):
+        """Reference PSF centre [N,2] for UN-normalised object points (reference: optics.py:888-913)."""
+        if method == "chief_ray":
+            ray = self.trace2sensor(self.sample_from_points(point, spp=GEO_SPP, shrink_pupil=True))
+            assert (ray.ra == 1).any(), "No sampled rays is valid."
+            c = (ray.o * ray.ra.unsqueeze(-1)).sum(0) / ray.ra.unsqueeze(-1).sum(0).add(EPSILON)
+            return -c[..., :2]
+        if method == "pinhole":
+            return -point[..., :2] / self.calc_scale_pinhole(point[..., 2])
+        raise Exception("Unsupported method.")
+
+    def _psf_launch(self, points, wvlns, ks, spp, center, map_layout):
+        """One fused launch (trace chief + main rays, splat, normalise) for len(wvlns)
+        wavelengths.  Host RNG order per wavelength: main theta, main r, chief theta,
+        chief r."""
+        dev = self._gpu()
+        L, N = len(wvlns), points.shape[0]
+        mains, chiefs = [], []
+        for _ in wvlns:
+            mains += [self.sampler.rand(spp), self.sampler.rand(spp)]
+            if center:
+                chiefs += [self.sampler.rand(GEO_SPP), self.sampler.rand(GEO_SPP)]
+        u_main = torch.stack(mains).to(dev)
+        u_chief = torch.stack(chiefs).to(dev) if center else None
+        pts = _abi.f32c(points, dev)
+        G = int(round(np.sqrt(N))) * ks
+        out = torch.empty((L, G, G) if map_layout else (N, L, ks, ks), dtype=torch.float32, device=dev)
+        flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _abi.call("aadff_psf_points", _abi.ptr(pts), 1, N, L, _abi.ptr(self._table(wvlns)),
+                      _abi.ptr(self._table([DEFAULT_WAVE])), self._lens_const(), _abi.ptr(self._state_device()),
+                      _abi.ptr(u_main), spp, _abi.ptr(u_chief), GEO_SPP, ks, int(bool(center)), int(map_layout),
+                      _abi.ptr(out), None, _abi.ptr(flags), _abi.stream_ptr(dev))
+        return out.to(self.device) if self.device.type != "cuda" else out
+
+    def psf(self, points, ks=31, wvln=DEFAULT_WAVE, spp=GEO_SPP, center=True):
+        """[N,ks,ks] (or [ks,ks]) single-wavelength PSFs of NORMALISED points (reference: optics.py:915-983)."""
+        return self.psf_diff(points=points, wvln=wvln, ks=ks, spp=spp, center=center)
+
+    def psf_diff(self, points, wvln=DEFAULT_WAVE, ks=31, spp=GEO_SPP, center=True):
+        if not torch.is_tensor(points):
+            points = torch.tensor(points)
+        single = len(points.shape) == 1
+        if single:
+            points = points.unsqueeze(0)
+        out = self._psf_launch(points.float(), [wvln], ks, spp, center, False)[:, 0]
+        return out.squeeze(0) if single else out
+
+    def psf_rgb(self, points, ks=31, spp=GEO_SPP, center=True):
+        """[N,3,ks,ks] (or [3,ks,ks]) PSFs at WAVE_RGB (reference: optics.py:986-1003)."""
+        if not torch.is_tensor(points):
+            points = torch.tensor(points)
+        single = len(points.shape) == 1
+        if single:
+            points = points.unsqueeze(0)
+        out = self._psf_launch(points.float(), WAVE_RGB, ks, spp, center, False)
+        return out.squeeze(0) if single else out
+
+    def psf_map(self, depth=DEPTH, grid=7, ks=51, spp=GEO_SPP, center=True):
+        """[3, grid*ks, grid*ks] RGB PSF map at one depth plane, row-major tiling, top row
+        = +y (reference: optics.py:1006-1026)."""
+        if ks > _abi.MAX_KS:
+            raise ValueError(f"ks={ks} exceeds the kernels' limit {_abi.MAX_KS}")
+        pts = self.point_source_grid(depth=depth, grid=grid, quater=False).reshape(-1, 3)
+        return self._psf_launch(pts, WAVE_RGB, ks, spp, center, True)
+
+    # ------------------------------------------------------------------ image rendering / misc
+    @torch.no_grad()
+    def render_single_img(self, img_org, depth=DEPTH, spp=64, unwarp=False, save_name=None, return_tensor=False,
+                          noise=0, method="psf"):
+        """`method='psf'` branch of the reference (optics.py:779-783): 7x7 PSF grid, ks 21."""
+        if method != "psf":
+            raise NotImplementedError("only method='psf' is on the focal-stack hot path")
+        if not isinstance(img_org, np.ndarray):
+            raise Exception("This function only supports ndarray input. If you want to render an image batch, use `render` function.")
+        H, W, Cn = img_org.shape
+        assert Cn == 3, "Only support RGB image, dtype should be ndarray."
+        old = self.sensor_res
+        self.prepare_sensor(sensor_res=[H, W])
+        img = torch.tensor((img_org / 255.).astype(np.float32)).permute(2, 0, 1).unsqueeze(0).to(self._gpu())
+        out = render_psf_map(img, self.psf_map(grid=7, ks=21, depth=depth), grid=7)
+        if noise > 0:
+            out = torch.clamp(out + torch.randn_like(out) * noise, 0, 1)
+        self.prepare_sensor(sensor_res=old)
+        if return_tensor:
+            return out
+        return out[0].mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()
+
+    def analysis(self, save_name="./test", render=False, **kw):
+        """The reference draws the lens layout and spot diagrams (optics.py:1552-1572);
+        here the same call logs the first-order numbers so scripts keep running."""
+        logging.getLogger().info("lens %s: foclen %.4f mm, F/%.4f, hfov %.5f rad, d_sensor %.5f mm, pixel %.6f mm",
+                                 getattr(self, "lens_name", "?"), self.foclen, self.fnum, self.hfov, self.d_sensor,
+                                 self.pixel_size)
+
+
+Lens = Lensgroup      # `north_star` calls the class optics.Lens

@@ -1,0 +1,198 @@
+"""PSFNet (lens + MLP PSF surrogate) and the thin-lens baseline on MI355X.
+
+Reference: deeplens/psfnet.py — PSFNet(Lensgroup) :14, render :393-441, pred :375-390,
+depth2z :447-450, get_training_data :135-170, train_psfnet :79-132, ThinLens :489-570.
+The per-pixel PSF application runs in csrc/conv.hip (local_psf_render); ray-traced
+training targets come from the fused PSF kernel of csrc/trace.hip.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from tqdm import tqdm
+
+from .optics import *            # noqa: F401,F403  (star chain is part of the API surface)
+from .optics import Lensgroup
+from .basics import DeepObj
+from .psfnet_arch import *       # noqa: F401,F403
+from .psfnet_arch import MLP, initialize_weights
+from .render_psf import *        # noqa: F401,F403
+from .render_psf import local_psf_render
+from .utils import make_grid, save_image   # noqa: F401
+
+DMIN = 200     # [mm]
+DMAX = 20000   # [mm]
+
+# pixels per MLP chunk: bounds the [chunk,256] fp32 activations to ~0.5 GB
+_MLP_CHUNK = 1 << 19
+
+
+class PSFNet(Lensgroup):
+    def __init__(self, filename, model_name="mlp", kernel_size=11, sensor_res=(512, 512), device="cuda"):
+        super().__init__(filename=filename, sensor_res=sensor_res, device=device)
+        self.in_features = 4
+        self.kernel_size = kernel_size
+        self.model_name = model_name
+        self.init_net()
+        self.spp = 4096
+        self.patch_size = 64
+        self.psf_grid = [sensor_res[0] // self.patch_size, sensor_res[1] // self.patch_size]
+        self.d_max, self.d_min = -DMAX, -DMIN
+        self.foc_d_arr = np.array([-500, -600, -700, -800, -900, -1000, -1250, -1500, -1750, -2000,
+                                   -2500, -3000, -4000, -5000, -6000, -8000, -10000, -12000, -15000, -20000])
+        self.foc_z_arr = (self.foc_d_arr - self.d_min) / (self.d_max - self.d_min)
+
+    # ------------------------------------------------------------------ network
+    def init_net(self):
+        if self.model_name != "mlp":
+            raise Exception("Unsupported PSF network architecture.")   # mlpconv/siren never construct in the reference either
+        ks = self.kernel_size
+        self.psfnet = MLP(in_features=4, out_features=ks ** 2, hidden_features=256, hidden_layers=8)
+        self.psfnet.apply(initialize_weights)
+        self.psfnet.to(self.device)
+
+    def load_net(self, net_path):
+        """Plain state_dict checkpoints, keys net.{0,2,..,20}.* (reference: psfnet.py:73-76;
+        map_location added so CUDA-saved files load anywhere)."""
+        self.psfnet.load_state_dict(torch.load(net_path, map_location=self.device))
+
+    def pred(self, inp):
+        psf = self.psfnet(inp)
+        return psf.reshape(*psf.shape[:-1], self.kernel_size, self.kernel_size)
+
+    def _pred_chunked(self, o):
+        flat = o.reshape(-1, o.shape[-1])
+        out = torch.empty((flat.shape[0], self.kernel_size ** 2), dtype=torch.float32, device=flat.device)
+        for i in range(0, flat.shape[0], _MLP_CHUNK):
+            out[i:i + _MLP_CHUNK] = self.psfnet(flat[i:i + _MLP_CHUNK])
+        return out.reshape(*o.shape[:-1], self.kernel_size, self.kernel_size)
+
+    @torch.no_grad()
+    def render(self, img, depth, foc_dist):
+        """Aberrated, defocused image from an all-in-focus image and a depth map (mm, < 0):
+        per-pixel (x, y, z, foc_z) -> MLP -> per-pixel PSF -> local_psf_render."""
+        dev = img.device
+        if len(img.shape) == 3:
+            H, W = depth.shape
+            z = self.depth2z(depth)
+            x, y = torch.meshgrid(torch.linspace(-1, 1, W), torch.linspace(1, -1, H), indexing="xy")
+            x, y = x.to(dev), y.to(dev)
+            foc_z = self.depth2z(torch.full_like(depth, foc_dist))
+            o = torch.stack((x, y, z, foc_z), -1)
+        elif len(img.shape) == 4:
+            N, C, H, W = img.shape
+            z = self.depth2z(depth).squeeze(1)
+            x, y = torch.meshgrid(torch.linspace(-1, 1, W), torch.linspace(1, -1, H), indexing="xy")
+            x, y = x.unsqueeze(0).repeat(N, 1, 1).to(dev), y.unsqueeze(0).repeat(N, 1, 1).to(dev)
+            foc_z = self.depth2z(foc_dist.unsqueeze(-1).unsqueeze(-1).repeat(1, H, W))
+            o = torch.stack((x, y, z, foc_z), -1).float()
+        else:
+            raise ValueError("img should be [C,H,W] or [N,C,H,W]")
+        psf = self._pred_chunked(o.to(next(self.psfnet.parameters()).device))
+        return local_psf_render(img, psf, self.kernel_size)
+
+    def depth2z(self, depth):
+        return torch.clamp((depth - self.d_min) / (self.d_max - self.d_min), min=0, max=1)
+
+    def z2depth(self, z):
+        return z * (self.d_max - self.d_min) + self.d_min
+
+    # ------------------------------------------------------------------ fitting
+    def get_training_data(self, bs=256, spp=4096):
+        """One focus distance, `bs` random (x, y, z) points and their ray-traced PSFs
+        (reference: psfnet.py:135-170; RNG order: np.random.choice, refocus draws,
+        rand x, rand y, randn z, psf draws)."""
+        foc_z = np.random.choice(self.foc_z_arr)
+        foc_dist = foc_z * (self.d_max - self.d_min) + self.d_min
+        self.refocus(depth=foc_dist)
+        x = (torch.rand(bs) - 0.5) * 2
+        y = (torch.rand(bs) - 0.5) * 2
+        z_gauss = torch.clamp(torch.randn(bs), min=-3, max=3)
+        z = torch.zeros_like(z_gauss)
+        z[z_gauss > 0] = (1 - foc_z) * z_gauss[z_gauss > 0] / 3 + foc_z
+        z[z_gauss < 0] = foc_z * z_gauss[z_gauss < 0] / 3 + foc_z
+        inp = torch.stack((x, y, z, torch.full_like(x, foc_z)), dim=-1)
+        points = torch.stack((x, y, self.z2depth(z)), dim=-1)
+        psf = self.psf(points=points, ks=self.kernel_size, spp=spp)
+        return inp, psf.view(bs, -1)
+
+    def train_psfnet(self, iters=10000, bs=128, lr=1e-4, spp=2048, evaluate_every=1000, result_dir="./results/temp",
+                     autocast_bf16=False):
+        """Fit the MLP to ray-traced PSFs generated on the fly (reference: psfnet.py:79-132:
+        MSE, AdamW, cosine schedule; checkpoints are plain state_dicts)."""
+        psfnet = self.psfnet
+        cri = nn.MSELoss()
+        optim = torch.optim.AdamW(psfnet.parameters(), lr)
+        sche = torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max=int(iters), eta_min=0)
+        dev = next(psfnet.parameters()).device
+        for i in tqdm(range(iters + 1)):
+            inp, psf = self.get_training_data(bs=bs, spp=spp)
+            inp, psf = inp.to(dev), psf.to(dev)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast_bf16 and dev.type == "cuda"):
+                pred = psfnet(inp)
+            optim.zero_grad()
+            loss = cri(pred.float(), psf)
+            loss.backward()
+            optim.step()
+            sche.step()
+            if (i + 1) % evaluate_every == 0:
+                ks = self.kernel_size
+                both = torch.stack((psf[:5].view(-1, ks, ks), pred[:5].detach().float().view(-1, ks, ks)), 1)
+                save_image(make_grid(both.reshape(-1, 1, ks, ks) / both.max(), nrow=2), f"{result_dir}/iter{i + 1}.png")
+                torch.save(psfnet.state_dict(), f"{result_dir}/iter{i + 1}_PSFNet_{self.model_name}.pkl")
+        torch.save(psfnet.state_dict(), f"{result_dir}/PSFNet_{self.model_name}.pkl")
+
+    @torch.no_grad()
+    def evaluate_psf(self, result_dir="./"):
+        """Ray-traced vs predicted PSFs at three field points, focus 1.5 m, depths
+        1.2/1.5/2 m (reference: psfnet.py:248-302; images written as PNG tiles)."""
+        ks = self.kernel_size
+        self.psfnet.eval()
+        dev = next(self.psfnet.parameters()).device
+        x = torch.Tensor([0, 0.6, 0.98])
+        foc_dist = -1500.0
+        foc_z = float(self.depth2z(torch.tensor(foc_dist)))
+        self.refocus(depth=foc_dist)
+        for depth in (-1200.0, -1500.0, -2000.0):
+            pts = torch.stack((x, x, torch.full_like(x, depth)), dim=-1)
+            gt = self.psf(points=pts, ks=ks, center=True)
+            z = float(self.depth2z(torch.tensor(depth)))
+            inp = torch.stack((x, x, torch.full_like(x, z), torch.full_like(x, foc_z)), dim=-1).to(dev)
+            pred = self.psfnet(inp).view(-1, ks, ks)
+            both = torch.cat((gt.to(dev), pred), 0)
+            save_image(make_grid((both / both.max()).unsqueeze(1), nrow=3), f"{result_dir}/foc{-foc_dist}_depth{-depth}.png")
+
+
+class ThinLens(DeepObj):
+    """Gaussian circle-of-confusion baseline (reference: psfnet.py:489-570)."""
+
+    def __init__(self, foc_len, fnum, kernel_size, sensor_size, sensor_res, device="cpu"):
+        self.d_max, self.d_min = DMAX, DMIN
+        self.kernel_size = kernel_size
+        self.foc_len, self.fnum = foc_len, fnum
+        self.sensor_size, self.sensor_res = sensor_size, sensor_res
+        self.ps = self.sensor_size[0] / self.sensor_res[0]
+        self.device = device
+
+    def coc(self, depth, foc_dist):
+        if (depth < 0).any():
+            depth, foc_dist = -depth, -foc_dist
+        depth = torch.clamp(depth, self.d_min, self.d_max)
+        coc = self.foc_len / self.fnum * torch.abs(depth - foc_dist) / depth * self.foc_len / (foc_dist - self.foc_len)
+        return torch.clamp(coc / self.ps, min=0.1)
+
+    @torch.no_grad()
+    def render(self, img, depth, foc_dist):
+        """img [N,C,H,W], depth [N,1,H,W], foc_dist [N] -> [N,C,H,W]."""
+        if len(img.shape) != 4:
+            raise ValueError("ThinLens.render needs [N,C,H,W] (the reference's 3-D branch calls methods ThinLens lacks)")
+        ks, dev = self.kernel_size, img.device
+        N, C, H, W = img.shape
+        fd = foc_dist.unsqueeze(-1).unsqueeze(-1).unsqueeze(-1).repeat(1, 1, H, W)
+        x, y = torch.meshgrid(torch.linspace(-ks / 2 + 1 / 2, ks / 2 - 1 / 2, ks),
+                              torch.linspace(ks / 2 - 1 / 2, -ks / 2 + 1 / 2, ks), indexing="xy")
+        x, y = x.to(dev), y.to(dev)
+        rad = self.coc(depth, fd).squeeze(1).unsqueeze(-1).unsqueeze(-1) / 2
+        psf = torch.exp(-(x ** 2 + y ** 2) / 2 / rad ** 2) / (2 * np.pi * rad ** 2)
+        psf = psf * (x ** 2 + y ** 2 < rad ** 2)
+        psf = psf / psf.sum((-1, -2)).unsqueeze(-1).unsqueeze(-1)
+        return local_psf_render(img, psf, ks)

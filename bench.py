@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Focal-stack MP/s on MI355X (BASELINE.json metric).
+
+Step = one M1 focal stack: 1024x1024 RGB, 10 focus distances, 11x11 PSF grid, ks 11,
+2048 rays per point and wavelength (+2048 chief rays), lens rf50mm:
+    host pupil-sample draws -> refocus (S states) -> fused ray-trace/PSF-grid kernel ->
+    stack-fused patch-PSF convolution,
+inputs (image, lens tables) resident in HBM.  One process per GPU; at N > 1 every rank
+renders its own scene's stack (weak scaling) and, with --gather, the
+stacks are all-gathered over RCCL on a side stream overlapped with the next step.
+
+Prints ONE JSON line (rank 0).  `roofline` is the patch-PSF convolution kernel against
+the 8 TB/s HBM roofline with ALGORITHMIC bytes (24 B/pixel/slice);
+`cpu_baseline` is the oracle (CPU restatement of the reference) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "aberration-aware-depth-from-focus_amd")
+for p in (REPO, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+H = W = 1024
+S, GRID, KS, SPP = 10, 11, 11, 2048
+HBM_PEAK = 8.0e12                       # B/s, MI355X_MICROARCH.md
+ALG_BYTES_PER_SLICE = 2 * 3 * H * W * 4  # read image once + write output once
+
+
+def cpu_baseline(lens_path, img, dbar, fds, budget_s=15.0):
+    """Oracle M1 slices (refocus -> psf_map -> render_psf_map) on the host cores."""
+    from oracle import conv as oconv
+    from oracle.lens import OracleLens
+    torch.set_num_threads(os.cpu_count() or 1)
+    lens = OracleLens(lens_path, sensor_res=(H, W))
+    torch.manual_seed(0)
+    t0 = time.perf_counter()
+    n = 0
+    for f in fds:
+        lens.refocus(float(f))
+        pm = lens.psf_map(depth=dbar, grid=GRID, ks=KS, spp=SPP)
+        oconv.render_psf_map(img, pm, GRID)
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(n * H * W / 1e6 / dt, 4), "unit": "MP/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} of {S} slices of the same 1024x1024 M1 stack (oracle: refocus+psf_map+render_psf_map), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gather", action="store_true", help="all-gather the rendered stacks over RCCL (config 3)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--device-rng", action="store_true", help="draw pupil samples on the GPU (not sample-comparable)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed launch with WORLD_SIZE={args.gpus} (got {world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from aadff.focal_stack import StackPlan, render_focal_stack_m1
+    from aadff.sampling import DeviceSampler
+    from aadff.synth import synth_depth_mm, synth_rgb
+    from deeplens.optics import Lensgroup
+
+    lens_path = os.path.join(REPO, "lenses", "rf50mm", "lens.json")
+    img_h = torch.from_numpy(synth_rgb(H, W, seed=1234 + rank))[None]
+    depth = synth_depth_mm(H, W, seed=5678 + rank)
+    dbar = -float(depth.mean())
+    fds = -np.linspace(depth.min(), depth.max(), S)
+    lens = Lensgroup(lens_path, sensor_res=(H, W), device=dev)
+    if args.device_rng:
+        lens.sampler = DeviceSampler(dev, seed=rank)
+    img = img_h.to(dev)
+    plan = StackPlan(lens, S, H, W, 1, 3, GRID, KS, SPP)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    gathered = comm = None
+    if world > 1 and args.gather:
+        gathered = torch.empty((world,) + tuple(plan.out.shape), dtype=torch.float32, device=dev)
+        comm = torch.cuda.Stream(dev)
+
+    def step(i, timed):
+        torch.manual_seed(i)
+        if timed:
+            plan.conv_events = ev[i]
+        out = render_focal_stack_m1(lens, img, dbar, fds, GRID, KS, SPP, plan=plan, update_lens=False)
+        plan.conv_events = None
+        if comm is not None:
+            comm.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(comm):
+                dist.all_gather_into_tensor(gathered, out)
+            torch.cuda.current_stream(dev).wait_stream(comm)   # next step overwrites plan.out
+        return out
+
+    for i in range(args.warmup):
+        step(i, False)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, True)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    conv_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    achieved = ALG_BYTES_PER_SLICE * S / (conv_ms * 1e-3)
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "conv_traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+    if rank == 0:
+        res = {
+            "metric": "focal-stack MP/s (1024^2 x 10 slices, 11x11 PSF grid)",
+            "value": round(world * S * H * W / 1e6 * args.steps / dt, 2), "unit": "MP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "rf50mm, 1024x1024 synthetic RGB + depth plane, 10 focus distances, 11x11 PSF grid, "
+                                   "ks 11, spp 2048 (+2048 chief), mode M1 (refocus -> psf_map -> render_psf_map)",
+                       "stacks_per_step_per_gpu": 1, "pupil_samples": "device RNG" if args.device_rng else "host torch RNG, reference call order",
+                       "gather": bool(comm is not None)},
+            "roofline": {"kernel": "conv_psf_map_kernel<11> (stack-fused, S=10)", "bound": "hbm", "achieved": round(achieved / 1e9, 2),
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+                         "kernel_ms": round(conv_ms, 4), "algorithmic_bytes_per_launch": ALG_BYTES_PER_SLICE * S,
+                         "tflops": round(2 * 3 * KS * KS * H * W * S / (conv_ms * 1e-3) / 1e12, 2)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(lens_path, img_h, dbar, fds)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+/*
+ * aadff.h — C ABI of the MI355X-native focal-stack rendering hot path.
+ *
+ * The reference (singer-yang/Aberration-Aware-Depth-from-Focus) has no FFI: its hot
+ * path is a chain of stock torch ops behind plain Python functions.
+ * This header is the boundary a maintainer would bind from those Python functions
+ * (ctypes stub: INTEGRATION.md).  Every entry point cites the reference code it
+ * replaces (paths relative to the reference repo).
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers to contiguous fp32 (or the struct types below)
+ *    unless the name ends in `_host`;
+ *  - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
+ *  - inputs are never written, outputs are caller-allocated;
+ *  - return 0 on success, a negative AADFF_E* for argument errors, a positive
+ *    hipError_t for runtime errors; aadff_last_error() gives the message.
+ */
+#ifndef AADFF_H_
+#define AADFF_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AADFF_ABI_VERSION 1
+
+#define AADFF_EINVAL      (-1)   /* bad shape / size / NULL pointer                  */
+#define AADFF_EUNSUPPORTED (-2)  /* parameter outside what the kernels were built for */
+
+#define AADFF_MAX_GRID   64      /* PSF grid per side (reference uses 7..11)          */
+#define AADFF_MAX_KS     31      /* PSF kernel size, odd                              */
+#define AADFF_MAX_SURF   32      /* surfaces per lens                                 */
+#define AADFF_MAX_AI     8       /* even-asphere coefficients a2..a16                 */
+
+typedef void* aadff_stream_t;
+
+/* Surface kinds = the three branches of Aspheric.ray_reaction, deeplens/surfaces.py:409,456,491 */
+enum { AADFF_SURF_STOP = 0, AADFF_SURF_SPHERIC = 1, AADFF_SURF_ASPHERIC = 2 };
+
+/* One surface at ONE wavelength.  Host code fills it (deeplens/optics.py: LensTable);
+ * values that the reference forms in float64 Python arithmetic and then feeds to fp32
+ * tensor ops are rounded to fp32 exactly once, here.  96 bytes. */
+typedef struct aadff_surface {
+    float d;            /* vertex z [mm]                            surfaces.py:11-14 */
+    float c;            /* curvature 1/roc                          surfaces.py:304   */
+    float k;            /* conic                                    surfaces.py:305   */
+    float r;            /* semi-diameter                            surfaces.py:16    */
+    float r2;           /* (float)(r*r), r*r in double              surfaces.py:466,727 */
+    float r2_shape;     /* fp32 (1-1e-9)/c^2/(1+k); +inf if unused  surfaces.py:727,738 */
+    float d_plus_roc;   /* fp32 d + 1/c (spheric normal)            surfaces.py:607-614 */
+    float eta_fwd;      /* n1/n2 (float64 -> fp32)                  surfaces.py:400-402 */
+    float eta_fwd2;     /* (n1/n2)^2 squared in float64 -> fp32     surfaces.py:658   */
+    float eta_bwd;      /* n2/n1                                    surfaces.py:403-405 */
+    float eta_bwd2;
+    int   kind;         /* AADFF_SURF_*                                               */
+    int   n_ai;         /* number of even-asphere coefficients (0..AADFF_MAX_AI)      */
+    int   refract_fwd;  /* 0 when kind==STOP and eta_fwd==1 (air-air stop skips it)   surfaces.py:449 */
+    int   refract_bwd;
+    int   k_gt_m1;      /* k > -1 selects the shape-domain test     surfaces.py:727,738 */
+    float ai[AADFF_MAX_AI];
+} aadff_surface_t;
+
+/* Per-focus-setting lens state; lives on the device so a whole stack is rendered
+ * without a host round trip.  Written by aadff_refocus / aadff_post_computation.
+ * Mirrors the attributes Lensgroup.refocus mutates (deeplens/optics.py:1155-1187). */
+typedef struct aadff_lens_state {
+    float d_sensor;     /* sensor z [mm]                                              */
+    float hfov;         /* half diagonal field of view [rad]   optics.py:1187-1217    */
+    float tan_hfov;     /* (float)tan((double)hfov)            optics.py:1289         */
+    float foclen;       /* r_last / tan(hfov)                  optics.py:1097-1102    */
+    float fnum;         /* foclen / (2*entrance pupil radius)  optics.py:186-187      */
+    int   n_focus_rays; /* rays that contributed to d_sensor (0 => refocus failed; optics.py:1176) */
+    int   flags;        /* bit0: NaN seen in a Newton residual (reference would exit(0), surfaces.py:555);
+                           bit1: hfov was NaN and replaced by 0.5 (optics.py:1210-1212) */
+    int   pad;
+} aadff_lens_state_t;
+
+/* Lens-constant sensor/pupil description (host-side scalars, passed by value). */
+typedef struct aadff_lens_const {
+    int   n_surf;
+    float r_last;          /* half sensor diagonal [mm]                   optics.py:2068 */
+    float sensor_w, sensor_h;  /* sensor_size[1], sensor_size[0] [mm]     optics.py:169  */
+    float pixel_size;      /* sensor_size[0]/H [mm]                       optics.py:175  */
+    float enp_z, enp_r;    /* entrance pupil (z, radius)                  optics.py:1320-1403 */
+    float enp_r2;          /* (float)(enp_r^2), squared in double         optics.py:481  */
+    float enp_r2_shrunk;   /* (float)((0.5*enp_r)^2)                      optics.py:1400,481 */
+    float exp_z;           /* exit pupil z                                               */
+    float exp_r_shrunk;    /* 0.5 * exit pupil radius (calc_fov)          optics.py:1196 */
+    float first_d;         /* first surface vertex z (refocus sampling)   surfaces.py:188-199 */
+    float first_r2;        /* (float)(first surface r^2)                  surfaces.py:193 */
+} aadff_lens_const_t;
+
+int         aadff_abi_version(void);
+const char* aadff_last_error(void);
+/* number of CUs etc. of the current device, for host-side launch heuristics */
+int         aadff_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------ image space */
+
+/* Spatially-varying blur with a g x g PSF grid.  Replaces render_psf_map,
+ * deeplens/render_psf.py:31-73.  img [B,C,H,W], psf_map [C,g*ks,g*ks], out [B,C,H,W]. */
+int aadff_render_psf_map(const float* img, const float* psf_map, float* out,
+                         int B, int C, int H, int W, int grid, int ks, aadff_stream_t stream);
+
+/* Stack-fused form: one image tile staged once for S PSF maps.  Replaces the slice loop
+ * of 2_aber_aware_dff_aif.py:104-114 over render_psf_map + torch.stack(dim=2).
+ * img [B,C,H,W], psf_maps [S,C,g*ks,g*ks], out [B,C,S,H,W]. */
+int aadff_render_psf_map_stack(const float* img, const float* psf_maps, float* out,
+                               int B, int C, int S, int H, int W, int grid, int ks,
+                               aadff_stream_t stream);
+
+/* One PSF for the whole image.  Replaces render_psf, deeplens/render_psf.py:12-28.
+ * psf [C,ks,ks]. */
+int aadff_render_psf(const float* img, const float* psf, float* out,
+                     int B, int C, int H, int W, int ks, aadff_stream_t stream);
+
+/* Per-pixel PSF gather (no flip, replicate padding, same PSF for every channel).
+ * Replaces local_psf_render, deeplens/render_psf.py:76-107.  psf [B,H,W,ks,ks]. */
+int aadff_local_psf_render(const float* img, const float* psf, float* out,
+                           int B, int C, int H, int W, int ks, aadff_stream_t stream);
+
+/* ------------------------------------------------------------------ ray tracing */
+
+/* Generic trace of n rays through surfaces [first,last) in travel order (reverse when
+ * !forward), optionally followed by propagation to z = state->d_sensor.  Replaces
+ * Lensgroup.trace / trace2sensor, deeplens/optics.py:598-714 + Ray.propagate_to,
+ * deeplens/basics.py:255-273.  o,d [n,3], ra [n]; in and out may alias. */
+int aadff_trace_rays(const float* o_in, const float* d_in, const float* ra_in,
+                     float* o_out, float* d_out, float* ra_out, int n,
+                     const aadff_surface_t* surf, int first, int last, int forward,
+                     const aadff_lens_state_t* state_or_null, int* flags_or_null,
+                     aadff_stream_t stream);
+
+/* Rays from object points through the entrance pupil to the sensor.  Replaces
+ * sample_from_points + trace2sensor, deeplens/optics.py:457-491,635-661.
+ * points_obj [N,3] (object space, mm); u_theta,u_r [spp] raw uniform draws
+ * (theta = u*2*pi, r = sqrt(u*R^2)); outputs o,d [spp,N,3], ra [spp,N]. */
+int aadff_trace_points(const float* points_obj, int N, const float* u_theta, const float* u_r, int spp,
+                       float pupil_z, float pupil_r, const aadff_surface_t* surf, int n_surf,
+                       const aadff_lens_state_t* state, float* o_out, float* d_out, float* ra_out,
+                       aadff_stream_t stream);
+
+/* Bilinear splat of sensor hits into ks x ks histograms + normalisation.  Replaces
+ * forward_integral / assign_points_to_pixels, deeplens/monte_carlo.py:9-121 and the
+ * division of deeplens/optics.py:978.  o [spp,N,3], ra [spp,N], centre [N,2];
+ * psf_raw_or_null / psf [N,ks,ks]. */
+int aadff_psf_splat(const float* o, const float* ra, const float* centre, int spp, int N,
+                    float pixel_size, int ks, float* psf_raw_or_null, float* psf,
+                    aadff_stream_t stream);
+
+/* Fused PSF of N normalised points for S focus states and L wavelengths in ONE launch:
+ * object-space mapping, chief-ray centre pass (shrunk pupil, `surf_chief` table), main
+ * pass, splat, normalise.  Replaces Lensgroup.psf_diff / psf_rgb / psf_map,
+ * deeplens/optics.py:888-1026.
+ *   points      [S,N,3]  normalised (x,y in [-1,1], z = depth mm < 0)
+ *   surf_main   [L][n_surf], surf_chief [n_surf]
+ *   states      [S]
+ *   u_main      [S,L,2,spp]      raw uniforms (theta row, r row)
+ *   u_chief     [S,L,2,spp_chief]
+ *   centre_mode 1: chief-ray centre (center=True); 0: ideal perspective centre (optics.py:970-975)
+ *   map_layout  0: psf [S,N,L,ks,ks] ; 1: psf_map layout [S,L,g*ks,g*ks] with N = g*g (optics.py:1025)
+ *   centre_out_or_null [S,L,N,2]
+ */
+int aadff_psf_points(const float* points, int S, int N, int L,
+                     const aadff_surface_t* surf_main, const aadff_surface_t* surf_chief,
+                     aadff_lens_const_t lc, const aadff_lens_state_t* states,
+                     const float* u_main, int spp, const float* u_chief, int spp_chief,
+                     int ks, int centre_mode, int map_layout, float* psf, float* centre_out_or_null,
+                     int* flags_or_null, aadff_stream_t stream);
+
+/* Refocus S lens states in one launch: trace spp rays from (0,0,depth[s]) (green table),
+ * least-squares axis crossing -> d_sensor, then hfov/foclen/fnum.  Replaces
+ * Lensgroup.refocus + post_computation + calc_fov + calc_efl,
+ * deeplens/optics.py:1155-1217,178-187,1097-1102.  depth [S] (mm, <0); u [S,2,spp]. */
+int aadff_refocus(const float* depth, int S, const float* u, int spp,
+                  const aadff_surface_t* surf_green, aadff_lens_const_t lc,
+                  aadff_lens_state_t* states, aadff_stream_t stream);
+
+/* hfov/foclen/fnum for states whose d_sensor is already set (lens load, or a caller
+ * that assigns d_sensor).  Replaces post_computation, deeplens/optics.py:178-187. */
+int aadff_post_computation(int S, const aadff_surface_t* surf_green, aadff_lens_const_t lc,
+                           aadff_lens_state_t* states, aadff_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AADFF_H_ */

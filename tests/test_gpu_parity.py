@@ -1,0 +1,450 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C
+ABI of include/aadff.h, against (a) the golden vectors generated from the reference and
+(b) the oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star): rendered images <= 1e-4 relative L2;
+PSFs <= 2e-3 relative L2 (fp32 trace noise floor ~5e-4); validity-mask mismatches <= 1e-4
+of rays; focus scalars <= 1e-5 relative.  Pure convolutions are held to 2e-6 abs.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from aadff import _abi                                   # noqa: E402
+from aadff.focal_stack import render_focal_stack_m1, render_focal_stack_m2   # noqa: E402
+from aadff.synth import mlp_state_dict, synth_depth_mm, synth_rgb           # noqa: E402
+from deeplens import monte_carlo as dl_mc                # noqa: E402
+import importlib                                          # noqa: E402
+rp = importlib.import_module("deeplens.render_psf")       # the package re-exports a same-named function
+from deeplens.basics import GEO_SPP, WAVE_RGB, Ray        # noqa: E402
+from deeplens.optics import Lensgroup                     # noqa: E402
+from deeplens.psfnet import PSFNet, ThinLens              # noqa: E402
+from oracle import conv as oconv                          # noqa: E402
+from oracle import psfnet as opsf                         # noqa: E402
+from oracle.lens import OracleLens                        # noqa: E402
+
+DEV = "cuda:0"
+IMG_TOL, PSF_TOL, CONV_ATOL = 1e-4, 2e-3, 2e-6
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def tt(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def lens_path(repo_root, name="rf50mm"):
+    return os.path.join(repo_root, "lenses", name, "lens.json")
+
+
+def test_native_library_is_loaded():
+    lib = _abi.require_gpu()
+    n_cu, lds = C.c_int(), C.c_int()
+    arch = C.create_string_buffer(64)
+    assert lib.aadff_device_info(C.byref(n_cu), C.byref(lds), arch, 64) == 0
+    assert arch.value.decode().startswith("gfx950"), arch.value
+    assert n_cu.value == 256
+    assert any("libaadff.so" in l for l in open("/proc/self/maps"))
+
+
+# ================================================================= G5: convolutions
+@pytest.fixture(scope="module")
+def g5(golden_dir):
+    return np.load(os.path.join(golden_dir, "g5_conv_small.npz"))
+
+
+@pytest.mark.parametrize("tag", list("abcde"))
+def test_render_psf_map_golden(g5, tag):
+    img, pm, grid = tt(g5[f"map_{tag}_img"]).to(DEV), tt(g5[f"map_{tag}_psf"]).to(DEV), int(g5[f"map_{tag}_grid"])
+    out = rp.render_psf_map(img, pm, grid)
+    assert out.is_cuda and out.shape == img.shape
+    assert np.abs(out.cpu().numpy() - g5[f"map_{tag}_out"]).max() <= CONV_ATOL
+
+
+@pytest.mark.parametrize("tag", list("ab"))
+def test_render_psf_golden(g5, tag):
+    out = rp.render_psf(tt(g5[f"uni_{tag}_img"]).to(DEV), tt(g5[f"uni_{tag}_psf"]).to(DEV))
+    assert np.abs(out.cpu().numpy() - g5[f"uni_{tag}_out"]).max() <= CONV_ATOL
+
+
+@pytest.mark.parametrize("tag,ks", [("a", 11), ("b", 5), ("c", 3), ("3d", 5)])
+def test_local_psf_render_golden(g5, tag, ks):
+    out = rp.local_psf_render(tt(g5[f"loc_{tag}_img"]).to(DEV), tt(g5[f"loc_{tag}_psf"]).to(DEV), kernel_size=ks)
+    assert out.shape == g5[f"loc_{tag}_out"].shape
+    assert np.abs(out.cpu().numpy() - g5[f"loc_{tag}_out"]).max() <= CONV_ATOL
+
+
+def test_local_psf_render_high_res_keeps_seams(g5):
+    out = rp.local_psf_render_high_res(tt(g5["hr_img"]).to(DEV), tt(g5["hr_psf"]).to(DEV), patch_size=[16, 20], kernel_size=11)
+    assert np.abs(out.cpu().numpy() - g5["hr_out"]).max() <= CONV_ATOL
+
+
+def test_cpu_tensors_round_trip_through_the_gpu(g5):
+    out = rp.render_psf_map(tt(g5["map_a_img"]), tt(g5["map_a_psf"]), 5)
+    assert not out.is_cuda
+    assert np.abs(out.numpy() - g5["map_a_out"]).max() <= CONV_ATOL
+
+
+@pytest.mark.parametrize("ks", [3, 5, 7, 9, 11, 13, 15, 17, 21, 31])
+def test_render_psf_map_all_kernel_sizes_vs_oracle(ks):
+    """fast path (templated ks) and generic path (17, 31) against the oracle."""
+    rng = np.random.Generator(np.random.PCG64(ks))
+    g, H, W = 3, 70, 101
+    img = tt(rng.random((2, 3, H, W), dtype=np.float32))
+    pm = tt(rng.random((3, g * ks, g * ks), dtype=np.float32)) / (ks * ks)
+    want = oconv.render_psf_map(img, pm, g).numpy()
+    got = rp.render_psf_map(img.to(DEV), pm.to(DEV), g).cpu().numpy()
+    assert np.abs(got - want).max() <= 4e-6
+
+
+@pytest.mark.parametrize("H,W,g", [(480, 640, 11), (11, 11, 11), (33, 1000, 7), (256, 256, 1), (97, 64, 64)])
+def test_render_psf_map_ragged_shapes_vs_oracle(H, W, g):
+    rng = np.random.Generator(np.random.PCG64(H * 7 + W))
+    ks = 11 if min(H, W) > 5 else 3
+    if min(H, W) <= 11:
+        ks = 3
+    img = tt(rng.random((1, 3, H, W), dtype=np.float32))
+    pm = tt(rng.random((3, g * ks, g * ks), dtype=np.float32)) / (ks * ks)
+    want = oconv.render_psf_map(img, pm, g).numpy()
+    got = rp.render_psf_map(img.to(DEV), pm.to(DEV), g).cpu().numpy()
+    assert np.abs(got - want).max() <= 4e-6
+
+
+def test_render_psf_map_1024_golden_crops(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g5_conv_1024.npz"))
+    img = tt(synth_rgb(1024, 1024))[None].to(DEV)
+    out = rp.render_psf_map(img, tt(g["psf_map"]).to(DEV), 11)[0].cpu().numpy()
+    for k in g.files:
+        if k.startswith("crop_"):
+            y, x = (int(v) for v in k[5:].split("_"))
+            assert np.abs(out[:, y:y + 64, x:x + 64] - g[k]).max() <= CONV_ATOL, k
+    assert out.astype(np.float64).sum((1, 2)) == pytest.approx(g["sums"], rel=1e-6)
+
+
+def test_stack_fused_equals_per_slice_bitwise():
+    rng = np.random.Generator(np.random.PCG64(3))
+    S, g, ks, H, W = 10, 11, 11, 1024, 1024
+    img = tt(synth_rgb(H, W))[None].to(DEV)
+    maps = tt(rng.random((S, 3, g * ks, g * ks), dtype=np.float32)).to(DEV) / 121
+    stack = rp.render_psf_map_stack(img, maps, g)
+    assert stack.shape == (1, 3, S, H, W)
+    for s in (0, 4, 9):
+        assert torch.equal(stack[:, :, s], rp.render_psf_map(img, maps[s], g))
+
+
+def test_conv_properties_at_full_size():
+    """Size-independent properties at 1024^2: delta PSF = identity, a normalised PSF keeps a
+    constant image constant (reflect padding), linearity in the image."""
+    g, ks, H, W = 11, 11, 1024, 1024
+    img = tt(synth_rgb(H, W))[None].to(DEV)
+    delta = torch.zeros(3, g, g, ks, ks)
+    delta[..., ks // 2, ks // 2] = 1
+    delta = delta.permute(0, 1, 3, 2, 4).reshape(3, g * ks, g * ks).to(DEV)
+    assert torch.equal(rp.render_psf_map(img, delta, g), img)
+    rng = np.random.Generator(np.random.PCG64(1))
+    p = tt(rng.random((3, g, g, ks, ks), dtype=np.float32))
+    p = (p / p.sum((-1, -2), keepdim=True)).permute(0, 1, 3, 2, 4).reshape(3, g * ks, g * ks).contiguous().to(DEV)
+    const = torch.full((1, 3, H, W), 0.625, device=DEV)
+    assert (rp.render_psf_map(const, p, g) - 0.625).abs().max().item() <= 2e-6
+    a = rp.render_psf_map(img, p, g)
+    b = rp.render_psf_map(img.flip(-1), p, g)
+    ab = rp.render_psf_map(0.5 * img + 0.25 * img.flip(-1), p, g)
+    assert (ab - (0.5 * a + 0.25 * b)).abs().max().item() <= 2e-6
+
+
+def test_conv_argument_errors():
+    img = torch.rand(1, 3, 32, 32, device=DEV)
+    with pytest.raises(AssertionError, match="should be odd"):
+        rp.render_psf_map(img, torch.rand(3, 8, 8, device=DEV), 2)
+    with pytest.raises(RuntimeError, match="grid"):
+        rp.render_psf_map(img, torch.rand(3, 3 * 40, 3 * 40, device=DEV), 40)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        rp.render_psf_map(img.clone().requires_grad_(True), torch.rand(3, 6, 6, device=DEV), 2)
+
+
+# ================================================================= G1: lens scalars, pupils, refocus
+@pytest.mark.parametrize("key", ["rf50mm@1024x1024", "rf50mm@480x640", "50mm_f2.8@1024x1024"])
+def test_lens_scalars_and_pupils(golden_dir, repo_root, key):
+    g = json.load(open(os.path.join(golden_dir, "g1_scalars.json")))[key]
+    name, res = key.split("@")
+    lens = Lensgroup(lens_path(repo_root, name), sensor_res=tuple(int(v) for v in res.split("x")), device=DEV)
+    for k in ("d_sensor", "hfov", "foclen", "fnum"):
+        assert getattr(lens, k) == pytest.approx(g["load"][k], rel=1e-5), k
+    assert lens.aper_idx == g["load"]["aper_idx"]
+    assert lens.entrance_pupil() == pytest.approx(tuple(g["entrance_pupil"]), rel=1e-5)
+    assert lens.exit_pupil() == pytest.approx(tuple(g["exit_pupil"]), rel=1e-5)
+    assert lens.entrance_pupil(shrink_pupil=True) == pytest.approx(tuple(g["entrance_pupil_shrunk"]), rel=1e-5)
+
+
+@pytest.mark.parametrize("name", ["rf50mm", "50mm_f2.8"])
+def test_refocus_seeded(golden_dir, repo_root, name):
+    g = json.load(open(os.path.join(golden_dir, "g1_scalars.json")))[f"{name}@1024x1024"]["refocus"]
+    lens = Lensgroup(lens_path(repo_root, name), sensor_res=(1024, 1024), device=DEV)
+    for f, want in g.items():
+        torch.manual_seed(0)
+        lens.refocus(float(f))
+        for k in ("d_sensor", "hfov", "foclen", "fnum"):
+            assert getattr(lens, k) == pytest.approx(want[k], rel=1e-5), (f, k)
+
+
+# ================================================================= G2/G3: trace and splat
+@pytest.fixture(scope="module")
+def g23(golden_dir):
+    return np.load(os.path.join(golden_dir, "g2_g3_trace_splat.npz"))
+
+
+@pytest.fixture(scope="module")
+def lens_foc2000(repo_root):
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(1024, 1024), device=DEV)
+    torch.manual_seed(0)
+    lens.refocus(-2000.0)
+    return lens
+
+
+def test_per_surface_states(g23, lens_foc2000):
+    """Surface by surface through Aspheric.ray_reaction -> aadff_trace_rays."""
+    ray = Ray(tt(g23["ray_o0"]).clone(), tt(g23["ray_d0"]).clone(), wvln=0.589, device=DEV)
+    for i, s in enumerate(lens_foc2000.surfaces):
+        ray = s.ray_reaction(ray)
+        ra = ray.ra.cpu().numpy()
+        assert np.array_equal(ra, g23["states_ra"][i]), f"surface {i} validity"
+        alive = ra > 0
+        # positions carry |t|*ulp error: t~1500 mm at surface 0, mm-scale after
+        tol = 4e-4 if i == 0 else 2e-5
+        assert np.abs(ray.o.cpu().numpy() - g23["states_o"][i])[alive].max() <= tol, f"surface {i} o"
+        assert np.abs(ray.d.cpu().numpy() - g23["states_d"][i])[alive].max() <= 2e-6, f"surface {i} d"
+        # dead rays keep their last state (the reference leaves them in place too)
+        assert np.abs(ray.o.cpu().numpy() - g23["states_o"][i])[~alive].max(initial=0) <= 4e-4
+
+
+def _trace_points(lens, pobj, u_theta, u_r, spp, wvln=0.589, shrunk=False):
+    pz, pr = lens.entrance_pupil(shrink_pupil=shrunk)
+    N = pobj.shape[0]
+    o = torch.empty((spp, N, 3), device=DEV)
+    d = torch.empty((spp, N, 3), device=DEV)
+    ra = torch.empty((spp, N), device=DEV)
+    _abi.call("aadff_trace_points", _abi.ptr(pobj.to(DEV).contiguous()), N, _abi.ptr(u_theta.to(DEV)), _abi.ptr(u_r.to(DEV)),
+              spp, float(pz), float(pr), _abi.ptr(lens._table([wvln])), len(lens.surfaces), _abi.ptr(lens._state_device()),
+              _abi.ptr(o), _abi.ptr(d), _abi.ptr(ra), _abi.stream_ptr(torch.device(DEV)))
+    return o, d, ra
+
+
+def test_sensor_hits_from_stored_uniforms(g23, lens_foc2000):
+    lens = lens_foc2000
+    assert lens.d_sensor == pytest.approx(float(g23["d_sensor"]), rel=1e-5)
+    o, d, ra = _trace_points(lens, tt(g23["points_obj"]), tt(g23["u_theta"]), tt(g23["u_r"]), 256)
+    ra_h, want_ra = ra.cpu().numpy() > 0, g23["sensor_ra"] > 0
+    assert (ra_h != want_ra).mean() <= 1e-4
+    both = ra_h & want_ra
+    err = np.abs(o[..., :2].cpu().numpy() - g23["sensor_xy"])[both]
+    assert err.mean() <= 2e-5 and err.max() <= 5e-4          # fp32-vs-fp64 floor: mean 5e-6, max 4e-5 (Appendix D)
+    assert np.abs(d.cpu().numpy() - g23["final_d"])[both].max() <= 5e-6
+
+
+def test_splat_matches_reference_histogram(g23, lens_foc2000):
+    """aadff_psf_splat on the reference's own sensor hits: isolates the histogram."""
+    o = torch.zeros((256, 121, 3))
+    o[..., :2] = tt(g23["sensor_xy"])
+    ray = Ray.__new__(Ray)
+    ray.o, ray.ra, ray.d = o.to(DEV), tt(g23["sensor_ra"]).float().to(DEV), None
+    raw = dl_mc.forward_integral(ray, ps=float(g23["pixel_size"]), ks=11, pointc_ref=tt(g23["centre"]).to(DEV))
+    assert np.abs(raw.cpu().numpy() - g23["psf_raw"]).max() <= 2e-4      # atomics: sum order
+    nrm = raw / raw.sum((-1, -2), keepdim=True)
+    assert rel_l2(nrm.cpu().numpy(), g23["psf"]) <= 1e-5
+
+
+def test_chief_ray_centres_and_psfs_from_stored_uniforms(g23, lens_foc2000):
+    """Fused kernel with the stored draws: centres and PSFs vs the reference."""
+    lens = lens_foc2000
+    N, spp, ks = 121, 256, 11
+    u_main = torch.stack((tt(g23["u_theta"]), tt(g23["u_r"])))[None].contiguous().to(DEV)        # [L=1,2,spp]
+    u_chief = torch.stack((tt(g23["c_theta"]), tt(g23["c_r"])))[None].contiguous().to(DEV)
+    psf = torch.empty((N, 1, ks, ks), device=DEV)
+    cen = torch.empty((1, N, 2), device=DEV)
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _abi.call("aadff_psf_points", _abi.ptr(tt(g23["points"]).to(DEV)), 1, N, 1, _abi.ptr(lens._table([0.589])),
+              _abi.ptr(lens._table([0.589])), lens._lens_const(), _abi.ptr(lens._state_device()), _abi.ptr(u_main), spp,
+              _abi.ptr(u_chief), GEO_SPP, ks, 1, 0, _abi.ptr(psf), _abi.ptr(cen), _abi.ptr(flags),
+              _abi.stream_ptr(torch.device(DEV)))
+    assert int(flags.item()) == 0
+    assert np.abs(cen[0].cpu().numpy() - g23["centre"]).max() <= 2e-5      # mm; pixel = 0.03 mm
+    assert rel_l2(psf[:, 0].cpu().numpy(), g23["psf"]) <= PSF_TOL
+
+
+def test_backward_trace_entrance_pupil_rays(g23, lens_foc2000):
+    lens = lens_foc2000
+    M = 32
+    aper = lens.surfaces[lens.aper_idx]
+    phi = torch.arange(-0.5, 0.5, 1.0 / M)
+    o = torch.tensor([[aper.r, 0, aper.d.item()]]).repeat(M, 1).to(torch.float32)
+    d = torch.stack((torch.sin(phi), torch.zeros_like(phi), -torch.cos(phi)), axis=-1)
+    ray, valid, _ = lens.trace(Ray(o, d, device=DEV), lens_range=range(0, lens.aper_idx))
+    assert np.array_equal(ray.ra.cpu().numpy(), g23["back_ra"])
+    alive = g23["back_ra"] > 0
+    assert np.abs(ray.o.cpu().numpy() - g23["back_o"])[alive].max() <= 2e-5
+    assert np.abs(ray.d.cpu().numpy() - g23["back_d"])[alive].max() <= 2e-6
+
+
+# ================================================================= G4: psf_map end to end (seeded host RNG)
+@pytest.mark.parametrize("name,res,foc,depth,spp", [("rf50mm", (1024, 1024), -2000.0, -1500.0, 2048),
+                                                   ("50mm_f2.8", (256, 256), -1000.0, -1250.0, 512)])
+def test_psf_map_seeded(golden_dir, repo_root, name, res, foc, depth, spp):
+    g = np.load(os.path.join(golden_dir, "g4_psf_map.npz"))
+    key = name.replace(".", "_")
+    lens = Lensgroup(lens_path(repo_root, name), sensor_res=res, device=DEV)
+    torch.manual_seed(0)
+    lens.refocus(foc)
+    pm = lens.psf_map(depth=depth, grid=11, ks=11, spp=spp)
+    assert pm.shape == (3, 121, 121) and pm.is_cuda
+    assert lens.d_sensor == pytest.approx(float(g[f"{key}_d_sensor"]), rel=1e-5)
+    assert rel_l2(pm.cpu().numpy(), g[f"{key}_psf_map"]) <= PSF_TOL
+    # and the map renders the same image as the reference's map (the 1e-4 budget applies to the IMAGE)
+    H, W = (256, 256)
+    img = tt(synth_rgb(H, W))[None]
+    want = oconv.render_psf_map(img, tt(g[f"{key}_psf_map"]), 11).numpy()
+    got = rp.render_psf_map(img.to(DEV), pm, 11).cpu().numpy()
+    assert rel_l2(got, want) <= IMG_TOL
+
+
+def test_psf_single_point_and_nocenter(golden_dir, repo_root):
+    g = np.load(os.path.join(golden_dir, "g4_psf_map.npz"))
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(480, 640), device=DEV)
+    torch.manual_seed(3)
+    p = lens.psf([0.3, -0.4, -1200.0], ks=11, spp=1024)
+    assert p.shape == (11, 11)
+    assert rel_l2(p.cpu().numpy(), g["single_point_psf"]) <= PSF_TOL
+    torch.manual_seed(3)
+    p = lens.psf(torch.tensor([[0.3, -0.4, -1200.0], [0.0, 0.0, -3000.0]]), ks=11, spp=1024, center=False)
+    assert rel_l2(p.cpu().numpy(), g["nocenter_psf"]) <= PSF_TOL
+
+
+def test_psf_rgb_layout_matches_psf_map(repo_root):
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(256, 256), device=DEV)
+    torch.manual_seed(1)
+    pm = lens.psf_map(depth=-1500.0, grid=3, ks=11, spp=256)
+    torch.manual_seed(1)
+    pts = lens.point_source_grid(depth=-1500.0, grid=3).reshape(-1, 3)
+    rgb = lens.psf_rgb(pts, ks=11, spp=256)
+    assert rgb.shape == (9, 3, 11, 11)
+    tiled = rgb.reshape(3, 3, 3, 11, 11).permute(2, 0, 3, 1, 4).reshape(3, 33, 33)
+    assert torch.equal(tiled, pm)
+    assert pm.sum().item() == pytest.approx(27.0, rel=1e-5)      # every PSF sums to 1
+
+
+# ================================================================= G8: M1 focal stack (config 0 scale)
+def test_focal_stack_m1_golden(golden_dir, repo_root):
+    g = np.load(os.path.join(golden_dir, "g8_stack_m1.npz"))
+    H = W = 256
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(H, W), device=DEV)
+    img = tt(synth_rgb(H, W))[None].to(DEV)
+    torch.manual_seed(0)
+    stack, maps = render_focal_stack_m1(lens, img, float(g["dbar"]), g["fds"], grid=11, ks=11, spp=GEO_SPP, return_maps=True)
+    assert stack.shape == (1, 3, 5, H, W)
+    s = stack[0].cpu().numpy()
+    assert rel_l2(maps.cpu().numpy(), g["psf_maps"]) <= PSF_TOL
+    assert rel_l2(s[:, :, 96:160, 96:160], g["crop"]) <= IMG_TOL
+    assert rel_l2(s[:, :, 64:192, 64:192], g["centre_f16"].astype(np.float32)) <= 5e-4     # fp16 fixture
+    assert s.astype(np.float64).sum((2, 3)) == pytest.approx(g["sums"], rel=1e-4)
+    # the lens is left focused at the last distance, as the reference loop leaves it
+    assert lens.d_sensor == pytest.approx(float(g["d_sensor"][-1]), rel=1e-5)
+
+
+def test_focal_stack_m1_equals_sequential_api(repo_root):
+    """The 3-launch batched stack == the reference-shaped per-slice loop on the same RNG stream."""
+    H = W = 128
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(H, W), device=DEV)
+    img = tt(synth_rgb(H, W))[None].to(DEV)
+    fds = [-600.0, -900.0, -1500.0, -4000.0]
+    torch.manual_seed(7)
+    batched = render_focal_stack_m1(lens, img, -1200.0, fds, grid=5, ks=11, spp=512).clone()
+    torch.manual_seed(7)
+    sl = []
+    for f in fds:
+        lens.refocus(f)
+        sl.append(rp.render_psf_map(img, lens.psf_map(depth=-1200.0, grid=5, ks=11, spp=512), 5))
+    assert torch.equal(batched, torch.stack(sl, dim=2))
+
+
+def test_focal_stack_m1_vs_oracle_full_pipeline(repo_root):
+    """Whole M1 pipeline (refocus -> psf_map -> conv) vs the oracle at a small size, second lens."""
+    H = W = 96
+    img = tt(synth_rgb(H, W, seed=5))[None]
+    fds = [-700.0, -1500.0, -3000.0, -6000.0]
+    ora = OracleLens(lens_path(repo_root, "50mm_f2.8"), sensor_res=(H, W))
+    torch.manual_seed(11)
+    want, _ = opsf.focal_stack_m1(ora, img, -1800.0, fds, grid=5, ks=11, spp=1024)
+    lens = Lensgroup(lens_path(repo_root, "50mm_f2.8"), sensor_res=(H, W), device=DEV)
+    torch.manual_seed(11)
+    got = render_focal_stack_m1(lens, img.to(DEV), -1800.0, fds, grid=5, ks=11, spp=1024)
+    assert rel_l2(got.cpu().numpy(), want.numpy()) <= IMG_TOL
+
+
+# ================================================================= G6/G7: PSFNet (M2) and thin lens
+@pytest.fixture(scope="module")
+def g67(golden_dir):
+    return np.load(os.path.join(golden_dir, "g6_g7_psfnet.npz"))
+
+
+@pytest.fixture(scope="module")
+def psfnet64(repo_root):
+    net = PSFNet(lens_path(repo_root), sensor_res=(64, 64), kernel_size=11, device=DEV)
+    net.psfnet.load_state_dict({k: tt(v) for k, v in mlp_state_dict(seed=4321).items()})
+    return net
+
+
+def test_mlp_golden(g67, psfnet64):
+    with torch.no_grad():
+        y = psfnet64.psfnet(tt(g67["mlp_in"]).to(DEV))
+    assert rel_l2(y.cpu().numpy(), g67["mlp_out"]) <= 1e-5
+
+
+def test_psfnet_render_golden(g67, psfnet64):
+    img = tt(synth_rgb(64, 64, seed=11))[None].to(DEV)
+    depth = -tt(synth_depth_mm(64, 64, seed=12))[None, None].to(DEV)
+    for i, f in enumerate(g67["render_fds"]):
+        out = psfnet64.render(img, depth, torch.tensor([float(f)], device=DEV))
+        assert rel_l2(out.cpu().numpy(), g67["render_out"][i:i + 1]) <= IMG_TOL, f
+    out3 = psfnet64.render(img[0], depth[0, 0], -1500.0)
+    assert rel_l2(out3.cpu().numpy(), g67["render3d_out"]) <= IMG_TOL
+    img2 = torch.cat((img, torch.flip(img, [-1])), 0)
+    depth2 = torch.cat((depth, torch.flip(depth, [-2])), 0)
+    outb = psfnet64.render(img2, depth2, torch.tensor([-700.0, -2500.0], device=DEV))
+    assert rel_l2(outb.cpu().numpy(), g67["render_b2_out"]) <= IMG_TOL
+
+
+def test_focal_stack_m2_vs_oracle(psfnet64):
+    sd = {k: tt(v) for k, v in mlp_state_dict(seed=4321).items()}
+    img = tt(synth_rgb(64, 64, seed=11))[None]
+    depth_m = tt(synth_depth_mm(64, 64, seed=12))[None, None] / 1e3
+    want = opsf.focal_stack_m2(sd, img, depth_m, 5).numpy()
+    got, fds = render_focal_stack_m2(psfnet64, img.to(DEV), depth_m.to(DEV), 5)
+    assert got.shape == (1, 3, 5, 64, 64)
+    assert rel_l2(got.cpu().numpy(), want) <= IMG_TOL
+
+
+def test_thinlens_golden(g67):
+    img = tt(synth_rgb(64, 64, seed=11))[None].to(DEV)
+    depth = -tt(synth_depth_mm(64, 64, seed=12))[None, None].to(DEV)
+    thin = ThinLens(foc_len=50.0, fnum=1.8, kernel_size=11, sensor_size=[24.0, 24.0], sensor_res=(64, 64))
+    out = thin.render(img, depth, torch.tensor([-1500.0], device=DEV))
+    assert rel_l2(out.cpu().numpy(), g67["thin_out"]) <= IMG_TOL
+
+
+def test_get_training_data_shapes_and_normalisation(repo_root):
+    net = PSFNet(lens_path(repo_root), sensor_res=(480, 640), kernel_size=11, device=DEV)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    inp, psf = net.get_training_data(bs=128, spp=4096)
+    assert inp.shape == (128, 4) and psf.shape == (128, 121)
+    s = psf.sum(-1).cpu().numpy()
+    ok = np.isfinite(s)
+    assert ok.mean() > 0.9 and np.abs(s[ok] - 1).max() <= 1e-5

@@ -1,0 +1,124 @@
+"""CPU: host-side logic of the product package (no kernels run): glass indices, surface
+packing, lens loading, RNG call order, focus-distance rule, and the loud failure when
+no GPU is present."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from aadff import _abi
+from aadff.focal_stack import draw_stack_uniforms, select_focus_dist, shard_units
+from aadff.sampling import HostSampler
+from aadff.synth import synth_depth_mm
+from deeplens.basics import WAVE_RGB, Material
+from deeplens.optics import Lensgroup
+from deeplens.utils import make_grid
+from oracle import psfnet as opsf
+from oracle.lens import OracleLens
+
+
+def lens_path(repo_root, name="rf50mm"):
+    return os.path.join(repo_root, "lenses", name, "lens.json")
+
+
+def test_material_ior_matches_reference(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "g1_scalars.json")))
+    for key in ("rf50mm@1024x1024", "50mm_f2.8@1024x1024"):
+        for m, vals in g[key]["ior"].items():
+            assert [float(Material(m).ior(w)) for w in WAVE_RGB] == pytest.approx(vals, abs=1e-14), m
+    with pytest.raises(KeyError):
+        Material("unobtainium")
+
+
+def test_lens_loads_on_cpu_without_kernels(repo_root, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "g1_scalars.json")))["rf50mm@480x640"]["load"]
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(480, 640), post_computation=False, device="cpu")
+    assert len(lens.surfaces) == 12 and lens.aper_idx == g["aper_idx"]
+    assert lens.pixel_size == pytest.approx(g["pixel_size"], abs=1e-15)
+    assert list(lens.sensor_size) == pytest.approx(g["sensor_size"], abs=1e-12)
+    assert lens.d_sensor == pytest.approx(g["d_sensor"], abs=1e-6)
+    kinds = [s.kind() for s in lens.surfaces]
+    assert kinds == [1, 1, 1, 1, 1, 0, 1, 1, 2, 2, 1, 1]
+
+
+def test_surface_packing_follows_reference_rounding(repo_root):
+    lens = Lensgroup(lens_path(repo_root), post_computation=False, device="cpu")
+    ora = OracleLens(lens_path(repo_root))
+    for i, (s, o) in enumerate(zip(lens.surfaces, ora.surfaces)):
+        for w in WAVE_RGB:
+            p = s.pack(w)
+            assert p.d == o.d.item() and p.c == o.c.item() and p.k == o.k.item()
+            assert p.r2 == np.float32(o.r ** 2)
+            ef = o.mat1.ior(w) / o.mat2.ior(w)
+            assert p.eta_fwd == np.float32(ef) and p.eta_fwd2 == np.float32(ef ** 2)
+            assert p.eta_bwd == np.float32(1 / ef if False else o.mat2.ior(w) / o.mat1.ior(w))
+            if p.kind != 0:
+                assert p.r2_shape == ((1 - 1e-9) / o.c ** 2 / (1 + o.k)).item()
+                assert p.d_plus_roc == (o.d + 1 / o.c).item()
+            if p.kind == 2:
+                assert p.n_ai == 6 and [p.ai[j] for j in range(6)] == [a.item() for a in o.ai]
+    stop = lens.surfaces[5].pack(0.589)
+    assert stop.kind == 0 and stop.refract_fwd == 0 and stop.refract_bwd == 0
+
+
+def test_stack_uniform_order_equals_reference_call_order():
+    """draw_stack_uniforms must consume the host generator exactly as the reference's
+    per-slice refocus -> psf_map loop does."""
+    S, spp = 3, 512
+    torch.manual_seed(5)
+    uf, um, uc = draw_stack_uniforms(HostSampler(), S, spp)
+    torch.manual_seed(5)
+    for s in range(S):
+        assert torch.equal(uf[s, 0], torch.rand(2048)) and torch.equal(uf[s, 1], torch.rand(2048))
+        for l in range(3):
+            assert torch.equal(um[s, l, 0], torch.rand(spp)) and torch.equal(um[s, l, 1], torch.rand(spp))
+            assert torch.equal(uc[s, l, 0], torch.rand(2048)) and torch.equal(uc[s, l, 1], torch.rand(2048))
+
+
+def test_select_focus_dist_matches_oracle():
+    d = torch.from_numpy(synth_depth_mm(32, 48)).reshape(1, 1, 32, 48) / 1e3
+    d = torch.cat((d, d.flip(-1) * 0.5), 0)
+    d[0, 0, :4, :4] = 0.0          # invalid pixels are ignored by the min
+    assert torch.equal(select_focus_dist(d, 6), opsf.select_focus_dist_linear(d, 6))
+    with pytest.raises(AssertionError):
+        select_focus_dist(d, 3)
+
+
+def test_make_grid_is_row_major_tiling():
+    t = torch.arange(6 * 1 * 2 * 2, dtype=torch.float32).reshape(6, 1, 2, 2)
+    g = make_grid(t, nrow=3, padding=0)
+    assert g.shape == (3, 4, 6)
+    assert torch.equal(g[0, 0:2, 2:4], t[1, 0]) and torch.equal(g[2, 2:4, 0:2], t[3, 0])
+
+
+def test_shard_units_partition():
+    for world in (1, 2, 8):
+        got = sorted(u for r in range(world) for u in shard_units(160, r, world))
+        assert got == list(range(160))
+    assert shard_units(160, 3, 8)[:3] == [3, 11, 19] and len(shard_units(160, 3, 8)) == 20
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_fails_loudly_without_gpu(repo_root):
+    from deeplens.render_psf import local_psf_render, render_psf_map
+    img = torch.rand(1, 3, 16, 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        render_psf_map(img, torch.rand(3, 6, 6), 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        local_psf_render(img, torch.rand(1, 16, 16, 3, 3), 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Lensgroup(lens_path(repo_root), device="cpu")      # post_computation needs the trace kernel
+
+
+def test_reference_assertions_are_kept():
+    from deeplens.render_psf import render_psf_map
+    with pytest.raises(AssertionError, match="Input image should be"):
+        render_psf_map(torch.rand(3, 16, 16), torch.rand(3, 6, 6), 2)
+    with pytest.raises(AssertionError, match="divisible by grid"):
+        render_psf_map(torch.rand(1, 3, 16, 16), torch.rand(3, 7, 7), 2)
+    with pytest.raises(AssertionError, match="should be odd"):
+        render_psf_map(torch.rand(1, 3, 16, 16), torch.rand(3, 8, 8), 2)
+    with pytest.raises(AssertionError, match="same channel"):
+        render_psf_map(torch.rand(1, 1, 16, 16), torch.rand(3, 6, 6), 2)

@@ -304,3 +304,30 @@ def test_g8_focal_stack_m1(golden_dir, repo_root):
     assert np.abs(s[:, :, 96:160, 96:160] - g["crop"]).max() <= ATOL
     assert np.abs(s[:, :, 64:192, 64:192] - g["centre_f16"].astype(np.float32)).max() <= 1e-3
     assert s.astype(np.float64).sum((2, 3)) == pytest.approx(g["sums"], rel=1e-7)
+
+
+# ----------------------------------------------------------------- plain-C restatement (oracle/conv_ref.c)
+def _c_oracle(repo_root):
+    import ctypes
+    p = os.path.join(repo_root, "oracle", "_build", "liboracle_conv.so")
+    if not os.path.exists(p):
+        pytest.skip("oracle/_build/liboracle_conv.so not built (run __graft_entry__.build())")
+    return ctypes.CDLL(p)
+
+
+def test_c_oracle_matches_golden(g5, repo_root):
+    import ctypes
+    lib = _c_oracle(repo_root)
+    fp = ctypes.POINTER(ctypes.c_float)
+    for tag in "abcd":
+        img, pm, grid = g5[f"map_{tag}_img"], g5[f"map_{tag}_psf"], int(g5[f"map_{tag}_grid"])
+        out = np.zeros_like(img)
+        B, Cn, H, W = img.shape
+        lib.oracle_render_psf_map(img.ctypes.data_as(fp), pm.ctypes.data_as(fp), out.ctypes.data_as(fp), B, Cn, H, W, grid, pm.shape[1] // grid)
+        assert np.abs(out - g5[f"map_{tag}_out"]).max() <= 3e-6, tag
+    for tag, ks in (("a", 11), ("b", 5), ("c", 3)):
+        img, p = g5[f"loc_{tag}_img"], g5[f"loc_{tag}_psf"]
+        out = np.zeros_like(img)
+        B, Cn, H, W = img.shape
+        lib.oracle_local_psf_render(img.ctypes.data_as(fp), np.ascontiguousarray(p).ctypes.data_as(fp), out.ctypes.data_as(fp), B, Cn, H, W, ks)
+        assert np.abs(out - g5[f"loc_{tag}_out"]).max() <= 3e-6, tag
