@@ -39,7 +39,7 @@ class LensConst(C.Structure):
 
 assert C.sizeof(Surface) == 96 and C.sizeof(LensState) == 32 and C.sizeof(LensConst) == 52
 
-_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 
 # name -> argtypes; every function returns int (0 = ok).  Kept in one table so the
 # symbol-export test can walk it (tests/test_abi_symbols.py).
@@ -51,8 +51,8 @@ PROTOTYPES = {
     "aadff_trace_rays": [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P],
     "aadff_trace_points": [_P, _I, _P, _P, _I, _F, _F, _P, _I, _P, _P, _P, _P, _P],
     "aadff_psf_splat": [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P],
-    "aadff_psf_points": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P],
-    "aadff_refocus": [_P, _I, _P, _I, _P, LensConst, _P, _P],
+    "aadff_psf_points": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _L, _L, _P, _I, _L, _L, _I, _I, _I, _P, _P, _P, _P],
+    "aadff_refocus": [_P, _I, _P, _I, _L, _P, LensConst, _P, _P],
     "aadff_post_computation": [_I, _P, LensConst, _P, _P],
 }
 OTHER_SYMBOLS = ["aadff_abi_version", "aadff_last_error", "aadff_device_info"]

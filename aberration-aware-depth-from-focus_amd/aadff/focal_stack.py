@@ -29,22 +29,29 @@ def select_focus_dist(depth, num, mode="linear"):
     return torch.sort(f, dim=-1)[0]
 
 
+def stack_uniform_layout(spp, L=3, spp_chief=GEO_SPP, spp_focus=GEO_SPP):
+    """Flat per-slice layout of the uniforms in the reference's host-RNG draw order (SURVEY.md
+    Appendix B): [focus theta, focus r, (main theta, main r, chief theta, chief r) x L].
+    Returns (floats per slice, offset of main, offset of chief, stride between wavelengths)."""
+    per_l = 2 * spp + 2 * spp_chief
+    return 2 * spp_focus + L * per_l, 2 * spp_focus, 2 * spp_focus + 2 * spp, per_l
+
+
 def draw_stack_uniforms(sampler, S, spp, L=3, spp_chief=GEO_SPP, spp_focus=GEO_SPP):
-    """Uniforms for an S-slice M1 stack in the reference's host-RNG order (SURVEY.md
-    Appendix B): per slice refocus (theta, r), then per wavelength main (theta, r) and
-    chief (theta, r).  Returns host tensors (u_focus [S,2,spp_focus], u_main [S,L,2,spp],
-    u_chief [S,L,2,spp_chief])."""
-    per = [spp_focus, spp_focus] + [spp, spp, spp_chief, spp_chief] * L
-    flat = sampler.rand_block(per * S).reshape(S, -1)
+    """Views (u_focus [S,2,spp_focus], u_main [S,L,2,spp], u_chief [S,L,2,spp_chief]) of ONE
+    flat draw of S slices (used by tests; the renderer consumes the flat block through strides)."""
+    per, o_main, o_chief, per_l = stack_uniform_layout(spp, L, spp_chief, spp_focus)
+    flat = sampler.rand_block([per * S]).reshape(S, per)
     u_focus = flat[:, :2 * spp_focus].reshape(S, 2, spp_focus)
-    rest = flat[:, 2 * spp_focus:].reshape(S, L, 2 * spp + 2 * spp_chief)
-    u_main = rest[:, :, :2 * spp].reshape(S, L, 2, spp)
-    u_chief = rest[:, :, 2 * spp:].reshape(S, L, 2, spp_chief)
-    return u_focus.contiguous(), u_main.contiguous(), u_chief.contiguous()
+    rest = flat[:, 2 * spp_focus:].reshape(S, L, per_l)
+    return u_focus, rest[:, :, :2 * spp].reshape(S, L, 2, spp), rest[:, :, 2 * spp:].reshape(S, L, 2, spp_chief)
 
 
 class StackPlan:
-    """Pre-allocated device buffers + cached tables for repeated M1 stacks of one shape."""
+    """Pre-allocated device buffers, cached lens tables and a pinned-host ring for the pupil
+    samples of repeated M1 stacks of one shape.  The ring lets the host draw step i+1's
+    samples while the GPU renders step i (copies are asynchronous from pinned memory)."""
+    RING = 3
 
     def __init__(self, lens, S, H, W, B=1, C_=3, grid=11, ks=11, spp=GEO_SPP):
         dev = lens._gpu()
@@ -58,34 +65,68 @@ class StackPlan:
         self.lc = lens._lens_const()
         self.pts_xy = lens.point_source_grid(depth=0.0, grid=grid).reshape(-1, 3)
         self.conv_events = None      # optional (start, end) torch.cuda.Event pair around the conv launch
+        self.per, self.o_main, self.o_chief, self.per_l = stack_uniform_layout(spp)
+        self.u_dev = [torch.empty(S * self.per, dtype=torch.float32, device=dev) for _ in range(self.RING)]
+        self.u_pin = [torch.empty(S * self.per, dtype=torch.float32).pin_memory() for _ in range(self.RING)]
+        self.u_evt = [None] * self.RING
+        self.turn = 0
+        self._geo_key, self._dep, self._pts = None, None, None
+
+    def uniforms(self, sampler):
+        """Device block of this step's uniforms, drawn in the reference's order."""
+        k = self.turn % self.RING
+        self.turn += 1
+        n = self.S * self.per
+        if sampler.on_device:
+            self.u_dev[k] = sampler.rand_block([n])
+            return self.u_dev[k]
+        if self.u_evt[k] is not None:
+            self.u_evt[k].synchronize()          # the copy that last used this pinned slot has finished
+        if type(sampler).__name__ == "HostSampler":
+            torch.rand(n, out=self.u_pin[k])     # == the reference's call-by-call draws (same generator stream)
+        else:
+            self.u_pin[k].copy_(sampler.rand_block([n]))
+        self.u_dev[k].copy_(self.u_pin[k], non_blocking=True)
+        self.u_evt[k] = torch.cuda.Event()
+        self.u_evt[k].record()
+        return self.u_dev[k]
+
+    def geometry(self, focus, depth_plane_mm):
+        key = (tuple(focus), float(depth_plane_mm))
+        if key != self._geo_key:
+            pts = self.pts_xy.clone()
+            pts[:, 2] = float(depth_plane_mm)
+            self._pts = pts.unsqueeze(0).repeat(self.S, 1, 1).contiguous().to(self.dev)
+            self._dep = torch.tensor(focus, dtype=torch.float32).to(self.dev)
+            self._geo_key = key
+        return self._dep, self._pts
 
 
 @torch.no_grad()
 def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, spp=GEO_SPP, plan=None,
                           return_maps=False, update_lens=True):
     """[B,C,S,H,W] aberrated focal stack of `img` [B,C,H,W] for S focus distances (mm < 0),
-    all scene points on one depth plane (mm < 0).  No host synchronisation inside."""
+    all scene points on one depth plane (mm < 0).  Three kernel launches, no host
+    synchronisation; with a reused `plan` the output buffer is reused too."""
     focus = [float(f) for f in np.asarray(focus_mm, dtype=np.float64).reshape(-1)]
     S = len(focus)
     B, C_, H, W = img.shape
-    assert list(lens.sensor_res) == [H, W] or tuple(lens.sensor_res) == (H, W), "lens.sensor_res must match the image"
+    assert tuple(lens.sensor_res) == (H, W), "lens.sensor_res must match the image"
     if plan is None:
         plan = StackPlan(lens, S, H, W, B, C_, grid, ks, spp)
     dev = plan.dev
-    u_focus, u_main, u_chief = draw_stack_uniforms(lens.sampler, S, spp)
-    u_focus, u_main, u_chief = (u.to(dev, non_blocking=True) for u in (u_focus, u_main, u_chief))
-    dep = torch.tensor(focus, dtype=torch.float32).to(dev, non_blocking=True)
-    pts = plan.pts_xy.clone()
-    pts[:, 2] = float(depth_plane_mm)
-    pts = pts.unsqueeze(0).repeat(S, 1, 1).contiguous().to(dev, non_blocking=True)
-    x = _abi.f32c(img, dev)
-    N = grid * grid
     with torch.cuda.device(dev):
+        u = plan.uniforms(lens.sampler)
+        dep, pts = plan.geometry(focus, depth_plane_mm)
+        x = _abi.f32c(img, dev)
+        N = grid * grid
+        ub = u.data_ptr()
         st = _abi.stream_ptr(dev)
-        _abi.call("aadff_refocus", _abi.ptr(dep), S, _abi.ptr(u_focus), GEO_SPP, _abi.ptr(plan.tab_green), plan.lc,
-                  _abi.ptr(plan.states), st)
+        _abi.call("aadff_refocus", _abi.ptr(dep), S, C.c_void_p(ub), GEO_SPP, plan.per, _abi.ptr(plan.tab_green),
+                  plan.lc, _abi.ptr(plan.states), st)
         _abi.call("aadff_psf_points", _abi.ptr(pts), S, N, 3, _abi.ptr(plan.tab_rgb), _abi.ptr(plan.tab_green),
-                  plan.lc, _abi.ptr(plan.states), _abi.ptr(u_main), spp, _abi.ptr(u_chief), GEO_SPP, ks, 1, 1,
+                  plan.lc, _abi.ptr(plan.states), C.c_void_p(ub + 4 * plan.o_main), spp, plan.per, plan.per_l,
+                  C.c_void_p(ub + 4 * plan.o_chief), GEO_SPP, plan.per, plan.per_l, ks, 1, 1,
                   _abi.ptr(plan.psf_maps), None, _abi.ptr(plan.flags), st)
         if plan.conv_events is not None:
             plan.conv_events[0].record()

@@ -312,9 +312,9 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
                                                           const aadff_surface_t* __restrict__ surf_chief,
                                                           aadff_lens_const_t lc,
                                                           const aadff_lens_state_t* __restrict__ states,
-                                                          const float* __restrict__ u_main, int spp,
-                                                          const float* __restrict__ u_chief, int spp_chief,
-                                                          SplatGeom g, int centre_mode, int map_grid, float* psf,
+                                                          const float* __restrict__ u_main, int spp, long main_ss,
+                                                          long main_sl, const float* __restrict__ u_chief,
+                                                          int spp_chief, long chief_ss, long chief_sl, SplatGeom g, int centre_mode, int map_grid, float* psf,
                                                           float* centre_out, int* flags) {
     __shared__ float hist[AADFF_MAX_KS * AADFF_MAX_KS];
     __shared__ float red[3 * 4];
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
 
     float cx, cy;
     if (centre_mode == 1) {
-        const float* ut = u_chief + ((size_t)(s * L + l) * 2) * spp_chief;
+        const float* ut = u_chief + (size_t)s * chief_ss + (size_t)l * chief_sl;
         const float* ur = ut + spp_chief;
         float sx = 0.f, sy = 0.f, sw = 0.f;
         for (int i = tid; i < spp_chief; i += 256) {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
     }
 
     const aadff_surface_t* tab = surf_main + (size_t)l * lc.n_surf;
-    const float* ut = u_main + ((size_t)(s * L + l) * 2) * spp;
+    const float* ut = u_main + (size_t)s * main_ss + (size_t)l * main_sl;
     const float* ur = ut + spp;
     for (int i = tid; i < spp; i += 256) {
         float x2, y2;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
 //   deeplens/optics.py:1155-1180 (refocus), :1187-1217 (calc_fov), :178-187, :1097-1102
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void refocus_kernel(const float* __restrict__ depth, const float* __restrict__ u,
-                                                       int spp, const aadff_surface_t* __restrict__ surf,
+                                                       int spp, long u_ss, const aadff_surface_t* __restrict__ surf,
                                                        aadff_lens_const_t lc, aadff_lens_state_t* states,
                                                        int do_refocus) {
     __shared__ float red[2 * 4];
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void refocus_kernel(const float* __restrict__ 
     int nan_flag = 0;
     int flags = 0;
     if (do_refocus) {
-        const float* ut = u + (size_t)s * 2 * spp;
+        const float* ut = u + (size_t)s * u_ss;
         const float* ur = ut + spp;
         const float dep = depth[s];
         float sum = 0.f, cnt = 0.f;
@@ -525,7 +525,8 @@ int aadff_psf_splat(const float* o, const float* ra, const float* centre, int sp
 
 int aadff_psf_points(const float* points, int S, int N, int L, const aadff_surface_t* surf_main,
                      const aadff_surface_t* surf_chief, aadff_lens_const_t lc, const aadff_lens_state_t* states,
-                     const float* u_main, int spp, const float* u_chief, int spp_chief, int ks, int centre_mode,
+                     const float* u_main, int spp, long main_stride_s, long main_stride_l, const float* u_chief,
+                     int spp_chief, long chief_stride_s, long chief_stride_l, int ks, int centre_mode,
                      int map_layout, float* psf, float* centre_out_or_null, int* flags_or_null,
                      aadff_stream_t stream) {
     AADFF_CHECK_ARG(points && surf_main && states && u_main && psf, "psf_points: NULL pointer");
@@ -539,17 +540,19 @@ int aadff_psf_points(const float* points, int S, int N, int L, const aadff_surfa
         AADFF_CHECK_ARG(map_grid * map_grid == N, "psf_points: psf_map layout needs N = g*g, got %d", N);
     }
     hipLaunchKernelGGL(psf_points_kernel, dim3(N, L, S), dim3(256), 0, (hipStream_t)stream, points, N, L, surf_main,
-                       surf_chief, lc, states, u_main, spp, u_chief, spp_chief, make_splat_geom(lc.pixel_size, ks),
+                       surf_chief, lc, states, u_main, spp, main_stride_s, main_stride_l, u_chief, spp_chief, chief_stride_s,
+                       chief_stride_l, make_splat_geom(lc.pixel_size, ks),
                        centre_mode, map_grid, psf, centre_out_or_null, flags_or_null);
     AADFF_CHECK_LAUNCH();
     return 0;
 }
 
-int aadff_refocus(const float* depth, int S, const float* u, int spp, const aadff_surface_t* surf_green,
-                  aadff_lens_const_t lc, aadff_lens_state_t* states, aadff_stream_t stream) {
+int aadff_refocus(const float* depth, int S, const float* u, int spp, long u_stride_s,
+                  const aadff_surface_t* surf_green, aadff_lens_const_t lc, aadff_lens_state_t* states,
+                  aadff_stream_t stream) {
     AADFF_CHECK_ARG(depth && u && surf_green && states, "refocus: NULL pointer");
     AADFF_CHECK_ARG(S > 0 && spp > 0 && lc.n_surf > 0 && lc.n_surf <= AADFF_MAX_SURF, "refocus: bad sizes S=%d spp=%d", S, spp);
-    hipLaunchKernelGGL(refocus_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, depth, u, spp, surf_green, lc, states, 1);
+    hipLaunchKernelGGL(refocus_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, depth, u, spp, u_stride_s, surf_green, lc, states, 1);
     AADFF_CHECK_LAUNCH();
     return 0;
 }
@@ -559,7 +562,7 @@ int aadff_post_computation(int S, const aadff_surface_t* surf_green, aadff_lens_
     AADFF_CHECK_ARG(surf_green && states, "post_computation: NULL pointer");
     AADFF_CHECK_ARG(S > 0 && lc.n_surf > 0 && lc.n_surf <= AADFF_MAX_SURF, "post_computation: bad sizes S=%d", S);
     hipLaunchKernelGGL(refocus_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr,
-                       (const float*)nullptr, 0, surf_green, lc, states, 0);
+                       (const float*)nullptr, 0, 0L, surf_green, lc, states, 0);
     AADFF_CHECK_LAUNCH();
     return 0;
 }

@@ -216,7 +216,7 @@ class Lensgroup(DeepObj):
         u = torch.stack((self.sampler.rand(GEO_SPP), self.sampler.rand(GEO_SPP))).to(st.device)
         dep = torch.tensor([float(depth)], dtype=torch.float32).to(st.device)
         with torch.cuda.device(st.device):
-            _abi.call("aadff_refocus", _abi.ptr(dep), 1, _abi.ptr(u), GEO_SPP, _abi.ptr(self._table([DEFAULT_WAVE])),
+            _abi.call("aadff_refocus", _abi.ptr(dep), 1, _abi.ptr(u), GEO_SPP, 2 * GEO_SPP, _abi.ptr(self._table([DEFAULT_WAVE])),
                       lc, _abi.ptr(st), _abi.stream_ptr(st.device))
         self._state_stale = True
 
@@ -363,7 +363,8 @@ class Lensgroup(DeepObj):
         with torch.cuda.device(dev):
             _abi.call("aadff_psf_points", _abi.ptr(pts), 1, N, L, _abi.ptr(self._table(wvlns)),
                       _abi.ptr(self._table([DEFAULT_WAVE])), self._lens_const(), _abi.ptr(self._state_device()),
-                      _abi.ptr(u_main), spp, _abi.ptr(u_chief), GEO_SPP, ks, int(bool(center)), int(map_layout),
+                      _abi.ptr(u_main), spp, 2 * L * spp, 2 * spp, _abi.ptr(u_chief), GEO_SPP, 2 * L * GEO_SPP, 2 * GEO_SPP,
+                      ks, int(bool(center)), int(map_layout),
                       _abi.ptr(out), None, _abi.ptr(flags), _abi.stream_ptr(dev))
         return out.to(self.device) if self.device.type != "cuda" else out
 

@@ -34,11 +34,24 @@ HBM_PEAK = 8.0e12                       # B/s, MI355X_MICROARCH.md
 ALG_BYTES_PER_SLICE = 2 * 3 * H * W * 4  # read image once + write output once
 
 
-def cpu_baseline(lens_path, img, dbar, fds, budget_s=15.0):
+def usable_cpus():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box shows 256 logical CPUs under a 16-CPU quota; oversubscribing it stalls OpenMP)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(lens_path, img, dbar, fds, budget_s=12.0):
     """Oracle M1 slices (refocus -> psf_map -> render_psf_map) on the host cores."""
     from oracle import conv as oconv
     from oracle.lens import OracleLens
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(usable_cpus())
     lens = OracleLens(lens_path, sensor_res=(H, W))
     torch.manual_seed(0)
     t0 = time.perf_counter()

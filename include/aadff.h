@@ -155,8 +155,10 @@ int aadff_psf_splat(const float* o, const float* ra, const float* centre, int sp
  *   points      [S,N,3]  normalised (x,y in [-1,1], z = depth mm < 0)
  *   surf_main   [L][n_surf], surf_chief [n_surf]
  *   states      [S]
- *   u_main      [S,L,2,spp]      raw uniforms (theta row, r row)
- *   u_chief     [S,L,2,spp_chief]
+ *   u_main      raw uniforms: theta row at u_main + s*main_stride_s + l*main_stride_l, r row spp
+ *               floats after it (dense [S,L,2,spp] has strides 2*L*spp, 2*spp)
+ *   u_chief     same with spp_chief and its own strides (any layout that keeps the host
+ *               generator's draw order can be consumed without a re-layout copy)
  *   centre_mode 1: chief-ray centre (center=True); 0: ideal perspective centre (optics.py:970-975)
  *   map_layout  0: psf [S,N,L,ks,ks] ; 1: psf_map layout [S,L,g*ks,g*ks] with N = g*g (optics.py:1025)
  *   centre_out_or_null [S,L,N,2]
@@ -164,15 +166,17 @@ int aadff_psf_splat(const float* o, const float* ra, const float* centre, int sp
 int aadff_psf_points(const float* points, int S, int N, int L,
                      const aadff_surface_t* surf_main, const aadff_surface_t* surf_chief,
                      aadff_lens_const_t lc, const aadff_lens_state_t* states,
-                     const float* u_main, int spp, const float* u_chief, int spp_chief,
+                     const float* u_main, int spp, long main_stride_s, long main_stride_l,
+                     const float* u_chief, int spp_chief, long chief_stride_s, long chief_stride_l,
                      int ks, int centre_mode, int map_layout, float* psf, float* centre_out_or_null,
                      int* flags_or_null, aadff_stream_t stream);
 
 /* Refocus S lens states in one launch: trace spp rays from (0,0,depth[s]) (green table),
  * least-squares axis crossing -> d_sensor, then hfov/foclen/fnum.  Replaces
  * Lensgroup.refocus + post_computation + calc_fov + calc_efl,
- * deeplens/optics.py:1155-1217,178-187,1097-1102.  depth [S] (mm, <0); u [S,2,spp]. */
-int aadff_refocus(const float* depth, int S, const float* u, int spp,
+ * deeplens/optics.py:1155-1217,178-187,1097-1102.  depth [S] (mm, <0); u: theta row at
+ * u + s*u_stride_s, r row spp floats after it (dense [S,2,spp]: stride 2*spp). */
+int aadff_refocus(const float* depth, int S, const float* u, int spp, long u_stride_s,
                   const aadff_surface_t* surf_green, aadff_lens_const_t lc,
                   aadff_lens_state_t* states, aadff_stream_t stream);
 
