@@ -4,7 +4,8 @@
 // include/aadff.h for the per-entry citations and DESIGN.md for the kernel design.
 #include <cmath>
 #include <cstdarg>
-#include <mutex>
+#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace aadff {
@@ -27,7 +28,13 @@ void set_error(const char* fmt, ...) {
 struct PatchBounds {
     int hb[AADFF_MAX_GRID + 1];
     int wb[AADFF_MAX_GRID + 1];
+    // ceil(2^32 / d) for the uniform block-index decompositions: n / d == __umulhi(n, magic) for
+    // n < 65536 (integer division has no scalar form on gfx950 and costs ~15 VALU slots each)
+    unsigned m_ntx, m_nty, m_nchunk, m_c;
 };
+
+__host__ __device__ inline unsigned magic_of(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }
+__device__ __forceinline__ int udiv_magic(unsigned n, unsigned d, unsigned magic) { return d == 1 ? (int)n : (int)__umulhi(n, magic); }
 
 static void fill_bounds(int* b, int grid, int n) {
     for (int i = 0; i <= grid; ++i) b[i] = (int)((double)i / (double)grid * (double)n);
@@ -43,108 +50,182 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 
 // ------------------------------------------------------------------------------------
 // Fast path: one wave per 32x32 output tile of ONE patch and ONE channel plane.
-//   lane = (k = lane>>4, q = lane&15) owns outputs rows 8k..8k+7, cols 2q,2q+1
-//   -> 16 accumulators; input rows slide through 12 registers read as ds_read_b64;
-//   PSF taps are wave-uniform (one patch per tile) -> SGPR operands of v_fma_f32.
-// LDS pitch P with P % 8 == 4: the two thread-rows of a half-wave are 8 tile rows apart,
-// 8*P*4 B = 128 (mod 256) -> the 32 lanes of a ds_read_b64 group hit 64 distinct banks.
+//   lane = (k, q) owns a CX-wide x RR-tall block of outputs (2x8 or 4x4 = 16 accumulators);
+//   input rows slide through registers read as whole ds_read_b64 / ds_read_b128 vectors;
+//   PSF taps are wave-uniform (one patch per tile) -> SGPR operands of v_fmac_f32.
 // Taps are consumed in groups of UG PSF rows so that UG*KS weights stay in SGPRs while
-// each input row is re-read only ceil(KS/UG) times.
+// each input row is re-read only ceil(KS/UG) times; the image tile is staged ONCE for
+// all S slices of a stack.
 // ------------------------------------------------------------------------------------
-constexpr int TW = 32, TH = 32, RR = 8;
+constexpr int TW = 32, TH = 32;
+constexpr int CX = 4, RR = 4, QN = TW / CX;      // lane = (k = lane/8, q = lane%8): cols 4q..4q+3, rows 4k..4k+3
+
+#ifndef AADFF_CONV_MINWAVES
+#define AADFF_CONV_MINWAVES 4      // waves per SIMD the register allocator must leave room for
+#endif
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// Packed fp32 FMA is the only way to the fp32 peak on gfx950 (measured, tools/fma_bench.hip:
+// v_fmac_f32 with an SGPR tap 75 TFLOP/s, v_pk_fma_f32 with an SGPR-pair tap 141 TFLOP/s).
+//   acc.lo += w * x.lo ; acc.hi += w * x.hi      with w = lo (HALF 0) or hi (HALF 1) half of an SGPR pair
+template <int HALF>
+__device__ __forceinline__ void pk_fma_bcast(float2v& acc, float2v wpair, float2v x) {
+    if constexpr (HALF == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(wpair), "v"(x));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(wpair), "v"(x));
+}
+// keeps a value "used" at this program point so the accumulation is not sunk into the masked stores
+__device__ __forceinline__ void pin(float2v& v) { asm volatile("" : "+v"(v)); }
 
 template <int KS>
 struct ConvCfg {
     static constexpr int PAD = KS / 2;
-    static constexpr int TWP = TW + KS - 1;
-    static constexpr int THP = TH + KS - 1;
-    static constexpr int PITCH = ((TWP - 4 + 7) / 8) * 8 + 4;
-    static constexpr int NIN = KS + 1;                       // input regs per row (2 cols + KS-1 halo)
-    static constexpr int UG = KS <= 7 ? KS : (KS <= 13 ? 4 : 3);   // PSF rows per SGPR group
+    static constexpr int TWP = TW + KS - 1;                  // staged columns
+    static constexpr int THP = TH + KS - 1;                  // staged rows
+    static constexpr int NIN = CX + KS - 1;                  // inputs a lane needs per row: in[0 .. KS+2]
+    static constexpr int NE = (NIN + 1) / 2;                 // even-aligned pairs E[j] = (in[2j], in[2j+1])
+    static constexpr int NO = (KS + 1) / 2;                  // shifted pairs     O[j] = (in[2j+1], in[2j+2])
+    static constexpr int NVA = (2 * NE + 3) / 4;             // ds_read_b128 per row from tile A
+    static constexpr int NVB = (2 * NO + 3) / 4;             // ds_read_b128 per row from tile B (= A shifted by one column)
+    // pitches: 16-B slot step between lane-rows (RR=4 tile rows apart) must be 8 (mod 16) so that the four
+    // lane-rows of a 16-lane ds_read_b128 group fall on disjoint bank quarters (64 banks x 4 B)
+    static constexpr int need_a = (QN - 1) * CX + 4 * NVA, need_b = (QN - 1) * CX + 4 * NVB;
+    static constexpr int PA = ((((need_a > TWP ? need_a : TWP)) - 8 + 15) / 16) * 16 + 8;
+    static constexpr int PB = ((need_b - 8 + 15) / 16) * 16 + 8;
+    static constexpr int NM = (KS + 1) / 2;                  // SGPR pairs per PSF row
+    static constexpr int UG = KS <= 7 ? KS : (KS <= 13 ? 4 : 2);   // PSF rows per SGPR group
 };
 
-template <int KS>
-__global__ __launch_bounds__(64) void conv_psf_map_kernel(const float* __restrict__ img,
-                                                           const float* __restrict__ psf,
-                                                           float* __restrict__ out, int C, int S, int H,
-                                                           int W, int grid, int ntx, int nty,
-                                                           PatchBounds pb) {
+// One workgroup = NW waves = one 32x32 output tile of ONE patch and ONE channel plane for a CHUNK of
+// NW slices: the reflect-padded input tile is staged once (tile A, plus tile B = A shifted left by one
+// column so that odd taps also read ALIGNED register pairs) and wave w renders slice chunk*NW + w.
+// Units are one slice long (short tail) yet NW waves share each 16 KB of LDS (>= 4 waves per SIMD).
+template <int KS, int NW>
+__global__ __launch_bounds__(64 * NW, AADFF_CONV_MINWAVES) void conv_psf_map_kernel(
+    const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, int C, int S, int H, int W,
+    int grid, int ntx, int nty, PatchBounds pb) {
     using Cfg = ConvCfg<KS>;
-    constexpr int P = Cfg::PITCH;
-    __shared__ __attribute__((aligned(16))) float tile[Cfg::THP * P];
+    constexpr int PA = Cfg::PA, PB = Cfg::PB;
+    static_assert(Cfg::TWP <= kWave, "staging maps one tile column to one lane");
+    __shared__ __attribute__((aligned(16))) float tileA[Cfg::THP * PA];
+    __shared__ __attribute__((aligned(16))) float tileB[Cfg::THP * PB];
 
-    const int lane = threadIdx.x;
-    const int pj = blockIdx.x / ntx, tx = blockIdx.x - pj * ntx;
-    const int pi = blockIdx.y / nty, ty = blockIdx.y - pi * nty;
-    const int bc = blockIdx.z;
-    const int c = bc % C;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform -> PSF taps via scalar loads
+    const int pj = udiv_magic(blockIdx.x, ntx, pb.m_ntx), tx = blockIdx.x - pj * ntx;
+    const int pi = udiv_magic(blockIdx.y, nty, pb.m_nty), ty = blockIdx.y - pi * nty;
+    const int nchunk = (S + NW - 1) / NW;
+    const int bc = udiv_magic(blockIdx.z, nchunk, pb.m_nchunk), chunk = blockIdx.z - bc * nchunk;
+    const int c = bc - udiv_magic(bc, C, pb.m_c) * C;
     const int x_hi = pb.wb[pj + 1], y_hi = pb.hb[pi + 1];
     const int x0 = pb.wb[pj] + tx * TW, y0 = pb.hb[pi] + ty * TH;
     if (x0 >= x_hi || y0 >= y_hi) return;
 
-    // ---- stage the reflect-padded input tile once (shared by all S slices) ----
-    const float* plane = img + (size_t)bc * H * W;
-    for (int e = lane; e < Cfg::THP * Cfg::TWP; e += kWave) {
-        const int r = e / Cfg::TWP, cc = e - r * Cfg::TWP;
-        const int yy = reflect_idx(y0 - Cfg::PAD + r, H);
-        const int xx = reflect_idx(x0 - Cfg::PAD + cc, W);
-        tile[r * P + cc] = plane[(size_t)yy * W + xx];
+    // ---- stage the reflect-padded tile: column = lane (reflected once), rows strided over the waves
+    //      (row index and its reflection are wave-uniform -> scalar ALU); every global load is issued
+    //      before the first LDS write so the latencies overlap ----
+    {
+        const float* plane = img + (size_t)bc * H * W;
+        constexpr int NR = (Cfg::THP + NW - 1) / NW;
+        const int xx = reflect_idx(x0 - Cfg::PAD + lane, W);
+        float v[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int r = wave + j * NW;
+            const int yy = reflect_idx(y0 - Cfg::PAD + r, H);
+            v[j] = (lane < Cfg::TWP && r < Cfg::THP) ? plane[(size_t)yy * W + xx] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int r = wave + j * NW;
+            if (lane < Cfg::TWP && r < Cfg::THP) {
+                tileA[r * PA + lane] = v[j];
+                if (lane >= 1 && lane - 1 < PB) tileB[r * PB + lane - 1] = v[j];
+            }
+        }
     }
     __syncthreads();
 
-    const int q = lane & 15, k = lane >> 4;
+    const int q = lane % QN, k = lane / QN;
     const int G = grid * KS;
-    const float* trow = &tile[(RR * k) * P + 2 * q];
+    const float* arow = &tileA[(RR * k) * PA + CX * q];
+    const float* brow = &tileB[(RR * k) * PB + CX * q];
 
-    for (int s = 0; s < S; ++s) {
+    const int s = chunk * NW + wave;
+    if (s < S) {
         // PSF block of this patch; conv2d is a correlation with the FLIPPED PSF
-        // (render_psf.py:62): w(u,v) = psf[KS-1-u][KS-1-v].
+        // (render_psf.py:62): w(u,v) = psf[KS-1-u][KS-1-v] = m_u[KS-1-v], m_u = PSF row KS-1-u.
         const float* wp = psf + ((size_t)(s * C + c) * G + pi * KS) * G + pj * KS;
-        float acc[RR][2];
+        float2v acc[RR][2];
 #pragma unroll
-        for (int r = 0; r < RR; ++r) acc[r][0] = acc[r][1] = 0.f;
+        for (int r = 0; r < RR; ++r) acc[r][0] = acc[r][1] = (float2v){0.f, 0.f};
 
 #pragma unroll
         for (int u0 = 0; u0 < KS; u0 += Cfg::UG) {
-            float w[Cfg::UG][KS];
+            float2v M[Cfg::UG][Cfg::NM];                    // M[ug][j] = (m[2j], m[2j+1]) -> SGPR pairs
 #pragma unroll
-            for (int ug = 0; ug < Cfg::UG; ++ug)
+            for (int ug = 0; ug < Cfg::UG; ++ug) {
+                const float* mrow = wp + (size_t)(KS - 1 - (u0 + ug < KS ? u0 + ug : KS - 1)) * G;
 #pragma unroll
-                for (int v = 0; v < KS; ++v)
-                    w[ug][v] = (u0 + ug < KS) ? wp[(size_t)(KS - 1 - (u0 + ug)) * G + (KS - 1 - v)] : 0.f;
+                for (int j = 0; j < Cfg::NM; ++j)
+                    M[ug][j] = (float2v){mrow[2 * j], mrow[2 * j + 1 < KS ? 2 * j + 1 : KS - 1]};
+            }
 #pragma unroll
             for (int ir = u0; ir < u0 + Cfg::UG - 1 + RR; ++ir) {
                 if (ir >= KS - 1 + RR) continue;
-                float in[Cfg::NIN];
-                const float2* rp = reinterpret_cast<const float2*>(trow + ir * P);
+                float2v E[2 * Cfg::NVA], O[2 * Cfg::NVB];
+                const float4* ap = reinterpret_cast<const float4*>(arow + ir * PA);
+                const float4* bp = reinterpret_cast<const float4*>(brow + ir * PB);
 #pragma unroll
-                for (int h = 0; h < Cfg::NIN / 2; ++h) {
-                    const float2 t2 = rp[h];
-                    in[2 * h] = t2.x;
-                    in[2 * h + 1] = t2.y;
+                for (int h = 0; h < Cfg::NVA; ++h) {
+                    const float4 t = ap[h];
+                    E[2 * h] = (float2v){t.x, t.y};
+                    E[2 * h + 1] = (float2v){t.z, t.w};
                 }
 #pragma unroll
-                for (int ug = 0; ug < Cfg::UG; ++ug) {
-                    const int u = u0 + ug, r = ir - u;
-                    if (u >= KS || r < 0 || r >= RR) continue;
+                for (int h = 0; h < Cfg::NVB; ++h) {
+                    const float4 t = bp[h];
+                    O[2 * h] = (float2v){t.x, t.y};
+                    O[2 * h + 1] = (float2v){t.z, t.w};
+                }
+                // tap loop outermost: the (up to) 4 output rows x 2 column pairs this input row feeds are
+                // independent accumulators -> 8 interleaved dependency chains per wave
 #pragma unroll
-                    for (int v = 0; v < KS; ++v) {
-                        acc[r][0] = fmaf(w[ug][v], in[v], acc[r][0]);
-                        acc[r][1] = fmaf(w[ug][v], in[v + 1], acc[r][1]);
+                for (int v = 0; v < KS; ++v) {
+                    const int idx = KS - 1 - v;                // position of tap v in memory row m
+#pragma unroll
+                    for (int ug = 0; ug < Cfg::UG; ++ug) {
+                        const int u = u0 + ug, r = ir - u;
+                        if (u >= KS || r < 0 || r >= RR) continue;
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const float2v x = (v % 2 == 0) ? E[(v + 2 * p) / 2] : O[(v + 2 * p - 1) / 2];
+                            if (idx % 2 == 0)
+                                pk_fma_bcast<0>(acc[r][p], M[ug][idx / 2], x);
+                            else
+                                pk_fma_bcast<1>(acc[r][p], M[ug][idx / 2], x);
+                        }
                     }
                 }
             }
+#pragma unroll
+            for (int r = 0; r < RR; ++r) { pin(acc[r][0]); pin(acc[r][1]); }
         }
 
-        float* oplane = out + ((size_t)bc * S + s) * H * W;
-        const int x = x0 + 2 * q;
+        const int x = x0 + CX * q, yb = y0 + RR * k;
+        float* o = out + (((size_t)bc * S + s) * H + yb) * W + x;
+        const bool m0 = x < x_hi, m1 = x + 1 < x_hi, m2 = x + 2 < x_hi, m3 = x + 3 < x_hi;
 #pragma unroll
         for (int r = 0; r < RR; ++r) {
-            const int y = y0 + RR * k + r;
-            if (y < y_hi) {
-                if (x < x_hi) oplane[(size_t)y * W + x] = acc[r][0];
-                if (x + 1 < x_hi) oplane[(size_t)y * W + x + 1] = acc[r][1];
+            if (yb + r < y_hi) {
+                if (m0) o[0] = acc[r][0].x;
+                if (m1) o[1] = acc[r][0].y;
+                if (m2) o[2] = acc[r][1].x;
+                if (m3) o[3] = acc[r][1].y;
             }
+            o += W;
         }
     }
 }
@@ -202,10 +283,41 @@ __global__ __launch_bounds__(256) void conv_psf_map_generic_kernel(const float* 
 }
 
 template <int KS>
-static void launch_fast(const float* img, const float* psf, float* out, int B, int C, int S, int H, int W,
-                        int grid, int ntx, int nty, const PatchBounds& pb, hipStream_t st) {
-    dim3 g(ntx * grid, nty * grid, B * C);
-    hipLaunchKernelGGL(conv_psf_map_kernel<KS>, g, dim3(64), 0, st, img, psf, out, C, S, H, W, grid, ntx, nty, pb);
+static int launch_fast(const float* img, const float* psf, float* out, int B, int C, int S, int H, int W,
+                       int grid, int ntx, int nty, const PatchBounds& pb, hipStream_t st) {
+    // waves per workgroup = slices of one chunk (one slice per wave): least padding, at most 5
+    int nw = 1, best = 1 << 30;
+    const int maxnw = KS == 11 ? 5 : 4;
+    for (int n = maxnw; n >= (S > 1 ? 2 : 1); --n) {      // larger n wins ties; a lone wave per tile only for S == 1
+        if (KS != 11 && n == 3) continue;
+        const int waste = (S + n - 1) / n * n - S;
+        if (waste < best) { best = waste; nw = n; }
+    }
+    const char* env = getenv("AADFF_CONV_NW");
+    if (env && KS == 11) nw = atoi(env);
+    const int nchunk = (S + nw - 1) / nw;
+    AADFF_CHECK_ARG((size_t)B * C * nchunk <= 65535, "render_psf_map: B*C*chunks too large");
+    PatchBounds pbm = pb;
+    pbm.m_ntx = magic_of(ntx); pbm.m_nty = magic_of(nty); pbm.m_nchunk = magic_of(nchunk); pbm.m_c = magic_of(C);
+    dim3 g(ntx * grid, nty * grid, B * C * nchunk);
+#define AADFF_LAUNCH(NWV) hipLaunchKernelGGL((conv_psf_map_kernel<KS, NWV>), g, dim3(64 * NWV), 0, st, img, psf, out, C, S, H, W, grid, ntx, nty, pbm)
+    if constexpr (KS == 11) {
+        switch (nw) {
+            case 5: AADFF_LAUNCH(5); break;
+            case 4: AADFF_LAUNCH(4); break;
+            case 3: AADFF_LAUNCH(3); break;
+            case 2: AADFF_LAUNCH(2); break;
+            default: AADFF_LAUNCH(1);
+        }
+    } else {
+        switch (nw) {
+            case 4: AADFF_LAUNCH(4); break;
+            case 2: AADFF_LAUNCH(2); break;
+            default: AADFF_LAUNCH(1);
+        }
+    }
+#undef AADFF_LAUNCH
+    return 0;
 }
 
 static int conv_dispatch(const float* img, const float* psf, float* out, int B, int C, int S, int H, int W,
@@ -230,7 +342,7 @@ static int conv_dispatch(const float* img, const float* psf, float* out, int B, 
     }
     const int ntx = (mw + TW - 1) / TW, nty = (mh + TH - 1) / TH;
     switch (ks) {
-#define AADFF_CASE(K) case K: launch_fast<K>(img, psf, out, B, C, S, H, W, grid, ntx, nty, pb, st); break;
+#define AADFF_CASE(K) case K: { int rc = launch_fast<K>(img, psf, out, B, C, S, H, W, grid, ntx, nty, pb, st); if (rc) return rc; } break;
         AADFF_CASE(3) AADFF_CASE(5) AADFF_CASE(7) AADFF_CASE(9) AADFF_CASE(11) AADFF_CASE(13)
         AADFF_CASE(15) AADFF_CASE(21)
 #undef AADFF_CASE
