@@ -82,8 +82,8 @@ class StackPlan:
             return self.u_dev[k]
         if self.u_evt[k] is not None:
             self.u_evt[k].synchronize()          # the copy that last used this pinned slot has finished
-        if type(sampler).__name__ == "HostSampler":
-            torch.rand(n, out=self.u_pin[k])     # == the reference's call-by-call draws (same generator stream)
+        if hasattr(sampler, "rand_into"):
+            sampler.rand_into(self.u_pin[k])     # == the reference's call-by-call draws (same generator stream)
         else:
             self.u_pin[k].copy_(sampler.rand_block([n]))
         self.u_dev[k].copy_(self.u_pin[k], non_blocking=True)

@@ -1,0 +1,81 @@
+// Host-side continuation of torch's CPU generator stream (no GPU code).
+//
+// The reference draws its pupil samples with torch.rand on the HOST generator
+// (deeplens/optics.py:480-481, deeplens/surfaces.py:192-193); sample-for-sample parity needs
+// exactly that stream.  torch.rand costs ~10 ns per float; this routine produces the same
+// floats from the same MT19937 state in ~1.5 ns each and hands the advanced state back, so
+// torch's global generator stays where the reference's call sequence would have left it.
+//
+// State layout = at::CPUGeneratorImpl::get_state(): CPUGeneratorImplStateLegacy
+//   u64 seed | i32 left | i32 seeded | u64 next | u64 state[624] | f64 normal_x,y,rho | i32 normal_valid (+pad)
+//   | f32 next_float_normal | bool valid (+pad)            = 5056 bytes
+// float32 uniform = (y & (2^24 - 1)) * 2^-24 with y the tempered 32-bit output
+// (ATen/core/DistributionsHelper.h uniform_real_distribution<float>), one draw per element, serial.
+#include <cstdint>
+#include <cstring>
+#include "aadff.h"
+#include "common.h"
+
+namespace {
+constexpr int N = 624, M = 397;
+constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
+
+inline uint32_t twist(uint32_t u, uint32_t v) {
+    return (((u & UPPER) | (v & LOWER)) >> 1) ^ ((v & 1u) ? MATRIX_A : 0u);
+}
+
+void next_state(uint32_t* st) {
+    int j = 0;
+    for (; j < N - M; ++j) st[j] = st[j + M] ^ twist(st[j], st[j + 1]);
+    for (; j < N - 1; ++j) st[j] = st[j + M - N] ^ twist(st[j], st[j + 1]);
+    st[N - 1] = st[M - 1] ^ twist(st[N - 1], st[0]);
+}
+
+inline float to_uniform(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return (float)(y & 0xffffffu) * (1.0f / 16777216.0f);
+}
+}  // namespace
+
+extern "C" int aadff_host_mt19937_uniform_f32(unsigned char* torch_state, long state_bytes, long n, float* out) {
+    AADFF_CHECK_ARG(torch_state && out && n >= 0, "host_mt19937: NULL pointer or negative count");
+    AADFF_CHECK_ARG(state_bytes == 5056, "host_mt19937: unexpected torch CPU generator state size %ld (want 5056)", state_bytes);
+    int32_t left;
+    uint64_t next64;
+    std::memcpy(&left, torch_state + 8, 4);
+    std::memcpy(&next64, torch_state + 16, 8);
+    AADFF_CHECK_ARG(left >= 1 && left <= N && next64 <= (uint64_t)N, "host_mt19937: corrupt generator state (left=%d next=%llu)", left, (unsigned long long)next64);
+    uint32_t st[N];
+    for (int i = 0; i < N; ++i) {
+        uint64_t v;
+        std::memcpy(&v, torch_state + 24 + 8 * i, 8);
+        st[i] = (uint32_t)v;
+    }
+    int nxt = (int)next64;
+    long i = 0;
+    while (i < n) {
+        // at::mt19937::operator(): if (--left == 0) next_state();  y = state[next++]
+        if (left == 1) {
+            next_state(st);
+            left = N + 1;
+            nxt = 0;
+        }
+        long run = left - 1;                 // outputs available before the next regeneration
+        if (run > n - i) run = n - i;
+        for (long k = 0; k < run; ++k) out[i + k] = to_uniform(st[nxt + k]);
+        i += run;
+        nxt += (int)run;
+        left -= (int)run;
+    }
+    next64 = (uint64_t)nxt;
+    std::memcpy(torch_state + 8, &left, 4);
+    std::memcpy(torch_state + 16, &next64, 8);
+    for (int k = 0; k < N; ++k) {
+        const uint64_t v = st[k];
+        std::memcpy(torch_state + 24 + 8 * k, &v, 8);
+    }
+    return 0;
+}

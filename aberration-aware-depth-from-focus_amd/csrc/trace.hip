@@ -17,37 +17,53 @@ constexpr int kNewtonMaxIter = 10;       // deeplens/surfaces.py:26
 constexpr float kTolTight = 10e-6f;      // deeplens/surfaces.py:27
 constexpr float kTolLoose = 50e-6f;      // deeplens/surfaces.py:28
 constexpr float kStepBound = 5.f;        // deeplens/surfaces.py:29
+constexpr int AADFF_SPHERIC_CLOSED_FORM = AADFF_SURF_SPHERIC;
 constexpr float kTwoPiHi = 3.14159274101257324f;   // (float)np.pi
 
 struct Ray {
     float ox, oy, oz, dx, dy, dz, ra;
 };
 
-// ---- even-asphere sag and d(sag)/d(r^2): deeplens/surfaces.py:787-830 ----
-__device__ __forceinline__ float sag_r2(const aadff_surface_t& s, float r2) {
-    float z = r2 * s.c / (1.f + sqrtf(1.f - (1.f + s.k) * r2 * (s.c * s.c)));
-    if (s.n_ai > 0) {
-        float p = r2;
-        for (int j = 0; j < s.n_ai; ++j) {
-            z += s.ai[j] * p;
-            p *= r2;
-        }
-    }
-    return z;
-}
+// ---- arithmetic primitives -------------------------------------------------------------
+// Default: hardware reciprocal / sqrt / rsqrt (1 ulp) instead of the IEEE-exact sequences (11
+// instructions per division, ~10 per sqrt).  Their error (~1e-7 relative on quantities of a few mm)
+// is three orders below the fp32 noise the reference itself carries at the first surface (one ulp of
+// t ~ 1500 mm is 1.2e-4 mm); -DAADFF_TRACE_IEEE restores the exact forms.
+#ifdef AADFF_TRACE_IEEE
+__device__ __forceinline__ float frcp(float x) { return 1.f / x; }
+__device__ __forceinline__ float fsqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ float frsq(float x) { return 1.f / sqrtf(x); }
+__device__ __forceinline__ float fdiv(float a, float b) { return a / b; }
+#else
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#endif
 
-__device__ __forceinline__ float dsag_dr2(const aadff_surface_t& s, float r2) {
+// ---- even-asphere sag and d(sag)/d(r^2): deeplens/surfaces.py:787-830 ----
+// sag = c r^2 / (1 + sf) + sum a_j r^(2j),  sf = sqrt(1 - (1+k) c^2 r^2).  The reference's expression for
+// the conic part of d(sag)/d(r^2), (1 + sf + (1+k) r^2 c^2 / (2 sf)) c / (1 + sf)^2, is identically
+// c / (2 sf); the closed form is used here (one reciprocal instead of two divisions).
+__device__ __forceinline__ void sag_and_slope(const aadff_surface_t& s, float r2, float& sag, float& slope) {
     const float a = (1.f + s.k) * r2 * (s.c * s.c);
-    const float sf = sqrtf(1.f - a);
-    float g = (1.f + sf + a / 2.f / sf) * s.c / ((1.f + sf) * (1.f + sf));
+    const float sf = fsqrt(1.f - a);
+    sag = r2 * s.c * frcp(1.f + sf);
+    slope = 0.5f * s.c * frcp(sf);
     if (s.n_ai > 0) {
         float p = 1.f;
         for (int j = 0; j < s.n_ai; ++j) {
-            g += (float)(j + 1) * s.ai[j] * p;
+            slope += (float)(j + 1) * s.ai[j] * p;
             p *= r2;
+            sag += s.ai[j] * p;
         }
     }
-    return g;
+}
+
+__device__ __forceinline__ float dsag_dr2(const aadff_surface_t& s, float r2) {
+    float sag, slope;
+    sag_and_slope(s, r2, sag, slope);
+    return slope;
 }
 
 // ---- validity masks: deeplens/surfaces.py:724-743 ----
@@ -65,10 +81,12 @@ __device__ __forceinline__ float newton_step(const aadff_surface_t& s, const Ray
     float r2 = px * px + py * py;
     const bool m = STRICT ? valid_strict(s, r2) : valid_loose(s, r2);
     r2 = m ? r2 : 0.f;                                   // x*valid, y*valid
-    const float ft = sag_r2(s, r2) + s.d - pz;
+    float sag, slope;
+    sag_and_slope(s, r2, sag, slope);
+    const float ft = sag + s.d - pz;
     const float dr2dt = 2.f * (dxy2 * t + od);
-    const float dfdt = dsag_dr2(s, r2) * dr2dt - r.dz;
-    float step = ft / (dfdt + kEps);
+    const float dfdt = slope * dr2dt - r.dz;
+    float step = fdiv(ft, dfdt + kEps);
     step = fminf(fmaxf(step, -kStepBound), kStepBound);
     t -= step;
     return ft;
@@ -77,7 +95,7 @@ __device__ __forceinline__ float newton_step(const aadff_surface_t& s, const Ray
 __device__ __forceinline__ void newton(const aadff_surface_t& s, const Ray& r, float& t_out, bool& valid_out, int& nan_flag) {
     const float dxy2 = r.dx * r.dx + r.dy * r.dy;
     const float od = r.dx * r.ox + r.dy * r.oy;
-    const float t0 = (s.d - r.oz) / r.dz;
+    const float t0 = fdiv(s.d - r.oz, r.dz);
     float t = t0;
     float ft = kMaxT;
     for (int it = 0; it < kNewtonMaxIter; ++it) {
@@ -108,7 +126,7 @@ __device__ __forceinline__ void refract(const aadff_surface_t& s, Ray& r, bool f
         const float g = dsag_dr2(s, r.ox * r.ox + r.oy * r.oy);
         nx = g * 2.f * r.ox; ny = g * 2.f * r.oy; nz = -1.f;
     }
-    const float inv = 1.f / fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-12f);   // F.normalize
+    const float inv = frsq(fmaxf(nx * nx + ny * ny + nz * nz, 1e-24f));           // F.normalize (eps 1e-12 on the norm)
     nx *= inv; ny *= inv; nz *= inv;
     if (forward) { nx = -nx; ny = -ny; nz = -nz; }
     const float eta = forward ? s.eta_fwd : s.eta_bwd;
@@ -117,7 +135,7 @@ __device__ __forceinline__ void refract(const aadff_surface_t& s, Ray& r, bool f
     const float sin2 = eta2 * (1.f - cosi * cosi);
     const bool valid = (cosi * cosi > 0.1f) && (sin2 < 1.f);
     if (valid) {
-        const float sr = sqrtf(1.f - sin2);
+        const float sr = fsqrt(1.f - sin2);
         r.dx = sr * nx + eta * (r.dx - cosi * nx);
         r.dy = sr * ny + eta * (r.dy - cosi * ny);
         r.dz = sr * nz + eta * (r.dz - cosi * nz);
@@ -130,9 +148,9 @@ __device__ __forceinline__ void refract(const aadff_surface_t& s, Ray& r, bool f
 __device__ __forceinline__ void react(const aadff_surface_t& s, Ray& r, bool forward, int& nan_flag) {
     if (!(r.ra > 0.f)) return;
     if (s.kind == AADFF_SURF_STOP) {
-        const float t = (s.d - r.oz) / r.dz;
+        const float t = fdiv(s.d - r.oz, r.dz);
         const float px = r.ox + t * r.dx, py = r.oy + t * r.dy, pz = r.oz + t * r.dz;
-        if (sqrtf(px * px + py * py) <= s.r) {
+        if (fsqrt(px * px + py * py) <= s.r) {
             r.ox = px; r.oy = py; r.oz = pz;
             if (forward ? s.refract_fwd : s.refract_bwd) refract(s, r, forward);
         } else {
@@ -140,15 +158,37 @@ __device__ __forceinline__ void react(const aadff_surface_t& s, Ray& r, bool for
         }
         return;
     }
-    float t;
-    bool nvalid;
-    newton(s, r, t, nvalid, nan_flag);
-    const float px = r.ox + t * r.dx, py = r.oy + t * r.dy, pz = r.oz + t * r.dz;
+    float t, px, py, pz;
     bool valid;
-    if (s.kind == AADFF_SURF_SPHERIC)
-        valid = (px * px + py * py <= s.r2) && (t >= 0.f);      // Newton's own mask is discarded (:466)
-    else
-        valid = nvalid;
+#ifndef AADFF_SPHERE_NEWTON
+    if (s.kind == AADFF_SPHERIC_CLOSED_FORM) {
+        // Sphere (k = 0, no polynomial): closed-form root instead of the reference's Newton iteration
+        // (deeplens/surfaces.py:456-487 keeps Newton's t but DISCARDS its convergence mask, so only the root
+        // matters).  From the vertex-plane point p0 = o + d*t0 the sphere |p - (0,0,d+R)| = R reads
+        //   tau^2 + 2 b tau + rho^2 = 0,  rho^2 = p0x^2 + p0y^2,  b = p0x dx + p0y dy - R dz,
+        // whose root next to the vertex plane is, in cancellation-free form and scaled by c = 1/R,
+        //   tau = c rho^2 / (-beta + sgn(-beta) sqrt(beta^2 - c^2 rho^2)),   beta = c (p0x dx + p0y dy) - dz.
+        const float t0 = fdiv(s.d - r.oz, r.dz);
+        const float p0x = r.ox + r.dx * t0, p0y = r.oy + r.dy * t0;
+        const float rho2 = p0x * p0x + p0y * p0y;
+        const float beta = s.c * (p0x * r.dx + p0y * r.dy) - r.dz;
+        const float disc = beta * beta - (s.c * s.c) * rho2;
+        const float root = fsqrt(fmaxf(disc, 0.f));
+        const float tau = fdiv(s.c * rho2, beta < 0.f ? (root - beta) : -(root + beta));
+        t = t0 + tau;
+        px = p0x + r.dx * tau; py = p0y + r.dy * tau; pz = s.d + r.dz * tau;
+        valid = (disc >= 0.f) && (px * px + py * py <= s.r2) && (t >= 0.f);
+    } else
+#endif
+    {
+        bool nvalid;
+        newton(s, r, t, nvalid, nan_flag);
+        px = r.ox + t * r.dx; py = r.oy + t * r.dy; pz = r.oz + t * r.dz;
+        if (s.kind == AADFF_SURF_SPHERIC)
+            valid = (px * px + py * py <= s.r2) && (t >= 0.f);      // Newton's own mask is discarded (:466)
+        else
+            valid = nvalid;
+    }
     if (valid) {
         r.ox = px; r.oy = py; r.oz = pz;
         refract(s, r, forward);
@@ -166,21 +206,27 @@ __device__ __forceinline__ void trace_range(const aadff_surface_t* __restrict__ 
 }
 
 __device__ __forceinline__ void propagate_to(Ray& r, float z) {      // deeplens/basics.py:255-273 (all rays)
-    const float t = (z - r.oz) / r.dz;
+    const float t = fdiv(z - r.oz, r.dz);
     r.ox += r.dx * t; r.oy += r.dy * t; r.oz += r.dz * t;
 }
 
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
-    const float inv = 1.f / fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
+    const float inv = frsq(fmaxf(x * x + y * y + z * z, 1e-24f));
     x *= inv; y *= inv; z *= inv;
 }
 
 // pupil / disc sample from two raw uniforms: deeplens/optics.py:480-485, surfaces.py:192-195
 __device__ __forceinline__ void disc_sample(float u_theta, float u_r, float R2, float& x, float& y) {
+    const float rr = fsqrt(u_r * R2);
+#ifdef AADFF_HW_SINCOS
+    // v_sin_f32 / v_cos_f32 take their argument in revolutions: sin(2*pi*u) in one instruction
+    x = rr * __builtin_amdgcn_cosf(u_theta);
+    y = rr * __builtin_amdgcn_sinf(u_theta);
+#else
     const float theta = u_theta * 2.f * kTwoPiHi;
-    const float rr = sqrtf(u_r * R2);
     x = rr * cosf(theta);
     y = rr * sinf(theta);
+#endif
 }
 
 __device__ __forceinline__ Ray ray_to(float px, float py, float pz, float tx, float ty, float tz) {
@@ -262,8 +308,8 @@ __device__ __forceinline__ void splat_hit(float* hist, const SplatGeom& g, float
     float X = -ox - cx, Y = -oy - cy;                 // image flip, then centre
     const bool in = (fabsf(X) < g.lim) && (fabsf(Y) < g.lim) && (ra > 0.f);
     if (!in) return;                                   // zero-weight taps at the centre bin are skipped
-    const float rowf = ((Y - g.hi) / g.den_row) * (float)(g.ks - 1);
-    const float colf = ((X - g.lo) / g.den_col) * (float)(g.ks - 1);
+    const float rowf = fdiv(Y - g.hi, g.den_row) * (float)(g.ks - 1);
+    const float colf = fdiv(X - g.lo, g.den_col) * (float)(g.ks - 1);
     const float fr = floorf(rowf), fc = floorf(colf);
     const float wb = rowf - fr, wr = colf - fc;
     const int r0 = (int)fr, c0 = (int)fc;
@@ -402,11 +448,12 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
 // Refocus + post_computation: workgroup per focus state.
 //   deeplens/optics.py:1155-1180 (refocus), :1187-1217 (calc_fov), :178-187, :1097-1102
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void refocus_kernel(const float* __restrict__ depth, const float* __restrict__ u,
+constexpr int kRefocusThreads = 1024;     // 16 waves: the per-slice trace is latency-bound, not throughput-bound
+__global__ __launch_bounds__(kRefocusThreads) void refocus_kernel(const float* __restrict__ depth, const float* __restrict__ u,
                                                        int spp, long u_ss, const aadff_surface_t* __restrict__ surf,
                                                        aadff_lens_const_t lc, aadff_lens_state_t* states,
                                                        int do_refocus) {
-    __shared__ float red[2 * 4];
+    __shared__ float red[2 * (kRefocusThreads / 64)];
     __shared__ float s_dsensor;
     __shared__ int s_count;
     const int s = blockIdx.x, tid = threadIdx.x;
@@ -417,7 +464,7 @@ __global__ __launch_bounds__(256) void refocus_kernel(const float* __restrict__ 
         const float* ur = ut + spp;
         const float dep = depth[s];
         float sum = 0.f, cnt = 0.f;
-        for (int i = tid; i < spp; i += 256) {
+        for (int i = tid; i < spp; i += kRefocusThreads) {
             float x2, y2;
             disc_sample(ut[i], ur[i], lc.first_r2, x2, y2);
             Ray r;
@@ -435,7 +482,8 @@ __global__ __launch_bounds__(256) void refocus_kernel(const float* __restrict__ 
         if ((tid & 63) == 0) { red[(tid >> 6) * 2] = sum; red[(tid >> 6) * 2 + 1] = cnt; }
         __syncthreads();
         if (tid == 0) {
-            const float ts = red[0] + red[2] + red[4] + red[6], tc = red[1] + red[3] + red[5] + red[7];
+            float ts = 0.f, tc = 0.f;
+            for (int w = 0; w < kRefocusThreads / 64; ++w) { ts += red[2 * w]; tc += red[2 * w + 1]; }
             s_dsensor = ts / tc;
             s_count = (int)tc;
         }
@@ -465,7 +513,8 @@ __global__ __launch_bounds__(256) void refocus_kernel(const float* __restrict__ 
     const int any_nan = __syncthreads_or(nan_flag);
     if (tid == 0) {
         if (any_nan) flags |= 1;
-        const float ts = red[0] + red[2] + red[4] + red[6], tw = red[1] + red[3] + red[5] + red[7];
+        float ts = 0.f, tw = 0.f;
+        for (int w = 0; w < kRefocusThreads / 64; ++w) { ts += red[2 * w]; tw += red[2 * w + 1]; }
         float hfov = atanf(ts / tw);
         if (hfov != hfov) { hfov = 0.5f; flags |= 2; }
         const double th = tan((double)hfov);
@@ -552,7 +601,7 @@ int aadff_refocus(const float* depth, int S, const float* u, int spp, long u_str
                   aadff_stream_t stream) {
     AADFF_CHECK_ARG(depth && u && surf_green && states, "refocus: NULL pointer");
     AADFF_CHECK_ARG(S > 0 && spp > 0 && lc.n_surf > 0 && lc.n_surf <= AADFF_MAX_SURF, "refocus: bad sizes S=%d spp=%d", S, spp);
-    hipLaunchKernelGGL(refocus_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, depth, u, spp, u_stride_s, surf_green, lc, states, 1);
+    hipLaunchKernelGGL(refocus_kernel, dim3(S), dim3(kRefocusThreads), 0, (hipStream_t)stream, depth, u, spp, u_stride_s, surf_green, lc, states, 1);
     AADFF_CHECK_LAUNCH();
     return 0;
 }
@@ -561,7 +610,7 @@ int aadff_post_computation(int S, const aadff_surface_t* surf_green, aadff_lens_
                            aadff_stream_t stream) {
     AADFF_CHECK_ARG(surf_green && states, "post_computation: NULL pointer");
     AADFF_CHECK_ARG(S > 0 && lc.n_surf > 0 && lc.n_surf <= AADFF_MAX_SURF, "post_computation: bad sizes S=%d", S);
-    hipLaunchKernelGGL(refocus_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr,
+    hipLaunchKernelGGL(refocus_kernel, dim3(S), dim3(kRefocusThreads), 0, (hipStream_t)stream, (const float*)nullptr,
                        (const float*)nullptr, 0, 0L, surf_green, lc, states, 0);
     AADFF_CHECK_LAUNCH();
     return 0;

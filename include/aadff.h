@@ -185,6 +185,15 @@ int aadff_refocus(const float* depth, int S, const float* u, int spp, long u_str
 int aadff_post_computation(int S, const aadff_surface_t* surf_green, aadff_lens_const_t lc,
                            aadff_lens_state_t* states, aadff_stream_t stream);
 
+/* ------------------------------------------------------------------ host helper */
+
+/* HOST routine (no GPU work): the next n float32 uniforms of torch's CPU generator, bit-identical
+ * to torch.rand(n), produced from / written back to the byte state of torch.get_rng_state()
+ * (5056 bytes).  Replaces the host draws torch.rand(spp) of deeplens/optics.py:480-481 and
+ * deeplens/surfaces.py:192-193 at ~7x the speed while leaving torch's generator exactly where the
+ * reference's call sequence would.  out_host may be pinned memory. */
+int aadff_host_mt19937_uniform_f32(unsigned char* torch_state_host, long state_bytes, long n, float* out_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,3 +122,31 @@ def test_reference_assertions_are_kept():
         render_psf_map(torch.rand(1, 3, 16, 16), torch.rand(3, 8, 8), 2)
     with pytest.raises(AssertionError, match="same channel"):
         render_psf_map(torch.rand(1, 1, 16, 16), torch.rand(3, 6, 6), 2)
+
+
+def test_fast_host_rng_continues_torch_generator_bit_exactly():
+    """aadff_host_mt19937_uniform_f32 == torch.rand, draw for draw, and leaves torch's global
+    generator in the identical state (also across MT19937 block boundaries and odd sizes)."""
+    import aadff.sampling as sm
+    s = HostSampler()
+    sizes = [1, 7, 623, 624, 625, 2048, 5000, 3]
+    torch.manual_seed(123)
+    want = [torch.rand(n) for n in sizes]
+    tail_want = torch.rand(9)
+    state_want = torch.get_rng_state()
+    torch.manual_seed(123)
+    got = [s.rand_block([n]) for n in sizes]
+    assert sm._FAST is True, "fast host RNG path was not taken"
+    tail_got = torch.rand(9)
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
+    assert torch.equal(tail_want, tail_got) and torch.equal(state_want, torch.get_rng_state())
+    # interleaving with torch.randn / np-free draws keeps working
+    torch.manual_seed(5)
+    a1, z1, a2 = torch.rand(10), torch.randn(4), torch.rand(10)
+    torch.manual_seed(5)
+    b1, z2, b2 = s.rand_block([10]), torch.randn(4), s.rand_block([10])
+    assert torch.equal(a1, b1) and torch.equal(z1, z2) and torch.equal(a2, b2)
+    lib = _abi.load_library()
+    import ctypes as C
+    bad = torch.zeros(100, dtype=torch.uint8)
+    assert lib.aadff_host_mt19937_uniform_f32(C.c_void_p(bad.data_ptr()), 100, 4, C.c_void_p(torch.empty(4).data_ptr())) == -1
