@@ -86,8 +86,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    from aadff.dist import init_from_env
+    init_from_env(backend="nccl", device=dev)       # RCCL; no-op for a single process
 
     from aadff.focal_stack import StackPlan, render_focal_stack_m1
     from aadff.sampling import DeviceSampler

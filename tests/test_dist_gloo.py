@@ -1,0 +1,72 @@
+"""CPU, world size 2, gloo: the sharded render + all-gather reassembles exactly the single-rank
+result (units are independent, so the check is bit-for-bit).  The per-unit
+renderer here is the oracle convolution (no GPU in this container); on the GPU box the same
+`render_sharded` runs with the HIP renderer over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from aadff.dist import init_from_env, padded_share, render_sharded, shard_units
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _unit_renderer():
+    from aadff.synth import synth_rgb
+    from oracle import conv as oconv
+    rng = np.random.Generator(np.random.PCG64(42))
+    imgs = [torch.from_numpy(synth_rgb(24, 32, seed=100 + i))[None] for i in range(3)]        # 3 scenes
+    maps = torch.from_numpy(rng.random((5, 3, 9, 9), dtype=np.float32)) / 9                    # 5 slices, grid 3, ks 3
+
+    def render(u):          # unit = (scene, slice)
+        scene, sl = divmod(u, 5)
+        return oconv.render_psf_map(imgs[scene], maps[sl], 3)[0]
+    return render, 15, (3, 24, 32)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    r, w = init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    render, n, shape = _unit_renderer()
+    full, mine = render_sharded(n, render, shape, gather=True)
+    assert mine == shard_units(n, rank, world)
+    torch.save(full, os.path.join(out_dir, f"full_{rank}.pt"))
+    local, mine2 = render_sharded(n, render, shape, gather=False)          # rank-local consumer: no collective
+    assert local.shape[0] == padded_share(n, world) and mine2 == mine
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_render_equals_single_rank(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    render, n, shape = _unit_renderer()
+    want = torch.stack([render(u) for u in range(n)])
+    for r in range(world):
+        got = torch.load(os.path.join(tmp_path, f"full_{r}.pt"))
+        assert got.shape == want.shape
+        assert torch.equal(got, want), f"rank {r}: gathered stack differs from the single-rank render"
+
+
+def test_single_process_path_needs_no_group():
+    render, n, shape = _unit_renderer()
+    full, mine = render_sharded(n, render, shape, gather=True)
+    assert mine == list(range(n)) and torch.equal(full, torch.stack([render(u) for u in range(n)]))
+
+
+def test_uneven_unit_counts_are_padded():
+    assert padded_share(15, 2) == 8 and padded_share(160, 8) == 20 and padded_share(7, 8) == 1
+    assert sorted(shard_units(15, 0, 2) + shard_units(15, 1, 2)) == list(range(15))
