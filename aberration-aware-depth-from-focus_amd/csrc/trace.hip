@@ -51,12 +51,16 @@ __device__ __forceinline__ void sag_and_slope(const aadff_surface_t& s, float r2
     sag = r2 * s.c * frcp(1.f + sf);
     slope = 0.5f * s.c * frcp(sf);
     if (s.n_ai > 0) {
-        float p = 1.f;
-        for (int j = 0; j < s.n_ai; ++j) {
-            slope += (float)(j + 1) * s.ai[j] * p;
-            p *= r2;
-            sag += s.ai[j] * p;
+        // sum a_j r2^j and its derivative by Horner over the fixed-size coefficient array (unused tail is 0):
+        // the reference's power form (surfaces.py:799,823) differs by rounding of terms that are < 1e-3 of the sag
+        float ps = s.ai[AADFF_MAX_AI - 1], pd = (float)AADFF_MAX_AI * s.ai[AADFF_MAX_AI - 1];
+#pragma unroll
+        for (int j = AADFF_MAX_AI - 2; j >= 0; --j) {
+            ps = ps * r2 + s.ai[j];
+            pd = pd * r2 + (float)(j + 1) * s.ai[j];
         }
+        sag += ps * r2;
+        slope += pd;
     }
 }
 
@@ -112,56 +116,57 @@ __device__ __forceinline__ void newton(const aadff_surface_t& s, const Ray& r, f
 }
 
 // ---- vector Snell refraction with the surface normal: deeplens/surfaces.py:589-679 ----
+// KEEP = true: a ray that fails keeps its direction (the reference leaves dead rays untouched and the
+// generic trace API exposes them); KEEP = false (fused PSF / refocus kernels): dead rays are never read
+// again, so nothing is preserved.
+// Sphere normal: the reference normalises +-2 (x, y, z - (d + R)); since |p - centre| = |R| on the sphere
+// that unit vector is exactly (c x, c y, c (z - d) - 1) for either sign of c -> no normalisation needed.
+// Refracted direction sr n + eta (d - cosi n) is evaluated as eta d + (sr - eta cosi) n.
+template <bool KEEP>
 __device__ __forceinline__ void refract(const aadff_surface_t& s, Ray& r, bool forward) {
     float nx, ny, nz;
     if (s.kind == AADFF_SURF_STOP) {
         nx = 0.f; ny = 0.f; nz = -1.f;
     } else if (s.kind == AADFF_SURF_SPHERIC) {
-        if (s.c > 0.f) {
-            nx = 2.f * r.ox; ny = 2.f * r.oy; nz = 2.f * r.oz - 2.f * s.d_plus_roc;
-        } else {
-            nx = -2.f * r.ox; ny = -2.f * r.oy; nz = -2.f * r.oz + 2.f * s.d_plus_roc;
-        }
+        nx = s.c * r.ox; ny = s.c * r.oy; nz = s.c * (r.oz - s.d) - 1.f;
     } else {
         const float g = dsag_dr2(s, r.ox * r.ox + r.oy * r.oy);
         nx = g * 2.f * r.ox; ny = g * 2.f * r.oy; nz = -1.f;
+        const float inv = frsq(fmaxf(nx * nx + ny * ny + 1.f, 1e-24f));           // F.normalize
+        nx *= inv; ny *= inv; nz = -inv;
     }
-    const float inv = frsq(fmaxf(nx * nx + ny * ny + nz * nz, 1e-24f));           // F.normalize (eps 1e-12 on the norm)
-    nx *= inv; ny *= inv; nz *= inv;
-    if (forward) { nx = -nx; ny = -ny; nz = -nz; }
+    // forward rays use -n (surfaces.py:654-655): fold the sign into cosi and the final combination
+    const float sgn = forward ? -1.f : 1.f;
     const float eta = forward ? s.eta_fwd : s.eta_bwd;
     const float eta2 = forward ? s.eta_fwd2 : s.eta_bwd2;
-    const float cosi = r.dx * nx + r.dy * ny + r.dz * nz;
+    const float cosi = sgn * (r.dx * nx + r.dy * ny + r.dz * nz);
     const float sin2 = eta2 * (1.f - cosi * cosi);
     const bool valid = (cosi * cosi > 0.1f) && (sin2 < 1.f);
-    if (valid) {
-        const float sr = fsqrt(1.f - sin2);
-        r.dx = sr * nx + eta * (r.dx - cosi * nx);
-        r.dy = sr * ny + eta * (r.dy - cosi * ny);
-        r.dz = sr * nz + eta * (r.dz - cosi * nz);
-    } else {
-        r.ra = 0.f;
-    }
-}
-
-// ---- one surface interaction: deeplens/surfaces.py:391-520 (dead rays are untouched) ----
-__device__ __forceinline__ void react(const aadff_surface_t& s, Ray& r, bool forward, int& nan_flag) {
-    if (!(r.ra > 0.f)) return;
-    if (s.kind == AADFF_SURF_STOP) {
-        const float t = fdiv(s.d - r.oz, r.dz);
-        const float px = r.ox + t * r.dx, py = r.oy + t * r.dy, pz = r.oz + t * r.dz;
-        if (fsqrt(px * px + py * py) <= s.r) {
-            r.ox = px; r.oy = py; r.oz = pz;
-            if (forward ? s.refract_fwd : s.refract_bwd) refract(s, r, forward);
+    const float g = sgn * (fsqrt(fmaxf(1.f - sin2, 0.f)) - eta * cosi);
+    if (KEEP) {
+        if (valid) {
+            r.dx = eta * r.dx + g * nx; r.dy = eta * r.dy + g * ny; r.dz = eta * r.dz + g * nz;
         } else {
             r.ra = 0.f;
         }
-        return;
+    } else {
+        r.dx = eta * r.dx + g * nx; r.dy = eta * r.dy + g * ny; r.dz = eta * r.dz + g * nz;
+        r.ra = valid ? r.ra : 0.f;
     }
+}
+
+// ---- one surface interaction: deeplens/surfaces.py:391-520 (dead rays are skipped) ----
+template <bool KEEP>
+__device__ __forceinline__ void react(const aadff_surface_t& s, Ray& r, bool forward, int& nan_flag) {
+    if (!(r.ra > 0.f)) return;
     float t, px, py, pz;
     bool valid;
+    if (s.kind == AADFF_SURF_STOP) {
+        t = fdiv(s.d - r.oz, r.dz);
+        px = r.ox + t * r.dx; py = r.oy + t * r.dy; pz = r.oz + t * r.dz;
+        valid = fsqrt(px * px + py * py) <= s.r;
 #ifndef AADFF_SPHERE_NEWTON
-    if (s.kind == AADFF_SPHERIC_CLOSED_FORM) {
+    } else if (s.kind == AADFF_SURF_SPHERIC) {
         // Sphere (k = 0, no polynomial): closed-form root instead of the reference's Newton iteration
         // (deeplens/surfaces.py:456-487 keeps Newton's t but DISCARDS its convergence mask, so only the root
         // matters).  From the vertex-plane point p0 = o + d*t0 the sphere |p - (0,0,d+R)| = R reads
@@ -178,31 +183,31 @@ __device__ __forceinline__ void react(const aadff_surface_t& s, Ray& r, bool for
         t = t0 + tau;
         px = p0x + r.dx * tau; py = p0y + r.dy * tau; pz = s.d + r.dz * tau;
         valid = (disc >= 0.f) && (px * px + py * py <= s.r2) && (t >= 0.f);
-    } else
 #endif
-    {
+    } else {
         bool nvalid;
         newton(s, r, t, nvalid, nan_flag);
         px = r.ox + t * r.dx; py = r.oy + t * r.dy; pz = r.oz + t * r.dz;
-        if (s.kind == AADFF_SURF_SPHERIC)
-            valid = (px * px + py * py <= s.r2) && (t >= 0.f);      // Newton's own mask is discarded (:466)
-        else
-            valid = nvalid;
+        valid = s.kind == AADFF_SURF_SPHERIC ? ((px * px + py * py <= s.r2) && (t >= 0.f))   // Newton's own mask is discarded (:466)
+                                             : nvalid;
     }
-    if (valid) {
+    if (KEEP) {
+        if (!valid) { r.ra = 0.f; return; }
         r.ox = px; r.oy = py; r.oz = pz;
-        refract(s, r, forward);
     } else {
-        r.ra = 0.f;
+        r.ox = px; r.oy = py; r.oz = pz;
+        if (!valid) { r.ra = 0.f; return; }
     }
+    if (s.kind != AADFF_SURF_STOP || (forward ? s.refract_fwd : s.refract_bwd)) refract<KEEP>(s, r, forward);
 }
 
+template <bool KEEP>
 __device__ __forceinline__ void trace_range(const aadff_surface_t* __restrict__ surf, int first, int last, bool forward,
                                             Ray& r, int& nan_flag) {
     if (forward)
-        for (int i = first; i < last; ++i) react(surf[i], r, true, nan_flag);
+        for (int i = first; i < last; ++i) react<KEEP>(surf[i], r, true, nan_flag);
     else
-        for (int i = last - 1; i >= first; --i) react(surf[i], r, false, nan_flag);
+        for (int i = last - 1; i >= first; --i) react<KEEP>(surf[i], r, false, nan_flag);
 }
 
 __device__ __forceinline__ void propagate_to(Ray& r, float z) {      // deeplens/basics.py:255-273 (all rays)
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(256) void trace_rays_kernel(const float* o_in, cons
     r.dx = d_in[3 * i]; r.dy = d_in[3 * i + 1]; r.dz = d_in[3 * i + 2];
     r.ra = ra_in ? ra_in[i] : 1.f;
     int nan_flag = 0;
-    trace_range(surf, first, last, forward != 0, r, nan_flag);
+    trace_range<true>(surf, first, last, forward != 0, r, nan_flag);
     if (state) propagate_to(r, state->d_sensor);
     o_out[3 * i] = r.ox; o_out[3 * i + 1] = r.oy; o_out[3 * i + 2] = r.oz;
     d_out[3 * i] = r.dx; d_out[3 * i + 1] = r.dy; d_out[3 * i + 2] = r.dz;
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256) void trace_points_kernel(const float* __restri
     disc_sample(u_theta[i], u_r[i], pupil_r2, x2, y2);
     Ray r = ray_to(pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], x2, y2, pupil_z);
     int nan_flag = 0;
-    trace_range(surf, 0, n_surf, true, r, nan_flag);
+    trace_range<true>(surf, 0, n_surf, true, r, nan_flag);
     propagate_to(r, state->d_sensor);
     const size_t e = (size_t)i * N + n;
     o_out[3 * e] = r.ox; o_out[3 * e + 1] = r.oy; o_out[3 * e + 2] = r.oz;
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
             float x2, y2;
             disc_sample(ut[i], ur[i], lc.enp_r2_shrunk, x2, y2);
             Ray r = ray_to(px, py, depth, x2, y2, lc.enp_z);
-            trace_range(surf_chief, 0, lc.n_surf, true, r, nan_flag);
+            trace_range<false>(surf_chief, 0, lc.n_surf, true, r, nan_flag);
             propagate_to(r, st.d_sensor);
             sx += r.ox * r.ra; sy += r.oy * r.ra; sw += r.ra;
         }
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
         float x2, y2;
         disc_sample(ut[i], ur[i], lc.enp_r2, x2, y2);
         Ray r = ray_to(px, py, depth, x2, y2, lc.enp_z);
-        trace_range(tab, 0, lc.n_surf, true, r, nan_flag);
+        trace_range<false>(tab, 0, lc.n_surf, true, r, nan_flag);
         propagate_to(r, st.d_sensor);
         splat_hit(hist, g, r.ox, r.oy, r.ra, cx, cy);
     }
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(kRefocusThreads) void refocus_kernel(const float* _
             r.dx = x2; r.dy = y2; r.dz = lc.first_d - dep;           // o - (0,0,depth)
             normalize3(r.dx, r.dy, r.dz);
             r.ra = 1.f;
-            trace_range(surf, 0, lc.n_surf, true, r, nan_flag);
+            trace_range<false>(surf, 0, lc.n_surf, true, r, nan_flag);
             float t = (r.dx * r.ox + r.dy * r.oy) / (r.dx * r.dx + r.dy * r.dy);
             t = t * r.ra;
             const float fd = r.oz - r.dz * t;
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(kRefocusThreads) void refocus_kernel(const float* _
         const float step = (end - start) / (float)(M - 1);
         const float x2 = tid < M / 2 ? start + step * (float)tid : end - step * (float)(M - 1 - tid);   // torch.linspace
         Ray r = ray_to(lc.r_last, 0.f, d_sensor, x2, 0.f, lc.exp_z);
-        trace_range(surf, 0, lc.n_surf, false, r, nan_flag);
+        trace_range<false>(surf, 0, lc.n_surf, false, r, nan_flag);
         tsum = (r.dx / r.dz) * r.ra;
         wsum = r.ra;
     }
