@@ -51,13 +51,17 @@ __device__ __forceinline__ void sag_and_slope(const aadff_surface_t& s, float r2
     sag = r2 * s.c * frcp(1.f + sf);
     slope = 0.5f * s.c * frcp(sf);
     if (s.n_ai > 0) {
-        // sum a_j r2^j and its derivative by Horner over the fixed-size coefficient array (unused tail is 0):
-        // the reference's power form (surfaces.py:799,823) differs by rounding of terms that are < 1e-3 of the sag
-        float ps = s.ai[AADFF_MAX_AI - 1], pd = (float)AADFF_MAX_AI * s.ai[AADFF_MAX_AI - 1];
+        // sum a_j r2^j and its derivative by Horner (the reference's power form, surfaces.py:799,823, differs
+        // by rounding of terms that are < 1e-3 of the sag); derivative coefficients (j+1) a_j come from the table
+        float ps, pd;
+        if (s.n_ai <= 6) {
+            ps = s.ai[5]; pd = s.dai[5];
 #pragma unroll
-        for (int j = AADFF_MAX_AI - 2; j >= 0; --j) {
-            ps = ps * r2 + s.ai[j];
-            pd = pd * r2 + (float)(j + 1) * s.ai[j];
+            for (int j = 4; j >= 0; --j) { ps = ps * r2 + s.ai[j]; pd = pd * r2 + s.dai[j]; }
+        } else {
+            ps = s.ai[AADFF_MAX_AI - 1]; pd = s.dai[AADFF_MAX_AI - 1];
+#pragma unroll
+            for (int j = AADFF_MAX_AI - 2; j >= 0; --j) { ps = ps * r2 + s.ai[j]; pd = pd * r2 + s.dai[j]; }
         }
         sag += ps * r2;
         slope += pd;
@@ -96,11 +100,34 @@ __device__ __forceinline__ float newton_step(const aadff_surface_t& s, const Ray
     return ft;
 }
 
+// Root of the ray with the CONIC part of the surface, measured from the vertex-plane point p0 = o + d t0:
+//   c (1 + k dz^2) tau^2 + 2 beta tau + c rho^2 = 0,  beta = c (p0x dx + p0y dy) - dz,  rho^2 = p0x^2 + p0y^2
+// (from c (1+k) z^2 - 2 z + c r^2 = 0 with z = dz tau); the root next to the vertex plane in cancellation-free
+// form.  k = 0 is the sphere.  Returns false when the ray misses the conic.
+__device__ __forceinline__ bool conic_root(const aadff_surface_t& s, const Ray& r, float t0, float& p0x, float& p0y, float& tau) {
+    p0x = r.ox + r.dx * t0; p0y = r.oy + r.dy * t0;
+    const float rho2 = p0x * p0x + p0y * p0y;
+    const float beta = s.c * (p0x * r.dx + p0y * r.dy) - r.dz;
+    const float A = s.c * (1.f + s.k * r.dz * r.dz);
+    const float disc = beta * beta - A * (s.c * rho2);
+    const float root = fsqrt(fmaxf(disc, 0.f));
+    tau = fdiv(s.c * rho2, beta < 0.f ? (root - beta) : -(root + beta));
+    return disc >= 0.f;
+}
+
 __device__ __forceinline__ void newton(const aadff_surface_t& s, const Ray& r, float& t_out, bool& valid_out, int& nan_flag) {
     const float dxy2 = r.dx * r.dx + r.dy * r.dy;
     const float od = r.dx * r.ox + r.dy * r.oy;
     const float t0 = fdiv(s.d - r.oz, r.dz);
     float t = t0;
+#ifndef AADFF_NEWTON_PLANE_START
+    // start from the conic root instead of the vertex plane (surfaces.py:543): Newton then only has to absorb
+    // the polynomial departure (1-2 steps instead of 3-4) and reaches the same root within its tolerance
+    {
+        float p0x, p0y, tau;
+        if (conic_root(s, r, t0, p0x, p0y, tau)) t = t0 + tau;
+    }
+#endif
     float ft = kMaxT;
     for (int it = 0; it < kNewtonMaxIter; ++it) {
         if (!__any(fabsf(ft) > kTolLoose)) break;
@@ -174,15 +201,11 @@ __device__ __forceinline__ void react(const aadff_surface_t& s, Ray& r, bool for
         // whose root next to the vertex plane is, in cancellation-free form and scaled by c = 1/R,
         //   tau = c rho^2 / (-beta + sgn(-beta) sqrt(beta^2 - c^2 rho^2)),   beta = c (p0x dx + p0y dy) - dz.
         const float t0 = fdiv(s.d - r.oz, r.dz);
-        const float p0x = r.ox + r.dx * t0, p0y = r.oy + r.dy * t0;
-        const float rho2 = p0x * p0x + p0y * p0y;
-        const float beta = s.c * (p0x * r.dx + p0y * r.dy) - r.dz;
-        const float disc = beta * beta - (s.c * s.c) * rho2;
-        const float root = fsqrt(fmaxf(disc, 0.f));
-        const float tau = fdiv(s.c * rho2, beta < 0.f ? (root - beta) : -(root + beta));
+        float p0x, p0y, tau;
+        const bool hit = conic_root(s, r, t0, p0x, p0y, tau);
         t = t0 + tau;
         px = p0x + r.dx * tau; py = p0y + r.dy * tau; pz = s.d + r.dz * tau;
-        valid = (disc >= 0.f) && (px * px + py * py <= s.r2) && (t >= 0.f);
+        valid = hit && (px * px + py * py <= s.r2) && (t >= 0.f);
 #endif
     } else {
         bool nvalid;

@@ -87,6 +87,7 @@ class Aspheric(Surface):
         s.n_ai = self.ai_degree
         for i in range(self.ai_degree):
             s.ai[i] = float(self.ai[i].item())
+            s.dai[i] = float(f32(i + 1) * f32(self.ai[i].item()))
         return s
 
     def ray_reaction(self, ray):

@@ -39,7 +39,7 @@ enum { AADFF_SURF_STOP = 0, AADFF_SURF_SPHERIC = 1, AADFF_SURF_ASPHERIC = 2 };
 
 /* One surface at ONE wavelength.  Host code fills it (deeplens/optics.py: LensTable);
  * values that the reference forms in float64 Python arithmetic and then feeds to fp32
- * tensor ops are rounded to fp32 exactly once, here.  96 bytes. */
+ * tensor ops are rounded to fp32 exactly once, here.  128 bytes. */
 typedef struct aadff_surface {
     float d;            /* vertex z [mm]                            surfaces.py:11-14 */
     float c;            /* curvature 1/roc                          surfaces.py:304   */
@@ -57,7 +57,8 @@ typedef struct aadff_surface {
     int   refract_fwd;  /* 0 when kind==STOP and eta_fwd==1 (air-air stop skips it)   surfaces.py:449 */
     int   refract_bwd;
     int   k_gt_m1;      /* k > -1 selects the shape-domain test     surfaces.py:727,738 */
-    float ai[AADFF_MAX_AI];
+    float ai[AADFF_MAX_AI];   /* a2, a4, ... (coefficient of r^(2(j+1)))       surfaces.py:799 */
+    float dai[AADFF_MAX_AI];  /* (j+1) * ai[j] in fp32: derivative coefficients surfaces.py:823 */
 } aadff_surface_t;
 
 /* Per-focus-setting lens state; lives on the device so a whole stack is rendered
