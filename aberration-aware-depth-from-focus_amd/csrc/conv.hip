@@ -358,16 +358,84 @@ static int conv_dispatch(const float* img, const float* psf, float* out, int B, 
 }
 
 // ------------------------------------------------------------------------------------
-// Per-pixel PSF gather (local_psf_render): HBM-bound on the PSF tensor (ks*ks*4 B/pixel).
-// One wave per run of NPX consecutive pixels of one image row:
-//   * the NPX*ks*ks PSF floats are contiguous in [B,H,W,ks,ks] -> fully coalesced stream
-//     into LDS; lane l then walks its own PSF at stride ks*ks (odd -> conflict-free);
-//   * the C x ks x (NPX+ks-1) replicate-clamped image window sits in LDS as well;
+// Per-pixel PSF gather (local_psf_render): HBM-bound on the PSF tensor (ks*ks*4 B/pixel + 24 B/pixel).
+// One wave per run of 64 consecutive pixels of one image row:
+//   * lane l streams ITS pixel's ks*ks taps straight from global memory with 16-byte loads (the taps of
+//     a pixel are contiguous; every byte of every cache line is used, the lines live in L1 for the few
+//     loads that share them) - no LDS round trip for the 484 B/pixel stream, so 8+ waves per CU keep
+//     tens of KB of loads in flight;
+//   * only the C x ks x (64+ks-1) replicate-clamped image window is staged in LDS (read at lane+v:
+//     conflict-free);
 //   * no flip (render_psf.py:99-105 multiplies unfold() patches with the kernel as is).
 // ------------------------------------------------------------------------------------
-template <int NPX>
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };   // 16-byte load at 4-byte alignment
+
+constexpr int LP_NPX = 64, LP_MAXC = 4;
+
+template <int KS>
 __global__ __launch_bounds__(64) void local_psf_kernel(const float* __restrict__ img, const float* __restrict__ psf,
-                                                        float* __restrict__ out, int C, int H, int W, int ks) {
+                                                        float* __restrict__ out, int C, int H, int W) {
+    constexpr int KK = KS * KS, PAD = KS / 2, TWD = LP_NPX + KS - 1;
+    __shared__ float tl[LP_MAXC * KS * TWD];
+    const int lane = threadIdx.x;
+    const int x0 = blockIdx.x * LP_NPX, y = blockIdx.y, b = blockIdx.z;
+    const int npx = min(LP_NPX, W - x0);
+    const bool act = lane < npx;
+    const float* pp = psf + ((size_t)(b * H + y) * W + x0 + (act ? lane : 0)) * KK;
+
+    // first batch of tap loads is in flight while the image window is staged
+    constexpr int NB = 8;                                    // 16-byte loads per batch
+    constexpr int NV = KK / 4, REM = KK - 4 * NV;            // KK = 4*NV + REM
+    f4u wq[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+        if (i < NV) wq[i] = *reinterpret_cast<const f4u*>(pp + 4 * i);
+
+    for (int e = lane; e < C * KS * TWD; e += kWave) {
+        const int cc = e / (KS * TWD), rem = e - cc * KS * TWD;
+        const int u = rem / TWD, xx = rem - u * TWD;
+        const int yy = min(max(y - PAD + u, 0), H - 1);
+        const int xs = min(max(x0 - PAD + xx, 0), W - 1);
+        tl[e] = img[((size_t)(b * C + cc) * H + yy) * W + xs];
+    }
+    __syncthreads();
+
+    float acc[LP_MAXC] = {0.f, 0.f, 0.f, 0.f};
+    auto tap = [&](int t, float wv) {
+        const int u = t / KS, v = t - u * KS;
+#pragma unroll
+        for (int cc = 0; cc < LP_MAXC; ++cc)
+            if (cc < C) acc[cc] = fmaf(tl[(cc * KS + u) * TWD + lane + v], wv, acc[cc]);
+    };
+#pragma unroll
+    for (int base = 0; base < NV; base += NB) {
+        f4u cur[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) cur[i] = wq[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i)                           // next batch goes out before this one is consumed
+            if (base + NB + i < NV) wq[i] = *reinterpret_cast<const f4u*>(pp + 4 * (base + NB + i));
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (base + i < NV) {
+                const int t = 4 * (base + i);
+                tap(t, cur[i].x); tap(t + 1, cur[i].y); tap(t + 2, cur[i].z); tap(t + 3, cur[i].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < REM; ++i) tap(4 * NV + i, pp[4 * NV + i]);
+    if (act) {
+#pragma unroll
+        for (int cc = 0; cc < LP_MAXC; ++cc)
+            if (cc < C) out[((size_t)(b * C + cc) * H + y) * W + x0 + lane] = acc[cc];
+    }
+}
+
+// any odd ks / any channel count: PSFs through LDS (the previous design), correctness path
+template <int NPX>
+__global__ __launch_bounds__(64) void local_psf_generic_kernel(const float* __restrict__ img, const float* __restrict__ psf,
+                                                                float* __restrict__ out, int C, int H, int W, int ks) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int kk = ks * ks, pad = ks / 2, tw = NPX + ks - 1;
     float* wl = smem;                 // [NPX][kk]
@@ -444,18 +512,27 @@ int aadff_local_psf_render(const float* img, const float* psf, float* out, int B
     AADFF_CHECK_ARG(ks % 2 == 1 && ks >= 1 && ks <= AADFF_MAX_KS, "local_psf_render: ks %d must be odd and <= %d", ks, AADFF_MAX_KS);
     AADFF_CHECK_ARG(H <= 65535 && B <= 65535, "local_psf_render: H or B too large for the launch grid");
     hipStream_t st = (hipStream_t)stream;
-    const int npx = ks <= 15 ? 64 : 16;
-    const size_t lds = ((size_t)npx * ks * ks + (size_t)C * ks * (npx + ks - 1)) * sizeof(float);
-    AADFF_CHECK_ARG(lds <= 160 * 1024, "local_psf_render: C=%d ks=%d needs %zu B of LDS", C, ks, lds);
-    dim3 g((W + npx - 1) / npx, H, B);
-    if (npx == 64) {
-        if (lds > 64 * 1024)
-            AADFF_CHECK_HIP(hipFuncSetAttribute((const void*)local_psf_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(local_psf_kernel<64>, g, dim3(64), lds, st, img, psf, out, C, H, W, ks);
+    if (C <= LP_MAXC && (ks == 3 || ks == 5 || ks == 7 || ks == 9 || ks == 11 || ks == 13)) {
+        dim3 g((W + LP_NPX - 1) / LP_NPX, H, B);
+        switch (ks) {
+#define AADFF_LP(K) case K: hipLaunchKernelGGL(local_psf_kernel<K>, g, dim3(64), 0, st, img, psf, out, C, H, W); break;
+            AADFF_LP(3) AADFF_LP(5) AADFF_LP(7) AADFF_LP(9) AADFF_LP(11) AADFF_LP(13)
+#undef AADFF_LP
+        }
     } else {
-        if (lds > 64 * 1024)
-            AADFF_CHECK_HIP(hipFuncSetAttribute((const void*)local_psf_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(local_psf_kernel<16>, g, dim3(64), lds, st, img, psf, out, C, H, W, ks);
+        const int npx = ks <= 15 ? 64 : 16;
+        const size_t lds = ((size_t)npx * ks * ks + (size_t)C * ks * (npx + ks - 1)) * sizeof(float);
+        AADFF_CHECK_ARG(lds <= 160 * 1024, "local_psf_render: C=%d ks=%d needs %zu B of LDS", C, ks, lds);
+        dim3 g((W + npx - 1) / npx, H, B);
+        if (npx == 64) {
+            if (lds > 64 * 1024)
+                AADFF_CHECK_HIP(hipFuncSetAttribute((const void*)local_psf_generic_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(local_psf_generic_kernel<64>, g, dim3(64), lds, st, img, psf, out, C, H, W, ks);
+        } else {
+            if (lds > 64 * 1024)
+                AADFF_CHECK_HIP(hipFuncSetAttribute((const void*)local_psf_generic_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(local_psf_generic_kernel<16>, g, dim3(64), lds, st, img, psf, out, C, H, W, ks);
+        }
     }
     AADFF_CHECK_LAUNCH();
     return 0;

@@ -454,3 +454,16 @@ def test_get_training_data_shapes_and_normalisation(repo_root):
     s = psf.sum(-1).cpu().numpy()
     ok = np.isfinite(s)
     assert ok.mean() > 0.9 and np.abs(s[ok] - 1).max() <= 1e-5
+
+
+def test_psfnet_render_bf16_mode_is_opt_in_and_close(g67, psfnet64):
+    """Opt-in bf16 MLP: not a parity mode (tolerance 5e-3 on the image), default stays fp32."""
+    img = tt(synth_rgb(64, 64, seed=11))[None].to(DEV)
+    depth = -tt(synth_depth_mm(64, 64, seed=12))[None, None].to(DEV)
+    assert psfnet64.mlp_precision == "fp32"
+    psfnet64.mlp_precision = "bf16"
+    try:
+        out = psfnet64.render(img, depth, torch.tensor([-1500.0], device=DEV))
+    finally:
+        psfnet64.mlp_precision = "fp32"
+    assert rel_l2(out.cpu().numpy(), g67["render_out"][2:3]) <= 5e-3
