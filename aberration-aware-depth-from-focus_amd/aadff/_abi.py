@@ -19,7 +19,7 @@ SURF_STOP, SURF_SPHERIC, SURF_ASPHERIC = 0, 1, 2
 
 class Surface(C.Structure):
     _fields_ = [("d", C.c_float), ("c", C.c_float), ("k", C.c_float), ("r", C.c_float),
-                ("r2", C.c_float), ("r2_shape", C.c_float), ("d_plus_roc", C.c_float),
+                ("r2", C.c_float), ("r2_shape", C.c_float),
                 ("eta_fwd", C.c_float), ("eta_fwd2", C.c_float), ("eta_bwd", C.c_float), ("eta_bwd2", C.c_float),
                 ("kind", C.c_int), ("n_ai", C.c_int), ("refract_fwd", C.c_int), ("refract_bwd", C.c_int),
                 ("k_gt_m1", C.c_int), ("ai", C.c_float * MAX_AI), ("dai", C.c_float * MAX_AI)]
@@ -37,7 +37,7 @@ class LensConst(C.Structure):
                 ("first_d", C.c_float), ("first_r2", C.c_float)]
 
 
-assert C.sizeof(Surface) == 128 and C.sizeof(LensState) == 32 and C.sizeof(LensConst) == 52
+assert C.sizeof(Surface) == 124 and C.sizeof(LensState) == 32 and C.sizeof(LensConst) == 52
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 

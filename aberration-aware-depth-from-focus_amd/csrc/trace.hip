@@ -1,11 +1,12 @@
 // Ray tracing through the lens surfaces, PSF accumulation and refocus for gfx950.
 //
-// One thread per ray; the surface table is wave-uniform (scalar loads, SGPR operands),
-// so every branch on the surface kind is uniform.  Newton's loop exits per WAVE
-// (`__any`), which mirrors the reference's batch-wide `while (...).any()`
-// (deeplens/surfaces.py:547) at wave granularity: extra steps on converged rays are the
-// same arithmetic the reference performs.  Semantics: SURVEY.md Appendix A.1/A.2,
-// citations per function below (paths relative to the reference repo).
+// One thread per ray; the surface table is wave-uniform (scalar loads, SGPR operands), so every
+// branch on the surface kind is uniform.  Spheres are intersected in closed form (the reference
+// keeps Newton's root but discards its convergence mask for them, deeplens/surfaces.py:466); even
+// aspheres run the reference's Newton iteration, whose loop exits per WAVE (`__any`) where the
+// reference's exits per batch (`while (...).any()`, deeplens/surfaces.py:547) - extra steps on
+// converged rays are the same arithmetic the reference performs.  Semantics: SURVEY.md Appendix
+// A.1/A.2, citations per function below (paths relative to the reference repo).
 #include <cmath>
 #include "common.h"
 

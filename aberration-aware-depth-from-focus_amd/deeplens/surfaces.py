@@ -68,7 +68,7 @@ class Aspheric(Surface):
     def pack(self, wvln):
         """aadff_surface_t for one wavelength.  Python-float expressions of the reference
         (r**2, eta**2, n1/n2) are evaluated in float64 and rounded once; expressions the
-        reference evaluates on fp32 tensors (1/c, d + 1/c, (1-eps)/c^2/(1+k)) in fp32."""
+        reference evaluates on fp32 tensors ((1-eps)/c^2/(1+k), (j+1)*a_j) in fp32."""
         s = _abi.Surface()
         d, c, k = f32(self.d.item()), f32(self.c.item()), f32(self.k.item())
         s.d, s.c, s.k, s.r = d, c, k, self.r
@@ -77,7 +77,6 @@ class Aspheric(Surface):
         s.k_gt_m1 = int(k > -1)
         with np.errstate(divide="ignore"):
             s.r2_shape = f32(1.0 - 1e-9) / (c * c) / (f32(1) + k) if (c != 0 and k > -1) else f32(np.inf)
-            s.d_plus_roc = d + f32(1) / c if c != 0 else f32(0)
         n1, n2 = self.mat1.ior(wvln), self.mat2.ior(wvln)
         ef, eb = n1 / n2, n2 / n1
         s.eta_fwd, s.eta_fwd2, s.eta_bwd, s.eta_bwd2 = ef, ef ** 2, eb, eb ** 2

@@ -39,7 +39,7 @@ enum { AADFF_SURF_STOP = 0, AADFF_SURF_SPHERIC = 1, AADFF_SURF_ASPHERIC = 2 };
 
 /* One surface at ONE wavelength.  Host code fills it (deeplens/optics.py: LensTable);
  * values that the reference forms in float64 Python arithmetic and then feeds to fp32
- * tensor ops are rounded to fp32 exactly once, here.  128 bytes. */
+ * tensor ops are rounded to fp32 exactly once, here.  124 bytes. */
 typedef struct aadff_surface {
     float d;            /* vertex z [mm]                            surfaces.py:11-14 */
     float c;            /* curvature 1/roc                          surfaces.py:304   */
@@ -47,7 +47,6 @@ typedef struct aadff_surface {
     float r;            /* semi-diameter                            surfaces.py:16    */
     float r2;           /* (float)(r*r), r*r in double              surfaces.py:466,727 */
     float r2_shape;     /* fp32 (1-1e-9)/c^2/(1+k); +inf if unused  surfaces.py:727,738 */
-    float d_plus_roc;   /* fp32 d + 1/c (spheric normal)            surfaces.py:607-614 */
     float eta_fwd;      /* n1/n2 (float64 -> fp32)                  surfaces.py:400-402 */
     float eta_fwd2;     /* (n1/n2)^2 squared in float64 -> fp32     surfaces.py:658   */
     float eta_bwd;      /* n2/n1                                    surfaces.py:403-405 */

@@ -56,9 +56,9 @@ def test_surface_packing_follows_reference_rounding(repo_root):
             assert p.eta_bwd == np.float32(1 / ef if False else o.mat2.ior(w) / o.mat1.ior(w))
             if p.kind != 0:
                 assert p.r2_shape == ((1 - 1e-9) / o.c ** 2 / (1 + o.k)).item()
-                assert p.d_plus_roc == (o.d + 1 / o.c).item()
             if p.kind == 2:
                 assert p.n_ai == 6 and [p.ai[j] for j in range(6)] == [a.item() for a in o.ai]
+                assert [p.dai[j] for j in range(6)] == [((j + 1) * a).item() for j, a in enumerate(o.ai)]
     stop = lens.surfaces[5].pack(0.589)
     assert stop.kind == 0 and stop.refract_fwd == 0 and stop.refract_bwd == 0
 
