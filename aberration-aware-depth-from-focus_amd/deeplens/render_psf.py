@@ -28,6 +28,8 @@ def render_psf(img, psf):
     B, C, H, W = img.shape
     assert C == C_, "PSF map should have the same channel as image"
     assert ks == ks2 and ks % 2 == 1, "PSF kernel size should be odd"
+    if img.numel() == 0:
+        return torch.empty_like(img, dtype=torch.float32)
     x, p = _abi.f32c(img, dev), _abi.f32c(psf, dev)
     out = torch.empty_like(x)
     with torch.cuda.device(dev):
@@ -47,6 +49,8 @@ def render_psf_map(img, psf_map, grid):
     assert ks % 2 == 1, "PSF kernel size should be odd"
     B, C, H, W = img.shape
     assert C == Cpsf, "PSF map should have the same channel as image"
+    if img.numel() == 0:                      # empty batch: the reference's conv2d loop returns an empty tensor too
+        return torch.empty_like(img, dtype=torch.float32)
     dev = _prep(img, "render_psf_map")
     x, p = _abi.f32c(img, dev), _abi.f32c(psf_map, dev)
     out = torch.empty_like(x)
@@ -67,6 +71,8 @@ def render_psf_map_stack(img, psf_maps, grid):
     assert ks % 2 == 1, "PSF kernel size should be odd"
     B, C, H, W = img.shape
     assert C == Cpsf, "PSF map should have the same channel as image"
+    if img.numel() == 0 or S == 0:
+        return torch.empty((B, C, S, H, W), dtype=torch.float32, device=img.device)
     dev = _prep(img, "render_psf_map_stack")
     x, p = _abi.f32c(img, dev), _abi.f32c(psf_maps, dev)
     out = torch.empty((B, C, S, H, W), dtype=torch.float32, device=dev)
@@ -81,6 +87,8 @@ def local_psf_render(input, psf, kernel_size=11):
     if len(input.shape) < 4:
         input = input.unsqueeze(0)
     b, c, h, w = input.shape
+    if input.numel() == 0:
+        return torch.empty_like(input, dtype=torch.float32)
     dev = _prep(input, "local_psf_render")
     x = _abi.f32c(input, dev)
     p = _abi.f32c(psf, dev).reshape(-1, h, w, kernel_size, kernel_size)

@@ -467,3 +467,39 @@ def test_psfnet_render_bf16_mode_is_opt_in_and_close(g67, psfnet64):
     finally:
         psfnet64.mlp_precision = "fp32"
     assert rel_l2(out.cpu().numpy(), g67["render_out"][2:3]) <= 5e-3
+
+
+def test_empty_inputs_return_empty():
+    e = torch.empty(0, 3, 32, 32, device=DEV)
+    assert rp.render_psf_map(e, torch.rand(3, 6, 6, device=DEV), 2).shape == (0, 3, 32, 32)
+    assert rp.render_psf(e, torch.rand(3, 3, 3, device=DEV)).shape == (0, 3, 32, 32)
+    assert rp.local_psf_render(e, torch.empty(0, 32, 32, 3, 3, device=DEV), 3).shape == (0, 3, 32, 32)
+    img = torch.rand(1, 3, 32, 32, device=DEV)
+    assert rp.render_psf_map_stack(img, torch.empty(0, 3, 6, 6, device=DEV), 2).shape == (1, 3, 0, 32, 32)
+
+
+def test_full_resolution_middlebury_size_properties():
+    """1988 x 2880 (the reference's Middlebury depth maps), grid 11, ks 11, 2 images x 4 slices: the delta PSF
+    is the identity in every slice, and slices of the stack equal the single-slice render (ragged 180/181-px
+    and 261/262-px patches, non-multiple-of-32 everything)."""
+    H, W, g, ks, S = 1988, 2880, 11, 11, 4
+    rng = np.random.Generator(np.random.PCG64(8))
+    img = tt(rng.random((2, 3, H, W), dtype=np.float32)).to(DEV)
+    delta = torch.zeros(3, g, g, ks, ks)
+    delta[..., ks // 2, ks // 2] = 1
+    delta = delta.permute(0, 1, 3, 2, 4).reshape(3, g * ks, g * ks).to(DEV)
+    maps = tt(rng.random((S, 3, g * ks, g * ks), dtype=np.float32)).to(DEV) / 121
+    maps[1] = delta
+    stack = rp.render_psf_map_stack(img, maps, g)
+    assert stack.shape == (2, 3, S, H, W)
+    assert torch.equal(stack[:, :, 1], img)
+    assert torch.equal(stack[:, :, 3], rp.render_psf_map(img, maps[3], g))
+    want = oconv.render_psf_map(img[1:, :, 900:1300, 1700:2100].cpu(), maps[2].cpu(), 1) if False else None
+    # spot-check one interior patch against the oracle (patch (5,5): rows 903..1083, cols 1309..1570)
+    hb = [int(i / g * H) for i in range(g + 1)]
+    wb = [int(j / g * W) for j in range(g + 1)]
+    y0, y1, x0, x1 = hb[5], hb[6], wb[5], wb[6]
+    crop = img[0:1, :, y0 - 5:y1 + 5, x0 - 5:x1 + 5].cpu()
+    k = maps[2][:, 5 * ks:6 * ks, 5 * ks:6 * ks].cpu()
+    ref = torch.nn.functional.conv2d(crop, torch.flip(k, [1, 2]).unsqueeze(1), groups=3)
+    assert (stack[0:1, :, 2, y0:y1, x0:x1].cpu() - ref).abs().max().item() <= 4e-6
