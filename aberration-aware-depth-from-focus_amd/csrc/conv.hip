@@ -231,6 +231,190 @@ __global__ __launch_bounds__(64 * NW, AADFF_CONV_MINWAVES) void conv_psf_map_ker
 }
 
 // ------------------------------------------------------------------------------------
+// MFMA path (KS <= 11): the patch convolution as a Toeplitz GEMM on v_mfma_f32_16x16x32_f16.
+//   D[m][n] += sum_k A_u[m][k] B_u[k][n],  m = output row (16), n = output column (16), k = input column (32),
+//   A_u[m][k] = in[y+m+u][x+k],  B_u[k][n] = w(u, k-n) for 0 <= k-n < KS else 0,   summed over the KS tap rows u.
+// fp32 operands are split into two fp16 halves after an exact power-of-two pre-scale (x = hi + lo + O(2^-23 |x|)),
+// and hi*hi + hi*lo + lo*hi are accumulated in fp32 by the MFMA: every fp16 product is exact in fp32, the dropped
+// lo*lo term is 2^-22 relative, so a 121-tap sum carries ~1e-8 |sum| of split error - below the rounding of an
+// fp32 FMA chain of the same length.  3*KS MFMAs (16 cycles each) per 16x16 block: 2112 MFMA cycles per 32x32
+// tile and slice against 3872 VALU cycles for packed fp32 FMAs, with 88 instead of 131 ds_read_b128.
+// LDS image: two fp16 planes [42][48]; the 48-half pitch (6 sixteen-byte slots per row) makes the A-fragment
+// ds_read_b128 (lane = row l&15, k-group l>>4) bank-conflict free.  B fragments (Toeplitz taps, 8*KS VGPRs) are
+// built once per wave and slice from the 121 taps.
+// ------------------------------------------------------------------------------------
+#ifndef AADFF_MFMA_SPW
+#define AADFF_MFMA_SPW 1          // slices per wave from one staged tile (2 measured slower: 118 vs 74 us)
+#endif
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+// 2^(9 - floor(log2(amax))) and its inverse (exact powers of two; amax <= 0 or non-finite -> 1)
+__device__ __forceinline__ void pow2_scale(float amax, float& s, float& inv) {
+    const unsigned bits = __float_as_uint(amax);
+    int e = (int)((bits >> 23) & 0xffu) - 127;
+    const bool ok = amax > 0.f && e < 128;
+    e = max(-100, min(e, 100));
+    s = ok ? __uint_as_float((unsigned)(127 + 9 - e) << 23) : 1.f;
+    inv = ok ? __uint_as_float((unsigned)(127 - 9 + e) << 23) : 1.f;
+}
+
+template <int KS, int NW, int SPW>
+__global__ __launch_bounds__(64 * NW) void conv_psf_map_mfma_kernel(
+    const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, int C, int S, int H, int W,
+    int grid, int ntx, int nty, PatchBounds pb) {
+    constexpr int PAD = KS / 2, TWP = TW + KS - 1, THP = TH + KS - 1, P = 48, KK = KS * KS;
+    static_assert(16 + KS - 1 <= 32 && TWP <= P, "Toeplitz band must fit K = 32");
+    __shared__ __attribute__((aligned(16))) _Float16 Ahi[THP * P];
+    __shared__ __attribute__((aligned(16))) _Float16 Alo[THP * P];
+    // zero-padded flipped tap rows R_u[i] = w(u, i-15) (i = 15..15+KS-1, else 0) as fp16 hi/lo planes; a lane's 8
+    // consecutive taps start at any half index: it reads the 5 covering dwords and funnel-shifts by 0 or 16 bits
+    constexpr int RP = 48;
+    __shared__ __attribute__((aligned(16))) _Float16 rows[NW][KS][2][RP + 2];
+    __shared__ float red[NW];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pj = udiv_magic(blockIdx.x, ntx, pb.m_ntx), tx = blockIdx.x - pj * ntx;
+    const int pi = udiv_magic(blockIdx.y, nty, pb.m_nty), ty = blockIdx.y - pi * nty;
+    const int nchunk = (S + NW * SPW - 1) / (NW * SPW);
+    const int bc = udiv_magic(blockIdx.z, nchunk, pb.m_nchunk), chunk = blockIdx.z - bc * nchunk;
+    const int c = bc - udiv_magic(bc, C, pb.m_c) * C;
+    const int x_hi = pb.wb[pj + 1], y_hi = pb.hb[pi + 1];
+    const int x0 = pb.wb[pj] + tx * TW, y0 = pb.hb[pi] + ty * TH;
+    if (x0 >= x_hi || y0 >= y_hi) return;
+    const int G = grid * KS;
+
+    // ---- stage: image window -> registers (column = lane, rows strided over waves), this wave's taps -> LDS ----
+    constexpr int NR = (THP + NW - 1) / NW;
+    float v[NR];
+    float amax = 0.f;
+    {
+        const float* plane = img + (size_t)bc * H * W;
+        const int xx = reflect_idx(x0 - PAD + lane, W);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int r = wave + j * NW;
+            const int yy = reflect_idx(y0 - PAD + r, H);
+            v[j] = (lane < TWP && r < THP) ? plane[(size_t)yy * W + xx] : 0.f;
+            amax = fmaxf(amax, fabsf(v[j]));
+        }
+    }
+    amax = wave_max(amax);
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();
+    float tmax = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) tmax = fmaxf(tmax, red[w]);
+    float sx, isx;
+    pow2_scale(tmax, sx, isx);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int r = wave + j * NW;
+        if (lane < P && r < THP) {
+            const float xs = (lane < TWP) ? v[j] * sx : 0.f;
+            const _Float16 h = (_Float16)xs;
+            Ahi[r * P + lane] = h;
+            Alo[r * P + lane] = (_Float16)(xs - (float)h);
+        }
+    }
+    __syncthreads();
+
+    // lane holds B[k = 8(l>>4)+j][n = l&15] = w(u, k-n) = R_u[st + j], st = 8(l>>4) - n + 15
+    const int kq = lane >> 4, n = lane & 15;
+    const int st = 8 * kq - n + 15;
+    const unsigned sh = (st & 1) * 16;
+    const unsigned* rbase = reinterpret_cast<const unsigned*>(&rows[wave][0][0][0]) + (st >> 1);
+    constexpr int RSTRIDE = (RP + 2) / 2;                               // dwords per (u, plane) row
+    auto load_frag = [&](int u, int plane) -> half8v {
+        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+        const unsigned* q = rbase + (u * 2 + plane) * RSTRIDE;
+        const unsigned d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+        uint4v r = {__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
+                    __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh)};
+        return __builtin_bit_cast(half8v, r);
+    };
+
+#pragma unroll 1
+    for (int sp = 0; sp < SPW; ++sp) {
+    const int s = (chunk * SPW + sp) * NW + wave;
+    if (s >= S) break;
+    // this wave's taps: lane i < RP owns padded index i, i.e. tap column v = i - 15, for every tap row u
+    float wcol[KS];
+    float wmax = 0.f;
+    {
+        const int tv = lane - 15;
+        const bool in = s < S && tv >= 0 && tv < KS;
+        const float* wp = psf + ((size_t)((s < S ? s : 0) * C + c) * G + pi * KS) * G + pj * KS;
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            wcol[u] = in ? wp[(size_t)(KS - 1 - u) * G + (KS - 1 - tv)] : 0.f;       // w(u,v) = psf[KS-1-u][KS-1-v]
+            wmax = fmaxf(wmax, fabsf(wcol[u]));
+        }
+    }
+    wmax = wave_max(wmax);
+    float sw, isw;
+    pow2_scale(wmax, sw, isw);
+    if (lane < RP + 2) {
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            const float w = lane < RP ? wcol[u] * sw : 0.f;
+            const _Float16 h = (_Float16)w;
+            rows[wave][u][0][lane] = h;
+            rows[wave][u][1][lane] = (_Float16)(w - (float)h);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const float inv = isx * isw;
+    float* oplane = out + ((size_t)bc * S + s) * H * W;
+    // tap row u outermost: one Toeplitz fragment pair live at a time, four 16x16 block accumulators
+    constexpr int NBY = TH / 16, NBX = TW / 16;
+    float4v acc[NBY][NBX];
+#pragma unroll
+    for (int by = 0; by < NBY; ++by)
+#pragma unroll
+        for (int bx = 0; bx < NBX; ++bx) acc[by][bx] = (float4v){0.f, 0.f, 0.f, 0.f};
+    const int abase = n * P + 8 * kq;                                    // A fragment: row m = l&15, 8 halves at k-group l>>4
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+        const half8v bh = load_frag(u, 0), bl = load_frag(u, 1);
+#pragma unroll
+        for (int by = 0; by < NBY; ++by)
+#pragma unroll
+            for (int bx = 0; bx < NBX; ++bx) {
+                const int off = abase + (16 * by + u) * P + 16 * bx;
+                const half8v ah = *reinterpret_cast<const half8v*>(&Ahi[off]);
+                const half8v al = *reinterpret_cast<const half8v*>(&Alo[off]);
+                acc[by][bx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[by][bx], 0, 0, 0);
+                acc[by][bx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[by][bx], 0, 0, 0);
+                acc[by][bx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[by][bx], 0, 0, 0);
+            }
+    }
+    // C/D layout: column n = l&15, rows 4(l>>4) + r
+#pragma unroll
+    for (int by = 0; by < NBY; ++by)
+#pragma unroll
+        for (int bx = 0; bx < NBX; ++bx) {
+            const int x = x0 + 16 * bx + n, yb = y0 + 16 * by + 4 * kq;
+            if (x < x_hi) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (yb + r < y_hi) oplane[(size_t)(yb + r) * W + x] = acc[by][bx][r] * inv;
+            }
+        }
+    __builtin_amdgcn_wave_barrier();      // the next slice overwrites this wave's tap rows
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Generic path (any odd ks <= AADFF_MAX_KS): same tiling, runtime loops, PSF taps staged
 // flipped in LDS and read as broadcasts.  Correctness path for unusual kernel sizes.
 // ------------------------------------------------------------------------------------
@@ -300,6 +484,27 @@ static int launch_fast(const float* img, const float* psf, float* out, int B, in
     PatchBounds pbm = pb;
     pbm.m_ntx = magic_of(ntx); pbm.m_nty = magic_of(nty); pbm.m_nchunk = magic_of(nchunk); pbm.m_c = magic_of(C);
     dim3 g(ntx * grid, nty * grid, B * C * nchunk);
+    // path: "mfma" (Toeplitz GEMM on fp16-split MFMA, KS <= 11) or "valu" (packed fp32 FMA); AADFF_CONV_PATH overrides
+    const char* penv = getenv("AADFF_CONV_PATH");
+    const bool use_mfma = KS <= 11 && !(penv && penv[0] == 'v');
+    if constexpr (KS <= 11) {
+        if (use_mfma) {
+            const int nchunk_m = (S + nw * AADFF_MFMA_SPW - 1) / (nw * AADFF_MFMA_SPW);
+            dim3 gm(ntx * grid, nty * grid, B * C * nchunk_m);
+            PatchBounds pbmm = pbm;
+            pbmm.m_nchunk = magic_of(nchunk_m);
+#define AADFF_LAUNCH_M(NWV) hipLaunchKernelGGL((conv_psf_map_mfma_kernel<KS, NWV, AADFF_MFMA_SPW>), gm, dim3(64 * NWV), 0, st, img, psf, out, C, S, H, W, grid, ntx, nty, pbmm)
+            switch (nw) {
+                case 5: if constexpr (KS == 11) { AADFF_LAUNCH_M(5); break; }
+                case 4: AADFF_LAUNCH_M(4); break;
+                case 3: if constexpr (KS == 11) { AADFF_LAUNCH_M(3); break; }
+                case 2: AADFF_LAUNCH_M(2); break;
+                default: AADFF_LAUNCH_M(1);
+            }
+#undef AADFF_LAUNCH_M
+            return 0;
+        }
+    }
 #define AADFF_LAUNCH(NWV) hipLaunchKernelGGL((conv_psf_map_kernel<KS, NWV>), g, dim3(64 * NWV), 0, st, img, psf, out, C, S, H, W, grid, ntx, nty, pbm)
     if constexpr (KS == 11) {
         switch (nw) {

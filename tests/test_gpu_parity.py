@@ -149,7 +149,8 @@ def test_conv_properties_at_full_size():
     delta = torch.zeros(3, g, g, ks, ks)
     delta[..., ks // 2, ks // 2] = 1
     delta = delta.permute(0, 1, 3, 2, 4).reshape(3, g * ks, g * ks).to(DEV)
-    assert torch.equal(rp.render_psf_map(img, delta, g), img)
+    # the MFMA path carries operands as hi+lo fp16 pairs (22 bits): identity to 2^-22 relative, not bit-exact
+    assert (rp.render_psf_map(img, delta, g) - img).abs().max().item() <= 5e-7
     rng = np.random.Generator(np.random.PCG64(1))
     p = tt(rng.random((3, g, g, ks, ks), dtype=np.float32))
     p = (p / p.sum((-1, -2), keepdim=True)).permute(0, 1, 3, 2, 4).reshape(3, g * ks, g * ks).contiguous().to(DEV)
@@ -492,7 +493,7 @@ def test_full_resolution_middlebury_size_properties():
     maps[1] = delta
     stack = rp.render_psf_map_stack(img, maps, g)
     assert stack.shape == (2, 3, S, H, W)
-    assert torch.equal(stack[:, :, 1], img)
+    assert (stack[:, :, 1] - img).abs().max().item() <= 5e-7
     assert torch.equal(stack[:, :, 3], rp.render_psf_map(img, maps[3], g))
     want = oconv.render_psf_map(img[1:, :, 900:1300, 1700:2100].cpu(), maps[2].cpu(), 1) if False else None
     # spot-check one interior patch against the oracle (patch (5,5): rows 903..1083, cols 1309..1570)
