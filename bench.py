@@ -159,8 +159,12 @@ def main():
             "config": {"workload": "rf50mm, 1024x1024 synthetic RGB + depth plane, 10 focus distances, 11x11 PSF grid, "
                                    "ks 11, spp 2048 (+2048 chief), mode M1 (refocus -> psf_map -> render_psf_map)",
                        "stacks_per_step_per_gpu": 1, "pupil_samples": "device RNG" if args.device_rng else "host torch RNG, reference call order",
-                       "gather": bool(comm is not None)},
-            "roofline": {"kernel": "conv_psf_map_kernel<11> (stack-fused, S=10)", "bound": "hbm", "achieved": round(achieved / 1e9, 2),
+                       "gather": bool(comm is not None),
+                       "arithmetic": "fp32 ray trace / PSF grid; convolution operands carried as exact hi+lo fp16 pairs "
+                                     "(22-bit significand) on MFMA with fp32 accumulation, <= 5e-7 abs from an fp32 FMA chain"},
+            "roofline": {"kernel": ("conv_psf_map_kernel<11,5> (packed fp32 FMA)" if os.environ.get("AADFF_CONV_PATH", "m")[0] == "v"
+                                    else "conv_psf_map_mfma_kernel<11,5> (Toeplitz GEMM, exact fp16x3 operand split, fp32 accumulate)") + ", stack-fused S=10",
+                         "bound": "hbm", "achieved": round(achieved / 1e9, 2),
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
                          "kernel_ms": round(conv_ms, 4), "algorithmic_bytes_per_launch": ALG_BYTES_PER_SLICE * S,
                          "tflops": round(2 * 3 * KS * KS * H * W * S / (conv_ms * 1e-3) / 1e12, 2)},
