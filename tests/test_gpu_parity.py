@@ -504,3 +504,55 @@ def test_full_resolution_middlebury_size_properties():
     k = maps[2][:, 5 * ks:6 * ks, 5 * ks:6 * ks].cpu()
     ref = torch.nn.functional.conv2d(crop, torch.flip(k, [1, 2]).unsqueeze(1), groups=3)
     assert (stack[0:1, :, 2, y0:y1, x0:x1].cpu() - ref).abs().max().item() <= 4e-6
+
+
+# ================================================================= script-facing API surface
+def test_train_psfnet_runs_and_checkpoints(repo_root, tmp_path):
+    """1_fit_psfnet.py's calls: analysis, write_lens_json, train_psfnet (2 iterations), evaluate_psf, load_net."""
+    net = PSFNet(lens_path(repo_root), sensor_res=(480, 640), kernel_size=11, device=DEV)
+    net.analysis(save_name=str(tmp_path / "lens"))
+    net.write_lens_json(str(tmp_path / "lens.json"))
+    np.random.seed(0)
+    torch.manual_seed(0)
+    net.train_psfnet(iters=1, bs=16, lr=1e-4, spp=256, evaluate_every=1, result_dir=str(tmp_path))
+    assert (tmp_path / "PSFNet_mlp.pkl").exists() and (tmp_path / "iter1.png").exists()
+    net.evaluate_psf(result_dir=str(tmp_path))
+    sd = torch.load(tmp_path / "PSFNet_mlp.pkl", map_location="cpu")
+    assert sorted(sd)[:2] == ["net.0.bias", "net.0.weight"] and sd["net.20.weight"].shape == (121, 256)
+    net2 = PSFNet(str(tmp_path / "lens.json"), sensor_res=(480, 640), kernel_size=11, device=DEV)
+    net2.load_net(str(tmp_path / "PSFNet_mlp.pkl"))
+    for k in ("d_sensor", "hfov", "foclen", "fnum"):
+        assert getattr(net2, k) == pytest.approx(getattr(Lensgroup(lens_path(repo_root), sensor_res=(480, 640), device=DEV), k), rel=1e-6)
+
+
+def test_render_single_img_psf_branch(repo_root):
+    """Lensgroup.render_single_img(method='psf'): 7x7 grid, ks 21 - the only in-repo caller of render_psf_map
+    in the reference (deeplens/optics.py:779-783)."""
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(128, 128), device=DEV)
+    rng = np.random.Generator(np.random.PCG64(0))
+    img = (rng.random((96, 128, 3)) * 255).astype(np.uint8)
+    torch.manual_seed(0)
+    out = lens.render_single_img(img, depth=-2000.0, method="psf")
+    assert out.shape == (96, 128, 3) and out.dtype == np.uint8
+    assert list(lens.sensor_res) == [128, 128]                       # restored
+    assert abs(float(out.mean()) - float(img.mean())) < 2.0          # a normalised PSF preserves the mean level
+    with pytest.raises(NotImplementedError):
+        lens.render_single_img(img, method="raytracing")
+
+
+def test_lens_state_properties_round_trip(repo_root):
+    """d_sensor / hfov are device-resident; assigning d_sensor (as scripts may) is honoured by the kernels."""
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(256, 256), device=DEV)
+    torch.manual_seed(0)
+    lens.refocus(-1000.0)
+    d1 = lens.d_sensor
+    lens.d_sensor = d1 + 0.25
+    assert lens.d_sensor == pytest.approx(d1 + 0.25, abs=1e-5)
+    lens.post_computation()
+    assert lens.hfov < 0.41 and lens.foclen == pytest.approx(lens.r_last / np.tan(lens.hfov), rel=1e-6)
+    torch.manual_seed(1)
+    a = lens.psf(torch.tensor([[0.0, 0.0, -1000.0]]), ks=11, spp=512)
+    lens.d_sensor = d1
+    torch.manual_seed(1)
+    b = lens.psf(torch.tensor([[0.0, 0.0, -1000.0]]), ks=11, spp=512)
+    assert (a - b).abs().max().item() > 1e-3                           # the sensor shift changed the PSF
