@@ -141,6 +141,73 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
     return (plan.out, plan.psf_maps) if return_maps else plan.out
 
 
+def depth_layers(depth_mm, layers):
+    """Quantise a depth map (mm, < 0 = in front of the lens; 0 = invalid) into `layers` bins that are uniform
+    in depth between the nearest and the farthest valid pixel.  Returns (index map int64 like depth, centre
+    depth of each layer [layers], mm < 0).  Invalid pixels go to the farthest layer."""
+    d = -depth_mm                                    # positive distances
+    valid = d > 0
+    dmin = torch.where(valid, d, torch.full_like(d, float("inf"))).amin()
+    dmax = d.amax()
+    width = torch.clamp((dmax - dmin) / layers, min=1e-6)
+    idx = torch.clamp(((d - dmin) / width).floor().long(), 0, layers - 1)
+    idx = torch.where(valid, idx, torch.full_like(idx, layers - 1))
+    centres = -(dmin + (torch.arange(layers, device=d.device, dtype=torch.float32) + 0.5) * width)
+    return idx, centres
+
+
+@torch.no_grad()
+def render_focal_stack_m1_layered(lens, img, depth_mm, focus_mm, layers=4, grid=11, ks=11, spp=GEO_SPP):
+    """RGB-D aware grid rendering ("M1-layered"): the depth map is quantised into `layers`
+    planes; for every focus distance and layer one PSF map is ray traced and the slice is the per-pixel
+    selection  out[s] = sum_l [layer == l] * render_psf_map(img, psf_map[s, l]).
+    Composes reference primitives only (refocus, psf_map, render_psf_map).  Host-RNG order: per focus
+    distance the refocus draws, then the psf_map draws of layer 0, 1, ...   img [B,C,H,W], depth_mm
+    [B,1,H,W] (mm, < 0), focus_mm [S] (mm, < 0) -> [B,C,S,H,W]."""
+    focus = [float(f) for f in np.asarray(focus_mm, dtype=np.float64).reshape(-1)]
+    S, L = len(focus), int(layers)
+    B, C_, H, W = img.shape
+    assert tuple(lens.sensor_res) == (H, W), "lens.sensor_res must match the image"
+    dev = lens._gpu()
+    x = _abi.f32c(img, dev)
+    idx, centres = depth_layers(_abi.f32c(depth_mm, dev), L)
+    centres_h = centres.cpu().tolist()
+    N, nb = grid * grid, C.sizeof(_abi.LensState)
+    per, o_main, o_chief, per_l = stack_uniform_layout(spp)              # per-layer block = per - 2*GEO_SPP
+    layer_block = per - o_main
+    u = lens.sampler.rand_block([S * (o_main + L * layer_block)]).to(dev)
+    states = torch.zeros(S * nb, dtype=torch.uint8, device=dev)
+    dep = torch.tensor(focus, dtype=torch.float32, device=dev)
+    maps = torch.empty((S * L, 3, grid * ks, grid * ks), dtype=torch.float32, device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    pts = lens.point_source_grid(depth=0.0, grid=grid).reshape(-1, 3).unsqueeze(0).repeat(L, 1, 1)
+    for l in range(L):
+        pts[l, :, 2] = centres_h[l]
+    pts = pts.contiguous().to(dev)
+    tab_rgb, tab_green, lc = lens._table(WAVE_RGB), lens._table([DEFAULT_WAVE]), lens._lens_const()
+    slice_stride = o_main + L * layer_block
+    with torch.cuda.device(dev):
+        st = _abi.stream_ptr(dev)
+        ub = u.data_ptr()
+        _abi.call("aadff_refocus", _abi.ptr(dep), S, C.c_void_p(ub), GEO_SPP, slice_stride, _abi.ptr(tab_green), lc,
+                  _abi.ptr(states), st)
+        for s in range(S):
+            st_rep = states[s * nb:(s + 1) * nb].repeat(L)                # the L layers share focus state s
+            base = ub + 4 * (s * slice_stride + o_main)
+            _abi.call("aadff_psf_points", _abi.ptr(pts), L, N, 3, _abi.ptr(tab_rgb), _abi.ptr(tab_green), lc,
+                      _abi.ptr(st_rep), C.c_void_p(base), spp, layer_block, per_l,
+                      C.c_void_p(base + 4 * 2 * spp), GEO_SPP, layer_block, per_l, ks, 1, 1,
+                      _abi.ptr(maps[s * L:(s + 1) * L]), None, _abi.ptr(flags), st)
+        tmp = torch.empty((B, C_, S * L, H, W), dtype=torch.float32, device=dev)
+        _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(maps), _abi.ptr(tmp), B, C_, S * L, H, W, grid,
+                  ks, st)
+    sel = idx.reshape(B, 1, 1, 1, H, W).expand(B, C_, S, 1, H, W)
+    out = torch.gather(tmp.view(B, C_, S, L, H, W), 3, sel).squeeze(3)
+    lens._state_device().copy_(states[(S - 1) * nb:S * nb])
+    lens._state_stale = True
+    return out
+
+
 @torch.no_grad()
 def render_focal_stack_m2(lens, img, depth_m, n_stack):
     """[B,C,S,H,W] stack with per-pixel PSFs: depth in metres (> 0 valid), focus distances by

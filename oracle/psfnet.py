@@ -102,3 +102,31 @@ def focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, spp=2048
         maps.append(pm)
         sl.append(render_psf_map(img, pm, grid))
     return torch.stack(sl, dim=2), torch.stack(maps)
+
+
+def depth_layers(depth_mm, layers):
+    """Oracle twin of aadff.focal_stack.depth_layers (the layered mode is a build extension: SURVEY.md §8d)."""
+    d = -depth_mm
+    valid = d > 0
+    dmin = torch.where(valid, d, torch.full_like(d, float("inf"))).amin()
+    dmax = d.amax()
+    width = torch.clamp((dmax - dmin) / layers, min=1e-6)
+    idx = torch.clamp(((d - dmin) / width).floor().long(), 0, layers - 1)
+    idx = torch.where(valid, idx, torch.full_like(idx, layers - 1))
+    centres = -(dmin + (torch.arange(layers, dtype=torch.float32) + 0.5) * width)
+    return idx, centres
+
+
+def focal_stack_m1_layered(lens, img, depth_mm, focus_mm, layers=4, grid=11, ks=11, spp=2048):
+    """M1-layered with reference primitives only: per focus distance refocus, then per layer psf_map and
+    render_psf_map, composited by the per-pixel layer index.  Same host-RNG order as the HIP renderer."""
+    idx, centres = depth_layers(depth_mm, layers)
+    slices = []
+    for f in focus_mm:
+        lens.refocus(float(f))
+        acc = torch.zeros_like(img)
+        for l in range(layers):
+            pm = lens.psf_map(depth=float(centres[l]), grid=grid, ks=ks, spp=spp)
+            acc = acc + (idx == l).to(img.dtype) * render_psf_map(img, pm, grid)
+        slices.append(acc)
+    return torch.stack(slices, dim=2)

@@ -556,3 +556,24 @@ def test_lens_state_properties_round_trip(repo_root):
     torch.manual_seed(1)
     b = lens.psf(torch.tensor([[0.0, 0.0, -1000.0]]), ks=11, spp=512)
     assert (a - b).abs().max().item() > 1e-3                           # the sensor shift changed the PSF
+
+
+def test_focal_stack_m1_layered_vs_oracle(repo_root):
+    """RGB-D aware grid rendering (depth quantised into layers) against the same composition of oracle primitives."""
+    from aadff.focal_stack import depth_layers, render_focal_stack_m1_layered
+    H = W = 64
+    img = tt(synth_rgb(H, W, seed=21))[None]
+    depth = -tt(synth_depth_mm(H, W, seed=22, dmin=600.0, dmax=4000.0))[None, None]
+    depth[0, 0, :3, :3] = 0.0                                      # invalid pixels
+    fds = [-700.0, -1500.0, -3500.0]
+    ora = OracleLens(lens_path(repo_root), sensor_res=(H, W))
+    torch.manual_seed(4)
+    want = opsf.focal_stack_m1_layered(ora, img, depth, fds, layers=3, grid=3, ks=11, spp=512)
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(H, W), device=DEV)
+    torch.manual_seed(4)
+    got = render_focal_stack_m1_layered(lens, img.to(DEV), depth.to(DEV), fds, layers=3, grid=3, ks=11, spp=512)
+    assert got.shape == (1, 3, 3, H, W)
+    assert rel_l2(got.cpu().numpy(), want.numpy()) <= IMG_TOL
+    idx_g, cen_g = depth_layers(depth.to(DEV), 3)
+    idx_o, cen_o = opsf.depth_layers(depth, 3)
+    assert torch.equal(idx_g.cpu(), idx_o) and torch.allclose(cen_g.cpu(), cen_o)
