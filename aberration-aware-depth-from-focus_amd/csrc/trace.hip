@@ -268,6 +268,185 @@ __device__ __forceinline__ Ray ray_to(float px, float py, float pz, float tx, fl
 }
 
 // ------------------------------------------------------------------------------------
+// Two rays per lane (fused PSF kernel only).  Every quantity is a float2 whose components belong to two
+// independent rays, so nearly all arithmetic issues as packed fp32 (v_pk_fma/mul/add_f32: two rays per
+// 4-cycle instruction instead of one ray per ~3-cycle instruction); only the transcendentals, compares
+// and selects stay per component.  Same formulas as the scalar core above, KEEP = false semantics (a dead
+// ray's state is never read again), masks are int2 (-1 / 0).
+// ------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+
+struct Ray2 {
+    f2 ox, oy, oz, dx, dy, dz, ra;
+};
+__device__ __forceinline__ f2 f2s(float a) { return (f2){a, a}; }
+__device__ __forceinline__ f2 vsqrt(f2 a) { return (f2){fsqrt(a.x), fsqrt(a.y)}; }
+__device__ __forceinline__ f2 vrcp(f2 a) { return (f2){frcp(a.x), frcp(a.y)}; }
+__device__ __forceinline__ f2 vrsq(f2 a) { return (f2){frsq(a.x), frsq(a.y)}; }
+__device__ __forceinline__ f2 vmax(f2 a, f2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ f2 vmin(f2 a, f2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ f2 vabs(f2 a) { return __builtin_elementwise_abs(a); }
+__device__ __forceinline__ f2 vsel(i2 m, f2 a, f2 b) { return (f2){m.x ? a.x : b.x, m.y ? a.y : b.y}; }
+__device__ __forceinline__ bool any2(i2 m) { return (m.x | m.y) != 0; }
+
+__device__ __forceinline__ void sag_and_slope2(const aadff_surface_t& s, f2 r2, f2& sag, f2& slope) {
+    const f2 a = (1.f + s.k) * r2 * (s.c * s.c);
+    const f2 sf = vsqrt(1.f - a);
+    sag = r2 * s.c * vrcp(1.f + sf);
+    slope = (0.5f * s.c) * vrcp(sf);
+    if (s.n_ai > 0) {
+        f2 ps, pd;
+        if (s.n_ai <= 6) {
+            ps = f2s(s.ai[5]); pd = f2s(s.dai[5]);
+#pragma unroll
+            for (int j = 4; j >= 0; --j) { ps = ps * r2 + s.ai[j]; pd = pd * r2 + s.dai[j]; }
+        } else {
+            ps = f2s(s.ai[AADFF_MAX_AI - 1]); pd = f2s(s.dai[AADFF_MAX_AI - 1]);
+#pragma unroll
+            for (int j = AADFF_MAX_AI - 2; j >= 0; --j) { ps = ps * r2 + s.ai[j]; pd = pd * r2 + s.dai[j]; }
+        }
+        sag += ps * r2;
+        slope += pd;
+    }
+}
+__device__ __forceinline__ i2 valid_strict2(const aadff_surface_t& s, f2 r2) {
+    const i2 a = r2 < s.r2;
+    return s.k_gt_m1 ? (a & (r2 < s.r2_shape)) : a;
+}
+__device__ __forceinline__ i2 valid_loose2(const aadff_surface_t& s, f2 r2) {
+    return s.k_gt_m1 ? (r2 < s.r2_shape) : (r2 > 0.f);
+}
+template <bool STRICT>
+__device__ __forceinline__ f2 newton_step2(const aadff_surface_t& s, const Ray2& r, f2 dxy2, f2 od, f2& t) {
+    const f2 px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t;
+    f2 r2 = px * px + py * py;
+    const i2 m = STRICT ? valid_strict2(s, r2) : valid_loose2(s, r2);
+    r2 = vsel(m, r2, f2s(0.f));
+    f2 sag, slope;
+    sag_and_slope2(s, r2, sag, slope);
+    const f2 ft = sag + s.d - pz;
+    const f2 dr2dt = 2.f * (dxy2 * t + od);
+    const f2 dfdt = slope * dr2dt - r.dz;
+    f2 step = ft * vrcp(dfdt + kEps);
+    step = vmin(vmax(step, f2s(-kStepBound)), f2s(kStepBound));
+    t -= step;
+    return ft;
+}
+__device__ __forceinline__ i2 conic_root2(const aadff_surface_t& s, const Ray2& r, f2 t0, f2& p0x, f2& p0y, f2& tau) {
+    p0x = r.ox + r.dx * t0; p0y = r.oy + r.dy * t0;
+    const f2 rho2 = p0x * p0x + p0y * p0y;
+    const f2 beta = s.c * (p0x * r.dx + p0y * r.dy) - r.dz;
+    const f2 A = s.c * (1.f + s.k * r.dz * r.dz);
+    const f2 disc = beta * beta - A * (s.c * rho2);
+    const f2 root = vsqrt(vmax(disc, f2s(0.f)));
+    tau = (s.c * rho2) * vrcp(vsel(beta < 0.f, root - beta, -(root + beta)));
+    return disc >= 0.f;
+}
+__device__ __forceinline__ void newton2(const aadff_surface_t& s, const Ray2& r, i2 alive, f2& t_out, i2& valid_out, int& nan_flag) {
+    const f2 dxy2 = r.dx * r.dx + r.dy * r.dy;
+    const f2 od = r.dx * r.ox + r.dy * r.oy;
+    const f2 t0 = (s.d - r.oz) * vrcp(r.dz);
+    f2 t = t0;
+#ifndef AADFF_NEWTON_PLANE_START
+    {
+        f2 p0x, p0y, tau;
+        const i2 hit = conic_root2(s, r, t0, p0x, p0y, tau);
+        t = vsel(hit, t0 + tau, t0);
+    }
+#endif
+    f2 ft = f2s(kMaxT);
+    for (int it = 0; it < kNewtonMaxIter; ++it) {
+        if (!__any(any2(alive & (vabs(ft) > kTolLoose)))) break;
+        ft = newton_step2<false>(s, r, dxy2, od, t);
+        if (any2(alive & (ft != ft))) nan_flag = 1;
+    }
+    const f2 t1 = t - t0;
+    t = t0 + t1;
+    ft = newton_step2<true>(s, r, dxy2, od, t);
+    const f2 px = r.ox + r.dx * t, py = r.oy + r.dy * t;
+    valid_out = valid_strict2(s, px * px + py * py) & (vabs(ft) < kTolTight) & (t > 0.f);
+    t_out = t;
+}
+__device__ __forceinline__ i2 refract2(const aadff_surface_t& s, Ray2& r, bool forward) {
+    f2 nx, ny, nz;
+    if (s.kind == AADFF_SURF_STOP) {
+        nx = f2s(0.f); ny = f2s(0.f); nz = f2s(-1.f);
+    } else if (s.kind == AADFF_SURF_SPHERIC) {
+        nx = s.c * r.ox; ny = s.c * r.oy; nz = s.c * (r.oz - s.d) - 1.f;
+    } else {
+        f2 sag, g;
+        sag_and_slope2(s, r.ox * r.ox + r.oy * r.oy, sag, g);
+        nx = g * 2.f * r.ox; ny = g * 2.f * r.oy;
+        const f2 inv = vrsq(vmax(nx * nx + ny * ny + 1.f, f2s(1e-24f)));
+        nx *= inv; ny *= inv; nz = -inv;
+    }
+    const float sgn = forward ? -1.f : 1.f;
+    const float eta = forward ? s.eta_fwd : s.eta_bwd;
+    const float eta2 = forward ? s.eta_fwd2 : s.eta_bwd2;
+    const f2 cosi = sgn * (r.dx * nx + r.dy * ny + r.dz * nz);
+    const f2 sin2 = eta2 * (1.f - cosi * cosi);
+    const i2 valid = (cosi * cosi > 0.1f) & (sin2 < 1.f);
+    const f2 g = sgn * (vsqrt(vmax(1.f - sin2, f2s(0.f))) - eta * cosi);
+    r.dx = eta * r.dx + g * nx; r.dy = eta * r.dy + g * ny; r.dz = eta * r.dz + g * nz;
+    return valid;
+}
+__device__ __forceinline__ void react2(const aadff_surface_t& s, Ray2& r, bool forward, int& nan_flag) {
+    const i2 alive = r.ra > 0.f;
+    if (!any2(alive)) return;
+    f2 t, px, py, pz;
+    i2 valid;
+    if (s.kind == AADFF_SURF_STOP) {
+        t = (s.d - r.oz) * vrcp(r.dz);
+        px = r.ox + t * r.dx; py = r.oy + t * r.dy; pz = r.oz + t * r.dz;
+        valid = (px * px + py * py) <= s.r * s.r;           // sqrt(x^2+y^2) <= r (surfaces.py:418)
+    } else if (s.kind == AADFF_SURF_SPHERIC) {
+        const f2 t0 = (s.d - r.oz) * vrcp(r.dz);
+        f2 p0x, p0y, tau;
+        const i2 hit = conic_root2(s, r, t0, p0x, p0y, tau);
+        t = t0 + tau;
+        px = p0x + r.dx * tau; py = p0y + r.dy * tau; pz = s.d + r.dz * tau;
+        valid = hit & ((px * px + py * py) <= s.r2) & (t >= 0.f);
+    } else {
+        newton2(s, r, alive, t, valid, nan_flag);
+        px = r.ox + t * r.dx; py = r.oy + t * r.dy; pz = r.oz + t * r.dz;
+    }
+    r.ox = px; r.oy = py; r.oz = pz;
+    valid &= alive;
+    if (s.kind != AADFF_SURF_STOP || (forward ? s.refract_fwd : s.refract_bwd)) valid &= refract2(s, r, forward);
+    r.ra = vsel(valid, r.ra, f2s(0.f));
+}
+__device__ __forceinline__ void trace_forward2(const aadff_surface_t* __restrict__ surf, int n_surf, Ray2& r, int& nan_flag) {
+    for (int i = 0; i < n_surf; ++i) react2(surf[i], r, true, nan_flag);
+}
+__device__ __forceinline__ void disc_sample2(f2 u_theta, f2 u_r, float R2, f2& x, f2& y) {
+    const f2 rr = vsqrt(u_r * R2);
+#ifdef AADFF_HW_SINCOS
+    x = rr * (f2){__builtin_amdgcn_cosf(u_theta.x), __builtin_amdgcn_cosf(u_theta.y)};
+    y = rr * (f2){__builtin_amdgcn_sinf(u_theta.x), __builtin_amdgcn_sinf(u_theta.y)};
+#else
+    const f2 theta = u_theta * 2.f * kTwoPiHi;
+    x = rr * (f2){cosf(theta.x), cosf(theta.y)};
+    y = rr * (f2){sinf(theta.x), sinf(theta.y)};
+#endif
+}
+// rays from one object point to two pupil samples, then through the lens to the sensor plane
+__device__ __forceinline__ Ray2 trace_pair_to_sensor(float px, float py, float pz, f2 tx, f2 ty, float tz, i2 active,
+                                                     const aadff_surface_t* __restrict__ surf, int n_surf, float d_sensor,
+                                                     int& nan_flag) {
+    Ray2 r;
+    r.ox = f2s(px); r.oy = f2s(py); r.oz = f2s(pz);
+    r.dx = tx - px; r.dy = ty - py; r.dz = f2s(tz - pz);
+    const f2 inv = vrsq(vmax(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz, f2s(1e-24f)));
+    r.dx *= inv; r.dy *= inv; r.dz *= inv;
+    r.ra = vsel(active, f2s(1.f), f2s(0.f));
+    trace_forward2(surf, n_surf, r, nan_flag);
+    const f2 t = (d_sensor - r.oz) * vrcp(r.dz);
+    r.ox += r.dx * t; r.oy += r.dy * t; r.oz += r.dz * t;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------
 // generic kernels
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void trace_rays_kernel(const float* o_in, const float* d_in, const float* ra_in,
@@ -411,6 +590,18 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
         const float* ut = u_chief + (size_t)s * chief_ss + (size_t)l * chief_sl;
         const float* ur = ut + spp_chief;
         float sx = 0.f, sy = 0.f, sw = 0.f;
+#ifndef AADFF_PSF_SCALAR
+        for (int i = tid; i < spp_chief; i += 512) {
+            const int i1 = i + 256;
+            const i2 act = {-1, i1 < spp_chief ? -1 : 0};
+            const int j1 = act.y ? i1 : i;
+            f2 x2, y2;
+            disc_sample2((f2){ut[i], ut[j1]}, (f2){ur[i], ur[j1]}, lc.enp_r2_shrunk, x2, y2);
+            const Ray2 r = trace_pair_to_sensor(px, py, depth, x2, y2, lc.enp_z, act, surf_chief, lc.n_surf, st.d_sensor, nan_flag);
+            const f2 wx = r.ox * r.ra, wy = r.oy * r.ra;
+            sx += wx.x + wx.y; sy += wy.x + wy.y; sw += r.ra.x + r.ra.y;
+        }
+#else
         for (int i = tid; i < spp_chief; i += 256) {
             float x2, y2;
             disc_sample(ut[i], ur[i], lc.enp_r2_shrunk, x2, y2);
@@ -419,6 +610,7 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
             propagate_to(r, st.d_sensor);
             sx += r.ox * r.ra; sy += r.oy * r.ra; sw += r.ra;
         }
+#endif
         sx = wave_sum(sx); sy = wave_sum(sy); sw = wave_sum(sw);
         if ((tid & 63) == 0) {
             red[(tid >> 6) * 3] = sx; red[(tid >> 6) * 3 + 1] = sy; red[(tid >> 6) * 3 + 2] = sw;
@@ -443,6 +635,18 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
     const aadff_surface_t* tab = surf_main + (size_t)l * lc.n_surf;
     const float* ut = u_main + (size_t)s * main_ss + (size_t)l * main_sl;
     const float* ur = ut + spp;
+#ifndef AADFF_PSF_SCALAR
+    for (int i = tid; i < spp; i += 512) {
+        const int i1 = i + 256;
+        const i2 act = {-1, i1 < spp ? -1 : 0};
+        const int j1 = act.y ? i1 : i;
+        f2 x2, y2;
+        disc_sample2((f2){ut[i], ut[j1]}, (f2){ur[i], ur[j1]}, lc.enp_r2, x2, y2);
+        const Ray2 r = trace_pair_to_sensor(px, py, depth, x2, y2, lc.enp_z, act, tab, lc.n_surf, st.d_sensor, nan_flag);
+        splat_hit(hist, g, r.ox.x, r.oy.x, r.ra.x, cx, cy);
+        splat_hit(hist, g, r.ox.y, r.oy.y, r.ra.y, cx, cy);
+    }
+#else
     for (int i = tid; i < spp; i += 256) {
         float x2, y2;
         disc_sample(ut[i], ur[i], lc.enp_r2, x2, y2);
@@ -451,6 +655,7 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
         propagate_to(r, st.d_sensor);
         splat_hit(hist, g, r.ox, r.oy, r.ra, cx, cy);
     }
+#endif
     __syncthreads();
     float part = 0.f;
     for (int e = tid; e < kk; e += 256) part += hist[e];
