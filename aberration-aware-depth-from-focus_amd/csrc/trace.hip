@@ -700,19 +700,25 @@ __global__ __launch_bounds__(kRefocusThreads) void refocus_kernel(const float* _
         const float* ur = ut + spp;
         const float dep = depth[s];
         float sum = 0.f, cnt = 0.f;
-        for (int i = tid; i < spp; i += kRefocusThreads) {
-            float x2, y2;
-            disc_sample(ut[i], ur[i], lc.first_r2, x2, y2);
-            Ray r;
-            r.ox = x2; r.oy = y2; r.oz = lc.first_d;
-            r.dx = x2; r.dy = y2; r.dz = lc.first_d - dep;           // o - (0,0,depth)
-            normalize3(r.dx, r.dy, r.dz);
-            r.ra = 1.f;
-            trace_range<false>(surf, 0, lc.n_surf, true, r, nan_flag);
-            float t = (r.dx * r.ox + r.dy * r.oy) / (r.dx * r.dx + r.dy * r.dy);
+        for (int i = tid; i < spp; i += 2 * kRefocusThreads) {            // two rays per lane (packed arithmetic)
+            const int i1 = i + kRefocusThreads;
+            const i2 act = {-1, i1 < spp ? -1 : 0};
+            const int j1 = act.y ? i1 : i;
+            f2 x2, y2;
+            disc_sample2((f2){ut[i], ut[j1]}, (f2){ur[i], ur[j1]}, lc.first_r2, x2, y2);
+            Ray2 r;
+            r.ox = x2; r.oy = y2; r.oz = f2s(lc.first_d);
+            r.dx = x2; r.dy = y2; r.dz = f2s(lc.first_d - dep);               // o - (0,0,depth)
+            const f2 inv = vrsq(vmax(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz, f2s(1e-24f)));
+            r.dx *= inv; r.dy *= inv; r.dz *= inv;
+            r.ra = vsel(act, f2s(1.f), f2s(0.f));
+            trace_forward2(surf, lc.n_surf, r, nan_flag);
+            f2 t = (r.dx * r.ox + r.dy * r.oy) * vrcp(r.dx * r.dx + r.dy * r.dy);
             t = t * r.ra;
-            const float fd = r.oz - r.dz * t;
-            if (r.ra > 0.f && fd == fd && fd > 0.f) { sum += fd; cnt += 1.f; }
+            const f2 fd = r.oz - r.dz * t;
+            const i2 ok = (r.ra > 0.f) & (fd == fd) & (fd > 0.f);
+            sum += (ok.x ? fd.x : 0.f) + (ok.y ? fd.y : 0.f);
+            cnt += (ok.x ? 1.f : 0.f) + (ok.y ? 1.f : 0.f);
         }
         sum = wave_sum(sum); cnt = wave_sum(cnt);
         if ((tid & 63) == 0) { red[(tid >> 6) * 2] = sum; red[(tid >> 6) * 2 + 1] = cnt; }
