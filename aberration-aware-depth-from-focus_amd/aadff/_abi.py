@@ -37,6 +37,13 @@ class LensConst(C.Structure):
                 ("first_d", C.c_float), ("first_r2", C.c_float)]
 
 
+class Stage(C.Structure):
+    """aadff_stage_t: upload folded into a psf_points launch."""
+    _fields_ = [("src_host", C.c_void_p), ("dst_dev", C.c_void_p), ("slice_stride", C.c_long),
+                ("first_slice", C.c_int), ("generation", C.c_uint), ("counters", C.c_void_p)]
+
+
+assert C.sizeof(Stage) == 40
 assert C.sizeof(Surface) == 124 and C.sizeof(LensState) == 32 and C.sizeof(LensConst) == 52
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
@@ -52,7 +59,10 @@ PROTOTYPES = {
     "aadff_trace_points": [_P, _I, _P, _P, _I, _F, _F, _P, _I, _P, _P, _P, _P, _P],
     "aadff_psf_splat": [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P],
     "aadff_psf_points": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _L, _L, _P, _I, _L, _L, _I, _I, _I, _P, _P, _P, _P],
+    "aadff_psf_points_staged": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _L, _L, _P, _I, _L, _L, _I, _I, _I, _P, _P, _P,
+                                C.POINTER(Stage), _P],
     "aadff_refocus": [_P, _I, _P, _I, _L, _P, LensConst, _P, _P],
+    "aadff_refocus_staged": [_P, _I, _P, _P, _L, _I, _L, _P, LensConst, _P, _P],
     "aadff_post_computation": [_I, _P, LensConst, _P, _P],
     "aadff_host_mt19937_uniform_f32": [_P, _L, _L, _P],
 }

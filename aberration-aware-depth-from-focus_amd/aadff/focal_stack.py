@@ -8,6 +8,7 @@ convolution; the S lens states stay on the device in between.
 Mode M2: the per-pixel-PSF path the training scripts call (PSFNet.render per slice).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -47,6 +48,10 @@ def draw_stack_uniforms(sampler, S, spp, L=3, spp_chief=GEO_SPP, spp_focus=GEO_S
     return u_focus, rest[:, :, :2 * spp].reshape(S, L, 2, spp), rest[:, :, 2 * spp:].reshape(S, L, 2, spp_chief)
 
 
+STAGED_UPLOAD = os.environ.get("AADFF_STAGED_UPLOAD", "1") != "0"
+STAGE_FIRST = int(os.environ.get("AADFF_STAGE_FIRST", "3"))   # focus states uploaded by the refocus launch
+
+
 class StackPlan:
     """Pre-allocated device buffers, cached lens tables and a pinned-host ring for the pupil
     samples of repeated M1 stacks of one shape.  The ring lets the host draw step i+1's
@@ -70,6 +75,10 @@ class StackPlan:
         self.u_pin = [torch.empty(S * self.per, dtype=torch.float32).pin_memory() for _ in range(self.RING)]
         self.u_evt = [None] * self.RING
         self.turn = 0
+        # staged upload (aadff_refocus_staged + aadff_psf_points_staged): the first STAGE_FIRST states' draws are
+        # copied behind the focus traces, the rest by leading workgroups of the PSF launch
+        self.stage_counters = torch.zeros(S, dtype=torch.int32, device=dev)
+        self.stage_generation = 0
         self._geo_key, self._dep, self._pts = None, None, None
 
     def uniforms(self, sampler):
@@ -90,6 +99,24 @@ class StackPlan:
         self.u_evt[k] = torch.cuda.Event()
         self.u_evt[k].record()
         return self.u_dev[k]
+
+    def uniforms_host(self, sampler):
+        """(pinned host block, device block) of this step's uniforms WITHOUT the upload: the caller hands
+        both to aadff_refocus_staged, which copies inside the refocus launch, then calls `staged()`."""
+        k = self.turn % self.RING
+        self.turn += 1
+        if self.u_evt[k] is not None:
+            self.u_evt[k].synchronize()          # the launch that last read this pinned slot has finished
+        if hasattr(sampler, "rand_into"):
+            sampler.rand_into(self.u_pin[k])
+        else:
+            self.u_pin[k].copy_(sampler.rand_block([self.S * self.per]))
+        return self.u_pin[k], self.u_dev[k]
+
+    def staged(self):
+        k = (self.turn - 1) % self.RING
+        self.u_evt[k] = torch.cuda.Event()
+        self.u_evt[k].record()
 
     def geometry(self, focus, depth_plane_mm):
         key = (tuple(focus), float(depth_plane_mm))
@@ -116,18 +143,36 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
         plan = StackPlan(lens, S, H, W, B, C_, grid, ks, spp)
     dev = plan.dev
     with torch.cuda.device(dev):
-        u = plan.uniforms(lens.sampler)
         dep, pts = plan.geometry(focus, depth_plane_mm)
         x = _abi.f32c(img, dev)
         N = grid * grid
-        ub = u.data_ptr()
         st = _abi.stream_ptr(dev)
-        _abi.call("aadff_refocus", _abi.ptr(dep), S, C.c_void_p(ub), GEO_SPP, plan.per, _abi.ptr(plan.tab_green),
-                  plan.lc, _abi.ptr(plan.states), st)
-        _abi.call("aadff_psf_points", _abi.ptr(pts), S, N, 3, _abi.ptr(plan.tab_rgb), _abi.ptr(plan.tab_green),
-                  plan.lc, _abi.ptr(plan.states), C.c_void_p(ub + 4 * plan.o_main), spp, plan.per, plan.per_l,
-                  C.c_void_p(ub + 4 * plan.o_chief), GEO_SPP, plan.per, plan.per_l, ks, 1, 1,
-                  _abi.ptr(plan.psf_maps), None, _abi.ptr(plan.flags), st)
+        stage = None
+        if lens.sampler.on_device or not STAGED_UPLOAD or plan.per % 4:
+            u = plan.uniforms(lens.sampler)
+            ub = u.data_ptr()
+            _abi.call("aadff_refocus", _abi.ptr(dep), S, C.c_void_p(ub), GEO_SPP, plan.per, _abi.ptr(plan.tab_green),
+                      plan.lc, _abi.ptr(plan.states), st)
+        else:       # host draws: the upload rides on the refocus launch
+            u_pin, u = plan.uniforms_host(lens.sampler)
+            ub = u.data_ptr()
+            first = min(S, STAGE_FIRST)
+            _abi.call("aadff_refocus_staged", _abi.ptr(dep), S, C.c_void_p(u_pin.data_ptr()), C.c_void_p(ub), first * plan.per,
+                      GEO_SPP, plan.per, _abi.ptr(plan.tab_green), plan.lc, _abi.ptr(plan.states), st)
+            plan.stage_generation += 1
+            stage = _abi.Stage(u_pin.data_ptr(), ub, plan.per, first, plan.stage_generation & 0xFFFFFFFF,
+                               plan.stage_counters.data_ptr())
+        if stage is None:
+            _abi.call("aadff_psf_points", _abi.ptr(pts), S, N, 3, _abi.ptr(plan.tab_rgb), _abi.ptr(plan.tab_green),
+                      plan.lc, _abi.ptr(plan.states), C.c_void_p(ub + 4 * plan.o_main), spp, plan.per, plan.per_l,
+                      C.c_void_p(ub + 4 * plan.o_chief), GEO_SPP, plan.per, plan.per_l, ks, 1, 1,
+                      _abi.ptr(plan.psf_maps), None, _abi.ptr(plan.flags), st)
+        else:
+            _abi.call("aadff_psf_points_staged", _abi.ptr(pts), S, N, 3, _abi.ptr(plan.tab_rgb), _abi.ptr(plan.tab_green),
+                      plan.lc, _abi.ptr(plan.states), C.c_void_p(ub + 4 * plan.o_main), spp, plan.per, plan.per_l,
+                      C.c_void_p(ub + 4 * plan.o_chief), GEO_SPP, plan.per, plan.per_l, ks, 1, 1,
+                      _abi.ptr(plan.psf_maps), None, _abi.ptr(plan.flags), C.byref(stage), st)
+            plan.staged()
         if plan.conv_events is not None:
             plan.conv_events[0].record()
         _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(plan.psf_maps), _abi.ptr(plan.out), B, C_, S,

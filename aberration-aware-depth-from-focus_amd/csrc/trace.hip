@@ -7,7 +7,9 @@
 // reference's exits per batch (`while (...).any()`, deeplens/surfaces.py:547) - extra steps on
 // converged rays are the same arithmetic the reference performs.  Semantics: SURVEY.md Appendix
 // A.1/A.2, citations per function below (paths relative to the reference repo).
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include "common.h"
 
 namespace aadff {
@@ -563,7 +565,21 @@ __global__ __launch_bounds__(256) void psf_splat_kernel(const float* __restrict_
 //   phase 2  main rays -> LDS histogram                    deeplens/optics.py:933-976
 //   phase 3  normalise, write (optionally in psf_map tiling, optics.py:1025)
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict__ points, int N, int L,
+// Upload riding on a psf_points launch (see aadff_stage_t in include/aadff.h).
+struct StageArgs {
+    const float4* src;
+    float4* dst;
+    long slice_n4;
+    int first_slice, copy_wgs;
+    unsigned* counters;
+    unsigned target;
+};
+
+#ifndef AADFF_PSF_THREADS
+#define AADFF_PSF_THREADS 512
+#endif
+constexpr int kPsfThreads = AADFF_PSF_THREADS, kPsfWaves = kPsfThreads / 64;
+__global__ __launch_bounds__(kPsfThreads) void psf_points_kernel(const float* __restrict__ points, int N, int L,
                                                           const aadff_surface_t* __restrict__ surf_main,
                                                           const aadff_surface_t* __restrict__ surf_chief,
                                                           aadff_lens_const_t lc,
@@ -571,13 +587,44 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
                                                           const float* __restrict__ u_main, int spp, long main_ss,
                                                           long main_sl, const float* __restrict__ u_chief,
                                                           int spp_chief, long chief_ss, long chief_sl, SplatGeom g, int centre_mode, int map_grid, float* psf,
-                                                          float* centre_out, int* flags) {
+                                                          float* centre_out, int* flags, StageArgs stage) {
     __shared__ float hist[AADFF_MAX_KS * AADFF_MAX_KS];
-    __shared__ float red[3 * 4];
-    const int n = blockIdx.x, l = blockIdx.y, s = blockIdx.z;
+    __shared__ float red[3 * kPsfWaves];
+    const int n = blockIdx.x, l = blockIdx.y;
+    int s = blockIdx.z;
     const int tid = threadIdx.x, kk = g.ks * g.ks;
+    if (stage.src) {
+        // Staged launch (aadff_psf_points_staged): the z = 0 plane of the grid is dispatched first; its first
+        // stage.copy_wgs workgroups stream the uniform blocks of focus states >= first_slice from pinned host
+        // memory into HBM and publish a per-state counter; PSF workgroups of those states wait on it.
+        if (s == 0) {
+            const int w = blockIdx.y * gridDim.x + blockIdx.x;
+            if (w >= stage.copy_wgs) return;
+            const int S = (int)gridDim.z - 1;
+            const long stride = (long)stage.copy_wgs * kPsfThreads;
+            for (int sl = stage.first_slice; sl < S; ++sl) {
+                const float4* src = stage.src + (long)sl * stage.slice_n4;
+                float4* dst = stage.dst + (long)sl * stage.slice_n4;
+                for (long i = (long)w * kPsfThreads + tid; i < stage.slice_n4; i += stride) dst[i] = src[i];
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(stage.counters + sl, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        s -= 1;
+        if (s >= stage.first_slice) {
+            if (tid == 0) {
+                int spins = 0;
+                while ((int)(__hip_atomic_load(stage.counters + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - stage.target) < 0) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spins > (1 << 22)) { if (flags) atomicOr(flags, 8); break; }     // never hang the queue
+                }
+            }
+            __syncthreads();
+        }
+    }
     const aadff_lens_state_t st = states[s];
-    for (int e = tid; e < kk; e += 256) hist[e] = 0.f;
+    for (int e = tid; e < kk; e += kPsfThreads) hist[e] = 0.f;
 
     // object-space point: deeplens/optics.py:953-959 with calc_scale_pinhole (:1286-1290)
     const float* pt = points + ((size_t)s * N + n) * 3;
@@ -593,8 +640,8 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
         const float* ur = ut + spp_chief;
         float sx = 0.f, sy = 0.f, sw = 0.f;
 #ifndef AADFF_PSF_SCALAR
-        for (int i = tid; i < spp_chief; i += 512) {
-            const int i1 = i + 256;
+        for (int i = tid; i < spp_chief; i += 2 * kPsfThreads) {
+            const int i1 = i + kPsfThreads;
             const i2 act = {-1, i1 < spp_chief ? -1 : 0};
             const int j1 = act.y ? i1 : i;
             f2 x2, y2;
@@ -604,7 +651,7 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
             sx += wx.x + wx.y; sy += wy.x + wy.y; sw += r.ra.x + r.ra.y;
         }
 #else
-        for (int i = tid; i < spp_chief; i += 256) {
+        for (int i = tid; i < spp_chief; i += kPsfThreads) {
             float x2, y2;
             disc_sample(ut[i], ur[i], lc.enp_r2_shrunk, x2, y2);
             Ray r = ray_to(px, py, depth, x2, y2, lc.enp_z);
@@ -618,9 +665,9 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
             red[(tid >> 6) * 3] = sx; red[(tid >> 6) * 3 + 1] = sy; red[(tid >> 6) * 3 + 2] = sw;
         }
         __syncthreads();
-        sx = red[0] + red[3] + red[6] + red[9];
-        sy = red[1] + red[4] + red[7] + red[10];
-        sw = red[2] + red[5] + red[8] + red[11];
+        sx = sy = sw = 0.f;
+#pragma unroll
+        for (int w = 0; w < kPsfWaves; ++w) { sx += red[3 * w]; sy += red[3 * w + 1]; sw += red[3 * w + 2]; }
         cx = -(sx / (sw + kEps));
         cy = -(sy / (sw + kEps));
         if (sw == 0.f && tid == 0 && flags) atomicOr(flags, 2);      // "No sampled rays is valid." (optics.py:901)
@@ -638,8 +685,8 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
     const float* ut = u_main + (size_t)s * main_ss + (size_t)l * main_sl;
     const float* ur = ut + spp;
 #ifndef AADFF_PSF_SCALAR
-    for (int i = tid; i < spp; i += 512) {
-        const int i1 = i + 256;
+    for (int i = tid; i < spp; i += 2 * kPsfThreads) {
+        const int i1 = i + kPsfThreads;
         const i2 act = {-1, i1 < spp ? -1 : 0};
         const int j1 = act.y ? i1 : i;
         f2 x2, y2;
@@ -649,7 +696,7 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
         splat_hit(hist, g, r.ox.y, r.oy.y, r.ra.y, cx, cy);
     }
 #else
-    for (int i = tid; i < spp; i += 256) {
+    for (int i = tid; i < spp; i += kPsfThreads) {
         float x2, y2;
         disc_sample(ut[i], ur[i], lc.enp_r2, x2, y2);
         Ray r = ray_to(px, py, depth, x2, y2, lc.enp_z);
@@ -660,14 +707,16 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
 #endif
     __syncthreads();
     float part = 0.f;
-    for (int e = tid; e < kk; e += 256) part += hist[e];
+    for (int e = tid; e < kk; e += kPsfThreads) part += hist[e];
     part = wave_sum(part);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = part;
     __syncthreads();
-    const float total = red[0] + red[1] + red[2] + red[3];
+    float total = 0.f;
+#pragma unroll
+    for (int w = 0; w < kPsfWaves; ++w) total += red[w];
     const int ks = g.ks;
-    for (int e = tid; e < kk; e += 256) {
+    for (int e = tid; e < kk; e += kPsfThreads) {
         const float v = hist[e] / total;
         if (map_grid > 0) {
             const int gi = n / map_grid, gj = n - gi * map_grid, u = e / ks, w = e - u * ks;
@@ -684,11 +733,32 @@ __global__ __launch_bounds__(256) void psf_points_kernel(const float* __restrict
 // Refocus + post_computation: workgroup per focus state.
 //   deeplens/optics.py:1155-1180 (refocus), :1187-1217 (calc_fov), :178-187, :1097-1102
 // ------------------------------------------------------------------------------------
+#ifndef AADFF_STAGE_COPY_WGS
+#define AADFF_STAGE_COPY_WGS 14
+#endif
+constexpr int kStageWorkgroups = 64;     // upload workgroups riding on the refocus launch (aadff_refocus_staged)
 constexpr int kRefocusThreads = 1024;     // 16 waves: the per-slice trace is latency-bound, not throughput-bound
 __global__ __launch_bounds__(kRefocusThreads) void refocus_kernel(const float* __restrict__ depth, const float* __restrict__ u,
                                                        int spp, long u_ss, const aadff_surface_t* __restrict__ surf,
                                                        aadff_lens_const_t lc, aadff_lens_state_t* states,
-                                                       int do_refocus) {
+                                                       int do_refocus, int S, const float* __restrict__ stage_src,
+                                                       float* __restrict__ stage_dst, long stage_n) {
+    if ((int)blockIdx.x >= S) {
+        // Upload workgroups: copy the pinned-host uniform block to HBM for the PSF kernel while the
+        // S focus workgroups (which read their own draws straight from the host block) trace.
+        const long n4 = stage_n >> 2;
+        const long stride = (long)(gridDim.x - S) * kRefocusThreads;
+        const float4* src4 = reinterpret_cast<const float4*>(stage_src);
+        float4* dst4 = reinterpret_cast<float4*>(stage_dst);
+        long i = (long)(blockIdx.x - S) * kRefocusThreads + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) {          // four loads in flight per lane: PCIe latency
+            const float4 a = src4[i], b = src4[i + stride], c = src4[i + 2 * stride], d = src4[i + 3 * stride];
+            dst4[i] = a; dst4[i + stride] = b; dst4[i + 2 * stride] = c; dst4[i + 3 * stride] = d;
+        }
+        for (; i < n4; i += stride) dst4[i] = src4[i];
+        if (blockIdx.x == S && threadIdx.x < (stage_n & 3)) stage_dst[(n4 << 2) + threadIdx.x] = stage_src[(n4 << 2) + threadIdx.x];
+        return;
+    }
     __shared__ float red[2 * (kRefocusThreads / 64)];
     __shared__ float s_dsensor;
     __shared__ int s_count;
@@ -814,12 +884,12 @@ int aadff_psf_splat(const float* o, const float* ra, const float* centre, int sp
     return 0;
 }
 
-int aadff_psf_points(const float* points, int S, int N, int L, const aadff_surface_t* surf_main,
+static int psf_points_launch(const float* points, int S, int N, int L, const aadff_surface_t* surf_main,
                      const aadff_surface_t* surf_chief, aadff_lens_const_t lc, const aadff_lens_state_t* states,
                      const float* u_main, int spp, long main_stride_s, long main_stride_l, const float* u_chief,
                      int spp_chief, long chief_stride_s, long chief_stride_l, int ks, int centre_mode,
                      int map_layout, float* psf, float* centre_out_or_null, int* flags_or_null,
-                     aadff_stream_t stream) {
+                     const aadff_stage_t* stage, aadff_stream_t stream) {
     AADFF_CHECK_ARG(points && surf_main && states && u_main && psf, "psf_points: NULL pointer");
     AADFF_CHECK_ARG(centre_mode == 0 || (surf_chief && u_chief && spp_chief > 0), "psf_points: chief-ray centre needs surf_chief/u_chief");
     AADFF_CHECK_ARG(S > 0 && S <= 65535 && N > 0 && L > 0 && L <= 65535 && spp > 0, "psf_points: bad sizes S=%d N=%d L=%d spp=%d", S, N, L, spp);
@@ -830,12 +900,55 @@ int aadff_psf_points(const float* points, int S, int N, int L, const aadff_surfa
         map_grid = (int)lround(std::sqrt((double)N));
         AADFF_CHECK_ARG(map_grid * map_grid == N, "psf_points: psf_map layout needs N = g*g, got %d", N);
     }
-    hipLaunchKernelGGL(psf_points_kernel, dim3(N, L, S), dim3(256), 0, (hipStream_t)stream, points, N, L, surf_main,
+    StageArgs sa{};
+    if (stage && stage->first_slice < S) {
+        AADFF_CHECK_ARG(stage->src_host && stage->dst_dev && stage->counters, "psf_points_staged: NULL pointer in aadff_stage_t");
+        AADFF_CHECK_ARG(stage->first_slice >= 0 && stage->slice_stride > 0 && (stage->slice_stride & 3) == 0,
+                        "psf_points_staged: slice_stride %ld must be a positive multiple of 4", stage->slice_stride);
+        AADFF_CHECK_ARG((((uintptr_t)stage->src_host | (uintptr_t)stage->dst_dev) & 15) == 0, "psf_points_staged: blocks must be 16-byte aligned");
+        AADFF_CHECK_ARG(S < 65535, "psf_points_staged: S=%d", S);
+        void* mapped = nullptr;
+        if (hipHostGetDevicePointer(&mapped, const_cast<float*>(stage->src_host), 0) != hipSuccess || !mapped) {
+            (void)hipGetLastError();
+            AADFF_CHECK_ARG(false, "psf_points_staged: src_host is not pinned (device-mapped) host memory");
+        }
+        sa.src = reinterpret_cast<const float4*>(mapped);
+        sa.dst = reinterpret_cast<float4*>(stage->dst_dev);
+        sa.slice_n4 = stage->slice_stride >> 2;
+        sa.first_slice = stage->first_slice;
+        sa.copy_wgs = (int)std::min<long>(std::min<long>(AADFF_STAGE_COPY_WGS, (long)N * L), (sa.slice_n4 + kPsfThreads - 1) / kPsfThreads);
+        sa.counters = stage->counters;
+        sa.target = stage->generation * (unsigned)sa.copy_wgs;
+    }
+    hipLaunchKernelGGL(psf_points_kernel, dim3(N, L, sa.src ? S + 1 : S), dim3(kPsfThreads), 0, (hipStream_t)stream, points, N, L, surf_main,
                        surf_chief, lc, states, u_main, spp, main_stride_s, main_stride_l, u_chief, spp_chief, chief_stride_s,
                        chief_stride_l, make_splat_geom(lc.pixel_size, ks),
-                       centre_mode, map_grid, psf, centre_out_or_null, flags_or_null);
+                       centre_mode, map_grid, psf, centre_out_or_null, flags_or_null, sa);
     AADFF_CHECK_LAUNCH();
     return 0;
+}
+
+int aadff_psf_points(const float* points, int S, int N, int L, const aadff_surface_t* surf_main,
+                     const aadff_surface_t* surf_chief, aadff_lens_const_t lc, const aadff_lens_state_t* states,
+                     const float* u_main, int spp, long main_stride_s, long main_stride_l, const float* u_chief,
+                     int spp_chief, long chief_stride_s, long chief_stride_l, int ks, int centre_mode,
+                     int map_layout, float* psf, float* centre_out_or_null, int* flags_or_null,
+                     aadff_stream_t stream) {
+    return psf_points_launch(points, S, N, L, surf_main, surf_chief, lc, states, u_main, spp, main_stride_s, main_stride_l,
+                             u_chief, spp_chief, chief_stride_s, chief_stride_l, ks, centre_mode, map_layout, psf,
+                             centre_out_or_null, flags_or_null, nullptr, stream);
+}
+
+int aadff_psf_points_staged(const float* points, int S, int N, int L, const aadff_surface_t* surf_main,
+                            const aadff_surface_t* surf_chief, aadff_lens_const_t lc, const aadff_lens_state_t* states,
+                            const float* u_main, int spp, long main_stride_s, long main_stride_l, const float* u_chief,
+                            int spp_chief, long chief_stride_s, long chief_stride_l, int ks, int centre_mode,
+                            int map_layout, float* psf, float* centre_out_or_null, int* flags_or_null,
+                            const aadff_stage_t* stage, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(stage, "psf_points_staged: NULL stage");
+    return psf_points_launch(points, S, N, L, surf_main, surf_chief, lc, states, u_main, spp, main_stride_s, main_stride_l,
+                             u_chief, spp_chief, chief_stride_s, chief_stride_l, ks, centre_mode, map_layout, psf,
+                             centre_out_or_null, flags_or_null, stage, stream);
 }
 
 int aadff_refocus(const float* depth, int S, const float* u, int spp, long u_stride_s,
@@ -843,7 +956,28 @@ int aadff_refocus(const float* depth, int S, const float* u, int spp, long u_str
                   aadff_stream_t stream) {
     AADFF_CHECK_ARG(depth && u && surf_green && states, "refocus: NULL pointer");
     AADFF_CHECK_ARG(S > 0 && spp > 0 && lc.n_surf > 0 && lc.n_surf <= AADFF_MAX_SURF, "refocus: bad sizes S=%d spp=%d", S, spp);
-    hipLaunchKernelGGL(refocus_kernel, dim3(S), dim3(kRefocusThreads), 0, (hipStream_t)stream, depth, u, spp, u_stride_s, surf_green, lc, states, 1);
+    hipLaunchKernelGGL(refocus_kernel, dim3(S), dim3(kRefocusThreads), 0, (hipStream_t)stream, depth, u, spp, u_stride_s, surf_green, lc, states, 1, S,
+                       (const float*)nullptr, (float*)nullptr, 0L);
+    AADFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int aadff_refocus_staged(const float* depth, int S, const float* u_host, float* u_dev, long n_u, int spp,
+                         long u_stride_s, const aadff_surface_t* surf_green, aadff_lens_const_t lc,
+                         aadff_lens_state_t* states, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(depth && u_host && u_dev && surf_green && states, "refocus_staged: NULL pointer");
+    AADFF_CHECK_ARG(S > 0 && spp > 0 && lc.n_surf > 0 && lc.n_surf <= AADFF_MAX_SURF, "refocus_staged: bad sizes S=%d spp=%d", S, spp);
+    AADFF_CHECK_ARG(n_u >= 0, "refocus_staged: n_u %ld", n_u);
+    AADFF_CHECK_ARG((((uintptr_t)u_host | (uintptr_t)u_dev) & 15) == 0, "refocus_staged: u_host/u_dev must be 16-byte aligned");
+    void* mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, const_cast<float*>(u_host), 0) != hipSuccess || !mapped) {
+        (void)hipGetLastError();
+        AADFF_CHECK_ARG(false, "refocus_staged: u_host is not pinned (device-mapped) host memory");
+    }
+    const long n4 = n_u >> 2;
+    const int copy_wgs = (int)std::min<long>(kStageWorkgroups, std::max<long>(1, (n4 + kRefocusThreads - 1) / kRefocusThreads));
+    hipLaunchKernelGGL(refocus_kernel, dim3(S + copy_wgs), dim3(kRefocusThreads), 0, (hipStream_t)stream, depth,
+                       (const float*)mapped, spp, u_stride_s, surf_green, lc, states, 1, S, (const float*)mapped, u_dev, n_u);
     AADFF_CHECK_LAUNCH();
     return 0;
 }
@@ -853,7 +987,7 @@ int aadff_post_computation(int S, const aadff_surface_t* surf_green, aadff_lens_
     AADFF_CHECK_ARG(surf_green && states, "post_computation: NULL pointer");
     AADFF_CHECK_ARG(S > 0 && lc.n_surf > 0 && lc.n_surf <= AADFF_MAX_SURF, "post_computation: bad sizes S=%d", S);
     hipLaunchKernelGGL(refocus_kernel, dim3(S), dim3(kRefocusThreads), 0, (hipStream_t)stream, (const float*)nullptr,
-                       (const float*)nullptr, 0, 0L, surf_green, lc, states, 0);
+                       (const float*)nullptr, 0, 0L, surf_green, lc, states, 0, S, (const float*)nullptr, (float*)nullptr, 0L);
     AADFF_CHECK_LAUNCH();
     return 0;
 }

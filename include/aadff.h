@@ -171,6 +171,31 @@ int aadff_psf_points(const float* points, int S, int N, int L,
                      int ks, int centre_mode, int map_layout, float* psf, float* centre_out_or_null,
                      int* flags_or_null, aadff_stream_t stream);
 
+/* Upload of the uniform blocks of focus states [first_slice, S) folded into an
+ * aadff_psf_points launch: a few leading workgroups copy src_host (PINNED host memory,
+ * [S][slice_stride] floats, the layout u_main/u_chief index into) to dst_dev and bump
+ * counters[s]; the PSF workgroups of those states wait for counters[s] to reach
+ * generation * (number of copy workgroups).  Blocks of states < first_slice must already be
+ * in dst_dev (aadff_refocus_staged with n_u = first_slice*slice_stride puts them there, hidden
+ * behind the focus traces).  counters: [S] device words zeroed once; generation = 1, 2, 3 ...
+ * for successive launches on the same counters (same S, N, L, slice_stride each time). */
+typedef struct aadff_stage {
+    const float* src_host;
+    float*       dst_dev;
+    long         slice_stride;
+    int          first_slice;
+    unsigned     generation;
+    unsigned*    counters;
+} aadff_stage_t;
+
+int aadff_psf_points_staged(const float* points, int S, int N, int L,
+                     const aadff_surface_t* surf_main, const aadff_surface_t* surf_chief,
+                     aadff_lens_const_t lc, const aadff_lens_state_t* states,
+                     const float* u_main, int spp, long main_stride_s, long main_stride_l,
+                     const float* u_chief, int spp_chief, long chief_stride_s, long chief_stride_l,
+                     int ks, int centre_mode, int map_layout, float* psf, float* centre_out_or_null,
+                     int* flags_or_null, const aadff_stage_t* stage, aadff_stream_t stream);
+
 /* Refocus S lens states in one launch: trace spp rays from (0,0,depth[s]) (green table),
  * least-squares axis crossing -> d_sensor, then hfov/foclen/fnum.  Replaces
  * Lensgroup.refocus + post_computation + calc_fov + calc_efl,
@@ -179,6 +204,18 @@ int aadff_psf_points(const float* points, int S, int N, int L,
 int aadff_refocus(const float* depth, int S, const float* u, int spp, long u_stride_s,
                   const aadff_surface_t* surf_green, aadff_lens_const_t lc,
                   aadff_lens_state_t* states, aadff_stream_t stream);
+
+/* aadff_refocus with the host->device upload of the step's uniform block folded into the same
+ * launch: u_host is PINNED host memory (hipHostMalloc / torch pin_memory) in the layout
+ * aadff_psf_points will read; the S focus workgroups read their 2*spp draws
+ * (u_host + s*u_stride_s) over PCIe while extra workgroups copy its first n_u floats to u_dev
+ * (the rest can ride on the PSF launch, aadff_psf_points_staged).
+ * Saves the separate hipMemcpyAsync and its queue gap in front of a focal stack
+ * (the torch.rand draws of deeplens/optics.py:480-481,1166 stay on the host, Appendix B).
+ * Both pointers 16-byte aligned.  The host block may be reused once this launch completed. */
+int aadff_refocus_staged(const float* depth, int S, const float* u_host, float* u_dev, long n_u, int spp,
+                         long u_stride_s, const aadff_surface_t* surf_green, aadff_lens_const_t lc,
+                         aadff_lens_state_t* states, aadff_stream_t stream);
 
 /* hfov/foclen/fnum for states whose d_sensor is already set (lens load, or a caller
  * that assigns d_sensor).  Replaces post_computation, deeplens/optics.py:178-187. */

@@ -577,3 +577,42 @@ def test_focal_stack_m1_layered_vs_oracle(repo_root):
     idx_g, cen_g = depth_layers(depth.to(DEV), 3)
     idx_o, cen_o = opsf.depth_layers(depth, 3)
     assert torch.equal(idx_g.cpu(), idx_o) and torch.allclose(cen_g.cpu(), cen_o)
+
+
+def test_staged_upload_equals_plain_copy_over_repeated_steps(repo_root, monkeypatch):
+    """aadff_refocus_staged + aadff_psf_points_staged (upload folded into the launches, per-state counters
+    reused across steps) == the hipMemcpyAsync path on the same RNG stream, for several steps of one plan."""
+    from aadff import focal_stack as fs
+    H = W = 64
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(H, W), device=DEV)
+    img = tt(synth_rgb(H, W))[None].to(DEV)
+    fds = [-600.0, -800.0, -1100.0, -1500.0, -2500.0, -5000.0]
+    outs = {}
+    for staged in (True, False):
+        monkeypatch.setattr(fs, "STAGED_UPLOAD", staged)
+        plan = fs.StackPlan(lens, len(fds), H, W, 1, 3, 5, 11, 512)
+        res = []
+        for step in range(5):                                  # > RING: pinned slots and counters are reused
+            torch.manual_seed(100 + step)
+            o, m = render_focal_stack_m1(lens, img, -1200.0, fds, grid=5, ks=11, spp=512, plan=plan, return_maps=True)
+            res.append((o.clone(), m.clone()))
+        torch.cuda.synchronize()
+        assert int(plan.flags.item()) & 8 == 0                 # no staging time-out
+        assert (plan.stage_generation > 0) == staged
+        outs[staged] = res
+    for (a, ma), (b, mb) in zip(outs[True], outs[False]):
+        assert (ma - mb).abs().max().item() <= 2e-6            # histogram atomics: sum order
+        assert (a - b).abs().max().item() <= 2e-6
+    assert (outs[True][0][0] - outs[True][1][0]).abs().max().item() > 1e-4   # different seeds do differ
+
+
+def test_staged_upload_rejects_unpinned_host_block(repo_root):
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(64, 64), device=DEV)
+    u_host = torch.rand(4 * GEO_SPP)                           # pageable, not device-mapped
+    u_dev = torch.empty(4 * GEO_SPP, device=DEV)
+    dep = torch.tensor([-1000.0], device=DEV)
+    states = torch.zeros(C.sizeof(_abi.LensState), dtype=torch.uint8, device=DEV)
+    with pytest.raises(RuntimeError, match="not pinned"):
+        _abi.call("aadff_refocus_staged", _abi.ptr(dep), 1, C.c_void_p(u_host.data_ptr()), _abi.ptr(u_dev), 2 * GEO_SPP,
+                  GEO_SPP, 2 * GEO_SPP, _abi.ptr(lens._table([0.589])), lens._lens_const(), _abi.ptr(states),
+                  _abi.stream_ptr(torch.device(DEV)))
