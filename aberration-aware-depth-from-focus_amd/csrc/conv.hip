@@ -415,6 +415,268 @@ __global__ __launch_bounds__(64 * NW) void conv_psf_map_mfma_kernel(
 }
 
 // ------------------------------------------------------------------------------------
+// Slice-batched MFMA path (ks = 11, stacks of >= 3 slices): the S slices of a stack share the image, so the image
+// window is the shared GEMM operand and the slices ride on the M dimension:
+//   D[m][n] += sum_k T[m][k] X[k][n]
+//   n = cx (16): base pixel (y, X0 + 2 cx) of a 2-row x 32-column group
+//   m = (sl, du, j) = 4 slices x 2 output rows x 2 output columns      (16)
+//   k = (u, t), u = 0..11 input rows, t = 0..11 input columns           (144 of K = 160)
+//   X[(u,t)][cx] = in[y + u][X0 + 2 cx + t],      T[(sl,du,j)][(u,t)] = w_sl(u - du, t - j)  (0 outside the 11x11 taps)
+// -> 121 of 160 MACs per lane-slot useful for 4 slices at once (the Toeplitz form above: 11 of 32 for one slice):
+// 15 MFMAs per 2x32 pixels x 4 slices instead of 66, and less than half the LDS operand bytes.
+// K order: a lane's 8 consecutive k (k-group kg, step st) are the 2x4 block of input rows (2up, 2up+1) x columns
+// (2dd0 .. 2dd0+3), slot q = 2 st + (kg >> 1): dd0 = 2 (q / 3), up = 2 (q % 3) + (kg & 1); slot 9 is padding (T = 0).
+// The image tile is stored row-pair interleaved (tile[a][dd][row parity] dwords of fp16 pairs), so that block is 16
+// contiguous bytes, 8-byte aligned: two ds_read_b64 per operand, and with a 224-dword row-pair pitch the 32 lanes of
+// a read group (16 cx x {up, up+1}) cover all 64 banks once.  T fragments (40 VGPRs) are built once per wave from
+// zero-padded tap rows in LDS; a workgroup = NC slice chunks x 2 row groups sharing one staged band of a patch, so
+// the image is read from HBM once for all slices.  Same exact fp16 hi/lo operand split as above.
+// ------------------------------------------------------------------------------------
+namespace sb {
+constexpr int KS = 11, PAD = 5;
+constexpr int TCOLS = 96;                 // output columns per workgroup tile (3 column blocks of 32)
+constexpr int WCOLS = TCOLS + 12;         // staged columns: t <= 11
+constexpr int WDW = WCOLS / 2;            // 54 dword columns (fp16 pairs) per row
+constexpr int RPP = 224;                  // row-PAIR pitch in dwords (== 32 mod 64): hi plane at 0, lo plane at LO
+constexpr int LO = 112;
+constexpr int PROWS = 14, PRD = 8;        // padded tap rows per slice (rows 0, 12, 13 zero), 8 dwords each
+constexpr int PSL = PROWS * PRD + 2;      // slice stride 114 dwords: the 32 lanes of a T-build read hit 32 banks
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) f2u { float x, y; };       // 8-byte store at 4-byte alignment
+
+// 16 operand bytes as two ds_read_b64 (full-rate LDS reads; a ds_read2_b64 or an 8-byte-aligned b128 is half rate
+// or worse).  Not tracked by the compiler's waitcnt insertion: consume only after lds_wait().
+template <int OFF>
+__device__ __forceinline__ void lds_read16(uint2v& a, uint2v& b, unsigned byte_addr) {
+    asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4" : "=v"(a), "=v"(b) : "v"(byte_addr), "n"(OFF), "n"(OFF + 8));
+}
+}  // namespace sb
+
+// Workgroup = one band of RB output rows x 96 columns of one patch and channel plane; wave = one chunk of 4 slices
+// (NC waves).  The band is staged once for all slices (HBM reads the image once), every wave builds the T fragments
+// of its own chunk and walks the band's row pairs.
+template <int RB, int NC>
+__global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
+    const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, int C, int S, int H, int W,
+    int grid, int ntx, int nty, int npass, PatchBounds pb) {
+    using namespace sb;
+    constexpr int NW = NC, THP = RB + KS - 1, NSL = 4 * NC;
+    static_assert(RB % 2 == 0 && THP % 2 == 0, "bands are whole row pairs");
+    static_assert(WDW <= 64, "one lane per dword column");
+    __shared__ __attribute__((aligned(16))) unsigned tile[(THP / 2) * RPP];
+    __shared__ __attribute__((aligned(16))) unsigned prow[2][NSL * PSL];            // [hi | lo] planes of the padded tap rows
+    __shared__ float red[NW];
+    __shared__ float s_isw[NSL];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pj = udiv_magic(blockIdx.x, ntx, pb.m_ntx), tx = blockIdx.x - pj * ntx;
+    const int pi = udiv_magic(blockIdx.y, nty, pb.m_nty), ty = blockIdx.y - pi * nty;
+    const int bc = udiv_magic(blockIdx.z, npass, pb.m_nchunk), pass = blockIdx.z - bc * npass;
+    const int c = bc - udiv_magic(bc, C, pb.m_c) * C;
+    const int x_hi = pb.wb[pj + 1], y_hi = pb.hb[pi + 1];
+    const int x0 = pb.wb[pj] + tx * TCOLS, y0 = pb.hb[pi] + ty * RB;
+    if (x0 >= x_hi || y0 >= y_hi) return;
+    const int G = grid * KS;
+    const int s_base = pass * NSL;                       // first slice of this workgroup
+    const int chunk = wave;
+    const int kg = lane >> 4, lo4 = lane & 15;
+
+    // ---- global loads up front: this wave's taps (4 slices, 2 per lane and slice), then its share of the image rows ----
+    float tw0[4], tw1[4];
+    const int t0 = lane, t1 = lane + 64;                                       // taps t0 (< 121 always) and t1 (< 121 for lane < 57)
+    const int tu0 = t0 / KS, tc0 = t0 - tu0 * KS, tu1 = t1 / KS, tc1 = t1 - tu1 * KS;
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+        const int s = s_base + 4 * chunk + k2;
+        tw0[k2] = 0.f; tw1[k2] = 0.f;
+        if (s < S) {
+            // w(u,v) = psf[KS-1-u][KS-1-v]  (deeplens/render_psf.py:60 flips the kernel before conv2d)
+            const float* wp = psf + ((size_t)(s * C + c) * G + pi * KS) * G + pj * KS;
+            tw0[k2] = wp[(size_t)(KS - 1 - tu0) * G + (KS - 1 - tc0)];
+            if (t1 < KS * KS) tw1[k2] = wp[(size_t)(KS - 1 - tu1) * G + (KS - 1 - tc1)];
+        }
+    }
+    // image band: wave = row (strided), lane = dword column (two pixels)
+    constexpr int NPT = (THP + NW - 1) / NW;
+    float v0[NPT], v1[NPT];
+    float amax = 0.f;
+    {
+        const float* plane = img + (size_t)bc * H * W;
+        const int xa = reflect_idx(x0 - PAD + 2 * lane, W), xb = reflect_idx(x0 - PAD + 2 * lane + 1, W);
+#pragma unroll
+        for (int e = 0; e < NPT; ++e) {
+            const int r = wave + e * NW;
+            const bool in = lane < WDW && r < THP;
+            const float* row = plane + (size_t)reflect_idx(y0 - PAD + r, H) * W;
+            v0[e] = in ? row[xa] : 0.f;
+            v1[e] = in ? row[xb] : 0.f;
+            amax = fmaxf(amax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
+        }
+    }
+    // ---- padded fp16 hi/lo tap rows of this wave's chunk ----
+    {
+        _Float16* ph = reinterpret_cast<_Float16*>(&prow[0][0]);
+        _Float16* pl = reinterpret_cast<_Float16*>(&prow[1][0]);
+        for (int e = lane; e < 4 * PSL; e += 64) { prow[0][4 * chunk * PSL + e] = 0u; prow[1][4 * chunk * PSL + e] = 0u; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            const int sl = 4 * chunk + k2;
+            const float wmax = wave_max(fmaxf(fabsf(tw0[k2]), fabsf(tw1[k2])));
+            float sw, isw;
+            pow2_scale(wmax, sw, isw);
+            if (lane == 0) s_isw[sl] = isw;
+            {
+                const float a = tw0[k2] * sw;
+                const _Float16 h = (_Float16)a;
+                const int base = (sl * PSL + (tu0 + 1) * PRD) * 2 + 2 + tc0;        // halves; taps start at half index 2
+                ph[base] = h;
+                pl[base] = (_Float16)(a - (float)h);
+            }
+            if (t1 < KS * KS) {
+                const float a = tw1[k2] * sw;
+                const _Float16 h = (_Float16)a;
+                const int base = (sl * PSL + (tu1 + 1) * PRD) * 2 + 2 + tc1;
+                ph[base] = h;
+                pl[base] = (_Float16)(a - (float)h);
+            }
+        }
+    }
+    amax = wave_max(amax);
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();
+    float tmax = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) tmax = fmaxf(tmax, red[w]);
+    float sx, isx;
+    pow2_scale(tmax, sx, isx);
+#pragma unroll
+    for (int e = 0; e < NPT; ++e) {
+        const int r = wave + e * NW;
+        if (lane < WDW && r < THP) {
+            const float a = v0[e] * sx, b = v1[e] * sx;
+            const _Float16 ah = (_Float16)a, bh = (_Float16)b;
+            const _Float16 al = (_Float16)(a - (float)ah), bl = (_Float16)(b - (float)bh);
+            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+            const int d = (r >> 1) * RPP + 2 * lane + (r & 1);
+            tile[d] = __builtin_bit_cast(unsigned, (half2v){ah, bh});
+            tile[d + LO] = __builtin_bit_cast(unsigned, (half2v){al, bl});
+        }
+    }
+
+    // ---- T fragments of this wave's chunk: slot q = 2 st + (kg >> 1) -> column pair dd0, row pair up (see header) ----
+    uint4v Th[5], Tl[5];
+    {
+        const int sl = lo4 >> 2, du = (lo4 >> 1) & 1, j = lo4 & 1;
+        const unsigned* pbh = &prow[0][(chunk * 4 + sl) * PSL];
+        const unsigned* pbl = &prow[1][(chunk * 4 + sl) * PSL];
+#pragma unroll
+        for (int st = 0; st < 5; ++st) {
+            const int q = 2 * st + (kg >> 1);
+            const bool real = q < 9;
+            const int dd0 = real ? 2 * (q / 3) : 0, up = 2 * (q % 3) + (kg & 1);
+            const int row = real ? 2 * up - du + 1 : 12;                       // tap row u - du, stored at +1; rows 12, 13 are zero
+            const int start = 2 + 2 * dd0 - j;                                 // half index of column t = 2 dd0
+            const int e = start >> 1;
+            const unsigned sh = (start & 1) * 16;
+            const unsigned* a0 = pbh + row * PRD + e;
+            const unsigned* a1 = pbl + row * PRD + e;
+            Th[st] = (uint4v){__builtin_amdgcn_alignbit(a0[1], a0[0], sh), __builtin_amdgcn_alignbit(a0[PRD + 1], a0[PRD], sh),
+                              __builtin_amdgcn_alignbit(a0[2], a0[1], sh), __builtin_amdgcn_alignbit(a0[PRD + 2], a0[PRD + 1], sh)};
+            Tl[st] = (uint4v){__builtin_amdgcn_alignbit(a1[1], a1[0], sh), __builtin_amdgcn_alignbit(a1[PRD + 1], a1[PRD], sh),
+                              __builtin_amdgcn_alignbit(a1[2], a1[1], sh), __builtin_amdgcn_alignbit(a1[PRD + 2], a1[PRD + 1], sh)};
+        }
+    }
+    const float inv = isx * s_isw[chunk * 4 + kg];                            // D rows 4 kg + i belong to slice kg of the chunk
+    __syncthreads();                                                          // the whole band is in LDS
+
+    const int s_out = s_base + chunk * 4 + kg;
+    const bool s_ok = s_out < S;
+    // stores: wave-uniform 64-bit base (first slice of the chunk) + 32-bit per-lane byte offset (host checks 16 H W < 2^32)
+    char* wbase = reinterpret_cast<char*>(out + ((size_t)bc * S + s_base + chunk * 4) * H * W);
+    const unsigned w4 = (unsigned)W * 4u;
+    bool pair_ok[3], one_ok[3];
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb) {
+        const int x = x0 + 32 * cb + 2 * lo4;
+        pair_ok[cb] = s_ok && x + 1 < x_hi;
+        one_ok[cb] = s_ok && x + 1 == x_hi;
+    }
+
+    // X operand byte addresses: lane n = cx
+    unsigned xaddr[5];
+    const unsigned tile_base = (unsigned)(size_t)tile;                        // LDS byte address of the tile
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int q = 2 * st + (kg >> 1);
+        const bool real = q < 9;
+        const int dd0 = real ? 2 * (q / 3) : 0, up = real ? 2 * (q % 3) + (kg & 1) : (kg & 1);
+        xaddr[st] = tile_base + 4u * (unsigned)(up * RPP + 2 * (lo4 + dd0));
+    }
+
+    int npairs = (y_hi - y0 + 1) / 2;                   // row pairs of this band that hold valid rows
+    npairs = npairs > RB / 2 ? RB / 2 : npairs;
+    // 15 (cb, st) steps per row pair, operand reads two steps ahead (three 8-register buffers; 15 % 3 == 0 keeps the
+    // rotation across row pairs, so the last two steps prefetch the next row pair's first two).  Column block
+    // outermost: one accumulator live, its stores overlap the next block's MFMAs.
+    uint2v xq[3][4];                                    // [buffer][hi0, hi1, lo0, lo1]
+    auto issue = [&](auto stepc, unsigned rowb) {
+        constexpr int step = decltype(stepc)::value, cb = step / 5, st = step % 5, bf = step % 3;
+        const unsigned a = xaddr[st] + rowb;
+        lds_read16<cb * 128>(xq[bf][0], xq[bf][1], a);
+        lds_read16<LO * 4 + cb * 128>(xq[bf][2], xq[bf][3], a);
+    };
+    issue(std::integral_constant<int, 0>{}, 0u);
+    issue(std::integral_constant<int, 1>{}, 0u);
+#pragma unroll 1
+    for (int rpi = 0; rpi < npairs; ++rpi) {
+        const unsigned rowb = (unsigned)(rpi * RPP * 4);
+        const unsigned rowb_next = (unsigned)((rpi + 1 < npairs ? rpi + 1 : rpi) * RPP * 4);
+        const int yl = 2 * rpi;
+        const bool row1 = y0 + yl + 1 < y_hi;           // row 0 of the pair is valid by construction of npairs
+        const unsigned loff = ((unsigned)kg * (unsigned)H + (unsigned)(y0 + yl)) * w4 + (unsigned)(x0 + 2 * lo4) * 4u;
+        float4v acc;
+        auto step_fn = [&](auto stepc) {
+            constexpr int step = decltype(stepc)::value, cb = step / 5, st = step % 5, bf = step % 3;
+            if constexpr (step + 2 < 15) issue(std::integral_constant<int, step + 2>{}, rowb);
+            else issue(std::integral_constant<int, step + 2 - 15>{}, rowb_next);
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xq[bf][0]), "+v"(xq[bf][1]), "+v"(xq[bf][2]), "+v"(xq[bf][3]));
+            const uint4v h4 = {xq[bf][0].x, xq[bf][0].y, xq[bf][1].x, xq[bf][1].y};
+            const uint4v l4 = {xq[bf][2].x, xq[bf][2].y, xq[bf][3].x, xq[bf][3].y};
+            const half8v bh = __builtin_bit_cast(half8v, h4), bl = __builtin_bit_cast(half8v, l4);
+            const half8v th = __builtin_bit_cast(half8v, Th[st]), tl = __builtin_bit_cast(half8v, Tl[st]);
+            if constexpr (st == 0) acc = (float4v){0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl, bh, acc, 0, 0, 0);
+            if constexpr (st == 4) {
+                // D[m = 4 kg + i][n = cx]: i = (du, j) -> out[slice kg][y + du][x0 + 32 cb + 2 cx + j]
+                const float a0 = acc[0] * inv, b0 = acc[1] * inv, a1 = acc[2] * inv, b1 = acc[3] * inv;
+                char* o0 = wbase + loff + cb * 128;
+                char* o1 = wbase + (loff + w4) + cb * 128;
+                if (pair_ok[cb]) {
+                    *reinterpret_cast<f2u*>(o0) = (f2u){a0, b0};
+                    if (row1) *reinterpret_cast<f2u*>(o1) = (f2u){a1, b1};
+                } else if (one_ok[cb]) {
+                    *reinterpret_cast<float*>(o0) = a0;
+                    if (row1) *reinterpret_cast<float*>(o1) = a1;
+                }
+            }
+        };
+        step_fn(std::integral_constant<int, 0>{}); step_fn(std::integral_constant<int, 1>{}); step_fn(std::integral_constant<int, 2>{});
+        step_fn(std::integral_constant<int, 3>{}); step_fn(std::integral_constant<int, 4>{}); step_fn(std::integral_constant<int, 5>{});
+        step_fn(std::integral_constant<int, 6>{}); step_fn(std::integral_constant<int, 7>{}); step_fn(std::integral_constant<int, 8>{});
+        step_fn(std::integral_constant<int, 9>{}); step_fn(std::integral_constant<int, 10>{}); step_fn(std::integral_constant<int, 11>{});
+        step_fn(std::integral_constant<int, 12>{}); step_fn(std::integral_constant<int, 13>{}); step_fn(std::integral_constant<int, 14>{});
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the two prefetches issued by the last row pair
+}
+
+// ------------------------------------------------------------------------------------
 // Generic path (any odd ks <= AADFF_MAX_KS): same tiling, runtime loops, PSF taps staged
 // flipped in LDS and read as broadcasts.  Correctness path for unusual kernel sizes.
 // ------------------------------------------------------------------------------------
@@ -487,6 +749,34 @@ static int launch_fast(const float* img, const float* psf, float* out, int B, in
     // path: "mfma" (Toeplitz GEMM on fp16-split MFMA, KS <= 11) or "valu" (packed fp32 FMA); AADFF_CONV_PATH overrides
     const char* penv = getenv("AADFF_CONV_PATH");
     const bool use_mfma = KS <= 11 && !(penv && penv[0] == 'v');
+    if constexpr (KS == 11) {
+        // stacks: slice-batched GEMM (the image is the shared operand); "toeplitz" / "valu" force the older paths
+        if (S >= 3 && !penv) {
+            constexpr int RB = 24;
+            const int nc = S <= 4 ? 1 : (S <= 8 ? 2 : (S <= 12 ? 3 : 4));
+            const int npass = (S + 4 * nc - 1) / (4 * nc);
+            int mh = 0, mw = 0;
+            for (int i = 0; i < grid; ++i) {
+                mh = std::max(mh, pb.hb[i + 1] - pb.hb[i]);
+                mw = std::max(mw, pb.wb[i + 1] - pb.wb[i]);
+            }
+            const int sntx = (mw + sb::TCOLS - 1) / sb::TCOLS, snty = (mh + RB - 1) / RB;
+            AADFF_CHECK_ARG((size_t)B * C * npass <= 65535 && (size_t)snty * grid <= 65535, "render_psf_map: grid too large");
+            AADFF_CHECK_ARG((size_t)H * W <= ((size_t)1 << 27), "render_psf_map: image planes above 2^27 pixels are not supported on the stack path");
+            PatchBounds pbs = pb;
+            pbs.m_ntx = magic_of(sntx); pbs.m_nty = magic_of(snty); pbs.m_nchunk = magic_of(npass); pbs.m_c = magic_of(C);
+            dim3 gs(sntx * grid, snty * grid, B * C * npass);
+#define AADFF_LAUNCH_S(NCV) hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV>), gs, dim3(64 * NCV), 0, st, img, psf, out, C, S, H, W, grid, sntx, snty, npass, pbs)
+            switch (nc) {
+                case 1: AADFF_LAUNCH_S(1); break;
+                case 2: AADFF_LAUNCH_S(2); break;
+                case 3: AADFF_LAUNCH_S(3); break;
+                default: AADFF_LAUNCH_S(4);
+            }
+#undef AADFF_LAUNCH_S
+            return 0;
+        }
+    }
     if constexpr (KS <= 11) {
         if (use_mfma) {
             const int nchunk_m = (S + nw * AADFF_MFMA_SPW - 1) / (nw * AADFF_MFMA_SPW);

@@ -162,8 +162,11 @@ def main():
                        "gather": bool(comm is not None),
                        "arithmetic": "fp32 ray trace / PSF grid; convolution operands carried as exact hi+lo fp16 pairs "
                                      "(22-bit significand) on MFMA with fp32 accumulation, <= 5e-7 abs from an fp32 FMA chain"},
-            "roofline": {"kernel": ("conv_psf_map_kernel<11,5> (packed fp32 FMA)" if os.environ.get("AADFF_CONV_PATH", "m")[0] == "v"
-                                    else "conv_psf_map_mfma_kernel<11,5> (Toeplitz GEMM, exact fp16x3 operand split, fp32 accumulate)") + ", stack-fused S=10",
+            "roofline": {"kernel": {"v": "conv_psf_map_kernel<11,5> (packed fp32 FMA)",
+                                    "t": "conv_psf_map_mfma_kernel<11,5> (Toeplitz GEMM, exact fp16x3 operand split, fp32 accumulate)"}.get(
+                                        os.environ.get("AADFF_CONV_PATH", "s")[0],
+                                        "conv_psf_map_sbatch_kernel<24,3> (slice-batched im2col GEMM on MFMA, exact fp16x3 operand split, "
+                                        "fp32 accumulate)") + ", stack-fused S=10",
                          "bound": "hbm", "achieved": round(achieved / 1e9, 2),
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
                          "kernel_ms": round(conv_ms, 4), "algorithmic_bytes_per_launch": ALG_BYTES_PER_SLICE * S,
