@@ -78,6 +78,7 @@ class StackPlan:
         # staged upload (aadff_refocus_staged + aadff_psf_points_staged): the first STAGE_FIRST states' draws are
         # copied behind the focus traces, the rest by leading workgroups of the PSF launch
         self.stage_counters = torch.zeros(S, dtype=torch.int32, device=dev)
+        self.refocus_scratch = torch.zeros(S * 16, dtype=torch.int32, device=dev)     # 64 B per focus state
         self.stage_generation = 0
         self._geo_key, self._dep, self._pts = None, None, None
 
@@ -158,7 +159,7 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
             ub = u.data_ptr()
             first = min(S, STAGE_FIRST)
             _abi.call("aadff_refocus_staged", _abi.ptr(dep), S, C.c_void_p(u_pin.data_ptr()), C.c_void_p(ub), first * plan.per,
-                      GEO_SPP, plan.per, _abi.ptr(plan.tab_green), plan.lc, _abi.ptr(plan.states), st)
+                      GEO_SPP, plan.per, _abi.ptr(plan.tab_green), plan.lc, _abi.ptr(plan.states), _abi.ptr(plan.refocus_scratch), st)
             plan.stage_generation += 1
             stage = _abi.Stage(u_pin.data_ptr(), ub, plan.per, first, plan.stage_generation & 0xFFFFFFFF,
                                plan.stage_counters.data_ptr())

@@ -736,46 +736,91 @@ __global__ __launch_bounds__(kPsfThreads) void psf_points_kernel(const float* __
 #ifndef AADFF_STAGE_COPY_WGS
 #define AADFF_STAGE_COPY_WGS 14
 #endif
-constexpr int kStageWorkgroups = 64;     // upload workgroups riding on the refocus launch (aadff_refocus_staged)
-constexpr int kRefocusThreads = 1024;     // 16 waves: the per-slice trace is latency-bound, not throughput-bound
-__global__ __launch_bounds__(kRefocusThreads) void refocus_kernel(const float* __restrict__ depth, const float* __restrict__ u,
+constexpr int kStageWorkgroups = 64;     // upload workgroups (x 1024 threads) riding on the refocus launch (aadff_refocus_staged)
+constexpr int kRefocusThreads = 1024;     // plain entry: 16 waves per focus state
+constexpr int kRefocusSplit = 4;          // staged entry: 4 workgroups x 256 threads per focus state, last arriver finishes
+struct RefocusScratch {                   // per focus state, zero-initialised once by the caller; self-resetting
+    float part[kRefocusSplit][2];         // (sum, count) of each quarter of the rays
+    unsigned arrived;
+    unsigned nan_seen;                    // NaN in a Newton residual of a quarter that did not finish the state
+    unsigned loaded, passed;              // [state 0 only] gate of the upload workgroups (see refocus_kernel)
+    unsigned pad[4];
+};
+static_assert(sizeof(RefocusScratch) == 64, "aadff.h documents 64 bytes per focus state");
+
+template <int NT, int SPLIT>
+__global__ __launch_bounds__(NT) void refocus_kernel(const float* __restrict__ depth, const float* __restrict__ u,
                                                        int spp, long u_ss, const aadff_surface_t* __restrict__ surf,
                                                        aadff_lens_const_t lc, aadff_lens_state_t* states,
                                                        int do_refocus, int S, const float* __restrict__ stage_src,
-                                                       float* __restrict__ stage_dst, long stage_n) {
-    if ((int)blockIdx.x >= S) {
+                                                       float* __restrict__ stage_dst, long stage_n, RefocusScratch* scratch) {
+    if ((int)blockIdx.x >= S * SPLIT) {
         // Upload workgroups: copy the pinned-host uniform block to HBM for the PSF kernel while the
-        // S focus workgroups (which read their own draws straight from the host block) trace.
+        // focus workgroups (which read their own draws straight from the host block) trace.
+        // The bulk copy would queue ~20 us of PCIe reads in front of the focus workgroups' own 16 KB of draws:
+        // wait until every focus workgroup holds its draws (they have lower block ids: dispatched first).
+        if constexpr (SPLIT > 1) {
+            if (threadIdx.x == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(&scratch->loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(S * SPLIT)) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1 << 20)) break;                       // never hang the queue; only the overlap is lost
+                }
+                const unsigned old = __hip_atomic_fetch_add(&scratch->passed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == gridDim.x - S * SPLIT - 1) {                  // last one through resets the gate for the next launch
+                    __hip_atomic_store(&scratch->loaded, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&scratch->passed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();
+        }
         const long n4 = stage_n >> 2;
-        const long stride = (long)(gridDim.x - S) * kRefocusThreads;
+        const int first = S * SPLIT;
+        const long stride = (long)(gridDim.x - first) * NT;
         const float4* src4 = reinterpret_cast<const float4*>(stage_src);
         float4* dst4 = reinterpret_cast<float4*>(stage_dst);
-        long i = (long)(blockIdx.x - S) * kRefocusThreads + threadIdx.x;
+        long i = (long)(blockIdx.x - first) * NT + threadIdx.x;
         for (; i + 3 * stride < n4; i += 4 * stride) {          // four loads in flight per lane: PCIe latency
             const float4 a = src4[i], b = src4[i + stride], c = src4[i + 2 * stride], d = src4[i + 3 * stride];
             dst4[i] = a; dst4[i + stride] = b; dst4[i + 2 * stride] = c; dst4[i + 3 * stride] = d;
         }
         for (; i < n4; i += stride) dst4[i] = src4[i];
-        if (blockIdx.x == S && threadIdx.x < (stage_n & 3)) stage_dst[(n4 << 2) + threadIdx.x] = stage_src[(n4 << 2) + threadIdx.x];
+        if ((int)blockIdx.x == first && threadIdx.x < (stage_n & 3)) stage_dst[(n4 << 2) + threadIdx.x] = stage_src[(n4 << 2) + threadIdx.x];
         return;
     }
-    __shared__ float red[2 * (kRefocusThreads / 64)];
+    __shared__ float red[2 * (NT / 64)];
     __shared__ float s_dsensor;
     __shared__ int s_count;
-    const int s = blockIdx.x, tid = threadIdx.x;
+    __shared__ int s_last, s_flags0;
+    const int s = blockIdx.x / SPLIT, part = blockIdx.x - s * SPLIT, tid = threadIdx.x;
     int nan_flag = 0;
     int flags = 0;
     if (do_refocus) {
         const float* ut = u + (size_t)s * u_ss;
         const float* ur = ut + spp;
         const float dep = depth[s];
+        // this workgroup's rays: [begin, end); two rays per lane (packed arithmetic)
+        const int chunk = (spp + SPLIT - 1) / SPLIT;
+        const int begin = part * chunk, end = min(spp, begin + chunk);
         float sum = 0.f, cnt = 0.f;
-        for (int i = tid; i < spp; i += 2 * kRefocusThreads) {            // two rays per lane (packed arithmetic)
-            const int i1 = i + kRefocusThreads;
-            const i2 act = {-1, i1 < spp ? -1 : 0};
+        // first pair of draws up front; with the staged entry they come over PCIe and open the upload gate
+        float pt0 = 0.f, pt1 = 0.f, pr0 = 0.f, pr1 = 0.f;
+        if (begin + tid < end) {
+            const int i = begin + tid, j1 = i + NT < end ? i + NT : i;
+            pt0 = ut[i]; pt1 = ut[j1]; pr0 = ur[i]; pr1 = ur[j1];
+        }
+        if constexpr (SPLIT > 1) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pt0), "+v"(pt1), "+v"(pr0), "+v"(pr1));
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(&scratch->loaded, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (int i = begin + tid; i < end; i += 2 * NT) {
+            const int i1 = i + NT;
+            const i2 act = {-1, i1 < end ? -1 : 0};
             const int j1 = act.y ? i1 : i;
             f2 x2, y2;
-            disc_sample2((f2){ut[i], ut[j1]}, (f2){ur[i], ur[j1]}, lc.first_r2, x2, y2);
+            const bool firstit = i == begin + tid;
+            disc_sample2((f2){firstit ? pt0 : ut[i], firstit ? pt1 : ut[j1]}, (f2){firstit ? pr0 : ur[i], firstit ? pr1 : ur[j1]}, lc.first_r2, x2, y2);
             Ray2 r;
             r.ox = x2; r.oy = y2; r.oz = f2s(lc.first_d);
             r.dx = x2; r.dy = y2; r.dz = f2s(lc.first_d - dep);               // o - (0,0,depth)
@@ -792,14 +837,37 @@ __global__ __launch_bounds__(kRefocusThreads) void refocus_kernel(const float* _
         }
         sum = wave_sum(sum); cnt = wave_sum(cnt);
         if ((tid & 63) == 0) { red[(tid >> 6) * 2] = sum; red[(tid >> 6) * 2 + 1] = cnt; }
-        __syncthreads();
+        const int s_nan = __syncthreads_or(nan_flag);
         if (tid == 0) {
             float ts = 0.f, tc = 0.f;
-            for (int w = 0; w < kRefocusThreads / 64; ++w) { ts += red[2 * w]; tc += red[2 * w + 1]; }
+            for (int w = 0; w < NT / 64; ++w) { ts += red[2 * w]; tc += red[2 * w + 1]; }
+            int last = 1;
+            s_flags0 = 0;
+            if constexpr (SPLIT > 1) {
+                // publish the partial, count arrivals (the counter wraps to 0 by itself), the last one reduces in
+                // fixed order (deterministic) and goes on to the field-of-view trace
+                RefocusScratch* sc = scratch + s;
+                sc->part[part][0] = ts; sc->part[part][1] = tc;
+                if (s_nan) atomicOr(&sc->nan_seen, 1u);
+                const unsigned old = __hip_atomic_fetch_add(&sc->arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                last = old == SPLIT - 1;
+                if (last) {
+                    __hip_atomic_store(&sc->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (atomicExch(&sc->nan_seen, 0u)) s_flags0 = 1;
+                    ts = 0.f; tc = 0.f;
+                    for (int p = 0; p < SPLIT; ++p) {
+                        ts += __hip_atomic_load(&sc->part[p][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        tc += __hip_atomic_load(&sc->part[p][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            s_last = last;
             s_dsensor = ts / tc;
             s_count = (int)tc;
         }
         __syncthreads();
+        if (!s_last) return;
+        flags = s_flags0;
     } else {
         if (tid == 0) { s_dsensor = states[s].d_sensor; s_count = states[s].n_focus_rays; }
         __syncthreads();
@@ -826,7 +894,7 @@ __global__ __launch_bounds__(kRefocusThreads) void refocus_kernel(const float* _
     if (tid == 0) {
         if (any_nan) flags |= 1;
         float ts = 0.f, tw = 0.f;
-        for (int w = 0; w < kRefocusThreads / 64; ++w) { ts += red[2 * w]; tw += red[2 * w + 1]; }
+        for (int w = 0; w < NT / 64; ++w) { ts += red[2 * w]; tw += red[2 * w + 1]; }
         float hfov = atanf(ts / tw);
         if (hfov != hfov) { hfov = 0.5f; flags |= 2; }
         const double th = tan((double)hfov);
@@ -956,16 +1024,16 @@ int aadff_refocus(const float* depth, int S, const float* u, int spp, long u_str
                   aadff_stream_t stream) {
     AADFF_CHECK_ARG(depth && u && surf_green && states, "refocus: NULL pointer");
     AADFF_CHECK_ARG(S > 0 && spp > 0 && lc.n_surf > 0 && lc.n_surf <= AADFF_MAX_SURF, "refocus: bad sizes S=%d spp=%d", S, spp);
-    hipLaunchKernelGGL(refocus_kernel, dim3(S), dim3(kRefocusThreads), 0, (hipStream_t)stream, depth, u, spp, u_stride_s, surf_green, lc, states, 1, S,
-                       (const float*)nullptr, (float*)nullptr, 0L);
+    hipLaunchKernelGGL((refocus_kernel<kRefocusThreads, 1>), dim3(S), dim3(kRefocusThreads), 0, (hipStream_t)stream, depth, u, spp, u_stride_s, surf_green, lc, states, 1, S,
+                       (const float*)nullptr, (float*)nullptr, 0L, (RefocusScratch*)nullptr);
     AADFF_CHECK_LAUNCH();
     return 0;
 }
 
 int aadff_refocus_staged(const float* depth, int S, const float* u_host, float* u_dev, long n_u, int spp,
                          long u_stride_s, const aadff_surface_t* surf_green, aadff_lens_const_t lc,
-                         aadff_lens_state_t* states, aadff_stream_t stream) {
-    AADFF_CHECK_ARG(depth && u_host && u_dev && surf_green && states, "refocus_staged: NULL pointer");
+                         aadff_lens_state_t* states, void* scratch, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(depth && u_host && u_dev && surf_green && states && scratch, "refocus_staged: NULL pointer");
     AADFF_CHECK_ARG(S > 0 && spp > 0 && lc.n_surf > 0 && lc.n_surf <= AADFF_MAX_SURF, "refocus_staged: bad sizes S=%d spp=%d", S, spp);
     AADFF_CHECK_ARG(n_u >= 0, "refocus_staged: n_u %ld", n_u);
     AADFF_CHECK_ARG((((uintptr_t)u_host | (uintptr_t)u_dev) & 15) == 0, "refocus_staged: u_host/u_dev must be 16-byte aligned");
@@ -974,10 +1042,12 @@ int aadff_refocus_staged(const float* depth, int S, const float* u_host, float* 
         (void)hipGetLastError();
         AADFF_CHECK_ARG(false, "refocus_staged: u_host is not pinned (device-mapped) host memory");
     }
+    constexpr int NT = 256;
     const long n4 = n_u >> 2;
-    const int copy_wgs = (int)std::min<long>(kStageWorkgroups, std::max<long>(1, (n4 + kRefocusThreads - 1) / kRefocusThreads));
-    hipLaunchKernelGGL(refocus_kernel, dim3(S + copy_wgs), dim3(kRefocusThreads), 0, (hipStream_t)stream, depth,
-                       (const float*)mapped, spp, u_stride_s, surf_green, lc, states, 1, S, (const float*)mapped, u_dev, n_u);
+    const int copy_wgs = (int)std::min<long>(kStageWorkgroups * (kRefocusThreads / NT), std::max<long>(1, (n4 + NT - 1) / NT));
+    hipLaunchKernelGGL((refocus_kernel<NT, kRefocusSplit>), dim3(S * kRefocusSplit + copy_wgs), dim3(NT), 0, (hipStream_t)stream, depth,
+                       (const float*)mapped, spp, u_stride_s, surf_green, lc, states, 1, S, (const float*)mapped, u_dev, n_u,
+                       reinterpret_cast<RefocusScratch*>(scratch));
     AADFF_CHECK_LAUNCH();
     return 0;
 }
@@ -986,8 +1056,9 @@ int aadff_post_computation(int S, const aadff_surface_t* surf_green, aadff_lens_
                            aadff_stream_t stream) {
     AADFF_CHECK_ARG(surf_green && states, "post_computation: NULL pointer");
     AADFF_CHECK_ARG(S > 0 && lc.n_surf > 0 && lc.n_surf <= AADFF_MAX_SURF, "post_computation: bad sizes S=%d", S);
-    hipLaunchKernelGGL(refocus_kernel, dim3(S), dim3(kRefocusThreads), 0, (hipStream_t)stream, (const float*)nullptr,
-                       (const float*)nullptr, 0, 0L, surf_green, lc, states, 0, S, (const float*)nullptr, (float*)nullptr, 0L);
+    hipLaunchKernelGGL((refocus_kernel<kRefocusThreads, 1>), dim3(S), dim3(kRefocusThreads), 0, (hipStream_t)stream, (const float*)nullptr,
+                       (const float*)nullptr, 0, 0L, surf_green, lc, states, 0, S, (const float*)nullptr, (float*)nullptr, 0L,
+                       (RefocusScratch*)nullptr);
     AADFF_CHECK_LAUNCH();
     return 0;
 }

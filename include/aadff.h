@@ -212,10 +212,13 @@ int aadff_refocus(const float* depth, int S, const float* u, int spp, long u_str
  * (the rest can ride on the PSF launch, aadff_psf_points_staged).
  * Saves the separate hipMemcpyAsync and its queue gap in front of a focal stack
  * (the torch.rand draws of deeplens/optics.py:480-481,1166 stay on the host, Appendix B).
- * Both pointers 16-byte aligned.  The host block may be reused once this launch completed. */
+ * Both pointers 16-byte aligned.  The host block may be reused once this launch completed.
+ * The rays of a focus state are traced by 4 workgroups; `scratch` (64 bytes per focus state,
+ * device memory, zeroed once by the caller, not shared by concurrent launches) carries their
+ * partial sums to the one that finishes the state (fixed summation order: deterministic). */
 int aadff_refocus_staged(const float* depth, int S, const float* u_host, float* u_dev, long n_u, int spp,
                          long u_stride_s, const aadff_surface_t* surf_green, aadff_lens_const_t lc,
-                         aadff_lens_state_t* states, aadff_stream_t stream);
+                         aadff_lens_state_t* states, void* scratch, aadff_stream_t stream);
 
 /* hfov/foclen/fnum for states whose d_sensor is already set (lens load, or a caller
  * that assigns d_sensor).  Replaces post_computation, deeplens/optics.py:178-187. */

@@ -398,7 +398,7 @@ def test_focal_stack_m1_equals_sequential_api(repo_root):
     for f in fds:
         lens.refocus(f)
         sl.append(rp.render_psf_map(img, lens.psf_map(depth=-1200.0, grid=5, ks=11, spp=512), 5))
-    assert (batched - torch.stack(sl, dim=2)).abs().max().item() <= 2e-6    # histogram atomics: sum order
+    assert (batched - torch.stack(sl, dim=2)).abs().max().item() <= 5e-6    # histogram atomics + refocus partial sums: sum order
 
 
 def test_focal_stack_m1_vs_oracle_full_pipeline(repo_root):
@@ -621,8 +621,10 @@ def test_staged_upload_equals_plain_copy_over_repeated_steps(repo_root, monkeypa
         assert (plan.stage_generation > 0) == staged
         outs[staged] = res
     for (a, ma), (b, mb) in zip(outs[True], outs[False]):
-        assert (ma - mb).abs().max().item() <= 2e-6            # histogram atomics: sum order
-        assert (a - b).abs().max().item() <= 2e-6
+        # histogram atomics: sum order; the staged refocus sums its rays in 4 quarters, d_sensor moves by an fp32
+        # ulp and now and then one of the 512 rays of a point flips across a validity edge (one ray = 1/400 of a PSF)
+        assert rel_l2(ma.cpu().numpy(), mb.cpu().numpy()) <= 5e-4
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5
     assert (outs[True][0][0] - outs[True][1][0]).abs().max().item() > 1e-4   # different seeds do differ
 
 
@@ -635,4 +637,4 @@ def test_staged_upload_rejects_unpinned_host_block(repo_root):
     with pytest.raises(RuntimeError, match="not pinned"):
         _abi.call("aadff_refocus_staged", _abi.ptr(dep), 1, C.c_void_p(u_host.data_ptr()), _abi.ptr(u_dev), 2 * GEO_SPP,
                   GEO_SPP, 2 * GEO_SPP, _abi.ptr(lens._table([0.589])), lens._lens_const(), _abi.ptr(states),
-                  _abi.stream_ptr(torch.device(DEV)))
+                  _abi.ptr(torch.zeros(16, dtype=torch.int32, device=DEV)), _abi.stream_ptr(torch.device(DEV)))
