@@ -1,0 +1,77 @@
+"""Pack an MLP (list of nn.Linear) for the fused PSF-network kernel (csrc/psfnet.hip, aadff_psfnet_forward):
+weights as exact fp16 (hi, lo) pairs in MFMA A-fragment order, biases padded to 16."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+
+MAX_WIDTH, MAX_OUT = 256, 128
+
+
+def linears_of(mlp):
+    """The nn.Linear layers of deeplens.psfnet_arch.MLP in order (Linear+ReLU ..., Linear+Sigmoid)."""
+    return [m for m in mlp.net if isinstance(m, torch.nn.Linear)]
+
+
+def supported(mlp):
+    lin = linears_of(mlp)
+    mods = list(mlp.net)
+    ok_acts = all(isinstance(mods[2 * i + 1], torch.nn.ReLU) for i in range(len(lin) - 1)) and isinstance(mods[-1], torch.nn.Sigmoid)
+    return (ok_acts and len(mods) == 2 * len(lin) and 1 <= len(lin) <= 16 and lin[0].in_features == 4
+            and all(l.in_features <= MAX_WIDTH and l.out_features <= MAX_WIDTH for l in lin) and lin[-1].out_features <= MAX_OUT)
+
+
+class PackedMLP:
+    """Device buffers for aadff_psfnet_forward; rebuilt when a parameter changes (version counters)."""
+
+    def __init__(self, mlp, device):
+        lin = linears_of(mlp)
+        self.key = tuple((p.data_ptr(), p._version) for l in lin for p in (l.weight, l.bias))
+        self.n = len(lin)
+        self.ins = (C.c_int * self.n)(*[l.in_features for l in lin])
+        self.outs = (C.c_int * self.n)(*[l.out_features for l in lin])
+        self.n_out = lin[-1].out_features
+        planes, biases = [], []
+        for l in lin:
+            w = l.weight.detach().to(device=device, dtype=torch.float32)          # [out, in]
+            n, k = w.shape
+            npad, kpad = (n + 15) // 16 * 16, (k + 31) // 32 * 32
+            wp = torch.zeros((npad, kpad), dtype=torch.float32, device=device)
+            wp[:n, :k] = w
+            hi = wp.half()
+            lo = (wp - hi.float()).half()
+            # [tile, m, step, kg, e] -> [tile, step, plane, lane = kg*16 + m, e]
+            f = torch.stack((hi, lo), 0).reshape(2, npad // 16, 16, kpad // 32, 4, 8).permute(1, 3, 0, 4, 2, 5)
+            planes.append(f.contiguous().reshape(-1))
+            b = torch.zeros(npad, dtype=torch.float32, device=device)
+            if l.bias is not None:
+                b[:n] = l.bias.detach().to(device=device, dtype=torch.float32)
+            biases.append(b)
+        self.wpack = torch.cat(planes).contiguous()
+        self.bias = torch.cat(biases).contiguous()
+
+    @staticmethod
+    def key_of(mlp):
+        return tuple((p.data_ptr(), p._version) for l in linears_of(mlp) for p in (l.weight, l.bias))
+
+
+def forward(packed, inp, mode, img=None, ks=0):
+    """mode 0: [P,4] -> [P,n_out] normalised PSFs; mode 1: img [N,C,H,W] + inp [N*H*W,4] -> [N,C,H,W]."""
+    dev = inp.device
+    inp = _abi.f32c(inp, dev).reshape(-1, 4)
+    P = inp.shape[0]
+    st = _abi.stream_ptr(dev)
+    with torch.cuda.device(dev):
+        if mode == 0:
+            out = torch.empty((P, packed.n_out), dtype=torch.float32, device=dev)
+            _abi.call("aadff_psfnet_forward", _abi.ptr(inp), P, _abi.ptr(packed.wpack), _abi.ptr(packed.bias), packed.n,
+                      packed.ins, packed.outs, 0, _abi.ptr(out), None, None, 0, 0, 0, 0, st)
+            return out
+        x = _abi.f32c(img, dev)
+        N, Cc, H, W = x.shape
+        out = torch.empty_like(x)
+        _abi.call("aadff_psfnet_forward", _abi.ptr(inp), P, _abi.ptr(packed.wpack), _abi.ptr(packed.bias), packed.n,
+                  packed.ins, packed.outs, 1, None, _abi.ptr(x), _abi.ptr(out), Cc, H, W, ks, st)
+        return out

@@ -40,10 +40,14 @@ class PSFNet(Lensgroup):
         self.foc_d_arr = np.array([-500, -600, -700, -800, -900, -1000, -1250, -1500, -1750, -2000,
                                    -2500, -3000, -4000, -5000, -6000, -8000, -10000, -12000, -15000, -20000])
         self.foc_z_arr = (self.foc_d_arr - self.d_min) / (self.d_max - self.d_min)
-        # "fp32" (default): MLP in fp32, rendered image within 1e-4 rel-L2 of the reference.
+        # "fp32" (default): inference runs the fused HIP kernel (csrc/psfnet.hip: the whole MLP + sigmoid +
+        #   L1-normalise + per-pixel gather in one launch, fp32 operands carried as exact fp16 hi/lo pairs on
+        #   MFMA with fp32 accumulation); rendered image within 1e-4 rel-L2 of the reference.
+        # "torch": the same in stock torch fp32 ops + the HIP gather (what training always uses).
         # "bf16": MLP GEMMs on bf16 MFMA under autocast (sigmoid / L1-normalise / gather stay fp32); the
-        # surrogate PSFs then differ by ~1e-3, far below the MLP's own fit error - opt-in, for throughput.
+        #   surrogate PSFs then differ by ~1e-3, far below the MLP's own fit error - opt-in.
         self.mlp_precision = "fp32"
+        self._packed = None
 
     # ------------------------------------------------------------------ network
     def init_net(self):
@@ -59,7 +63,22 @@ class PSFNet(Lensgroup):
         map_location added so CUDA-saved files load anywhere)."""
         self.psfnet.load_state_dict(torch.load(net_path, map_location=self.device))
 
+    def _fused(self, dev):
+        """PackedMLP for the fused kernel, or None when it does not apply (CPU, autograd, other modes/shapes)."""
+        from aadff import psfnet_pack
+        if self.mlp_precision != "fp32" or torch.device(dev).type != "cuda" or not psfnet_pack.supported(self.psfnet):
+            return None
+        if self._packed is None or self._packed.key != psfnet_pack.PackedMLP.key_of(self.psfnet) or self._packed.wpack.device != torch.device(dev):
+            self._packed = psfnet_pack.PackedMLP(self.psfnet, torch.device(dev))
+        return self._packed
+
     def pred(self, inp):
+        if not torch.is_grad_enabled() and inp.is_cuda:
+            packed = self._fused(inp.device)
+            if packed is not None:
+                from aadff import psfnet_pack
+                psf = psfnet_pack.forward(packed, inp.reshape(-1, inp.shape[-1]), 0)
+                return psf.reshape(*inp.shape[:-1], self.kernel_size, self.kernel_size)
         psf = self.psfnet(inp)
         return psf.reshape(*psf.shape[:-1], self.kernel_size, self.kernel_size)
 
@@ -95,6 +114,13 @@ class PSFNet(Lensgroup):
             o = torch.stack((x, y, z, foc_z), -1).float()
         else:
             raise ValueError("img should be [C,H,W] or [N,C,H,W]")
+        packed = self._fused(dev)
+        if packed is not None:
+            from aadff import psfnet_pack
+            x = img if len(img.shape) == 4 else img.unsqueeze(0)
+            out = psfnet_pack.forward(packed, o.reshape(-1, 4), 1, img=x.to(dev), ks=self.kernel_size)
+            out = out if len(img.shape) == 4 else out.squeeze(0)
+            return out.to(img.device)
         psf = self._pred_chunked(o)
         return local_psf_render(img, psf, self.kernel_size)
 

@@ -434,6 +434,44 @@ def test_mlp_golden(g67, psfnet64):
     assert rel_l2(y.cpu().numpy(), g67["mlp_out"]) <= 1e-5
 
 
+def test_fused_mlp_pred_golden_and_vs_torch(g67, psfnet64):
+    """aadff_psfnet_forward mode 0 (the whole MLP in one HIP kernel, fp16 hi/lo MFMA) against the reference's
+    MLP outputs (G6) and against torch fp32 on sizes that are not multiples of the 128-pixel tile."""
+    assert psfnet64.mlp_precision == "fp32" and psfnet64._fused(DEV) is not None
+    with torch.no_grad():
+        y = psfnet64.pred(tt(g67["mlp_in"]).to(DEV))
+    assert y.shape == (g67["mlp_in"].shape[0], 11, 11)
+    assert rel_l2(y.reshape(y.shape[0], -1).cpu().numpy(), g67["mlp_out"]) <= 1e-5
+    rng = np.random.Generator(np.random.PCG64(77))
+    for n in (1, 127, 129, 1000):
+        x = tt(rng.random((n, 4), dtype=np.float32)).to(DEV)
+        x[:, :2] = x[:, :2] * 2 - 1
+        with torch.no_grad():
+            a = psfnet64.pred(x).reshape(n, -1)
+            b = psfnet64.psfnet(x)
+        assert (a - b).abs().max().item() <= 2e-7 and rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 2e-6, n
+        assert a.sum(-1).cpu().numpy() == pytest.approx(1.0, abs=1e-5)
+    with torch.enable_grad():                                   # training keeps the autograd path
+        x = tt(rng.random((8, 4), dtype=np.float32)).to(DEV)
+        assert psfnet64.pred(x).requires_grad
+
+
+def test_fused_render_equals_torch_mlp_plus_gather(psfnet64):
+    """mode 1 (MLP + gather fused) == torch MLP + aadff_local_psf_render, incl. a ragged last tile and B = 2."""
+    rng = np.random.Generator(np.random.PCG64(78))
+    img = tt(rng.random((2, 3, 50, 37), dtype=np.float32)).to(DEV)
+    depth = -tt(rng.random((2, 1, 50, 37), dtype=np.float32) * 4000 + 300).to(DEV)
+    fd = torch.tensor([-800.0, -2500.0], device=DEV)
+    net = PSFNet.__new__(PSFNet)
+    net.__dict__.update(psfnet64.__dict__)
+    net.sensor_res, net._packed = (50, 37), None
+    fused = net.render(img, depth, fd)
+    net.mlp_precision = "torch"
+    ref = net.render(img, depth, fd)
+    assert fused.shape == ref.shape == img.shape
+    assert rel_l2(fused.cpu().numpy(), ref.cpu().numpy()) <= 2e-6
+
+
 def test_psfnet_render_golden(g67, psfnet64):
     img = tt(synth_rgb(64, 64, seed=11))[None].to(DEV)
     depth = -tt(synth_depth_mm(64, 64, seed=12))[None, None].to(DEV)
