@@ -5,22 +5,23 @@
 // replicate padding, no flip).  1.14 MFLOP per pixel against 28 bytes of HBM traffic: the activations never leave
 // the CU (the unfused path writes and re-reads 484 B/pixel of PSFs plus every layer's activations).
 //
-// Workgroup = 128 pixels x 8 waves.  Activations live in LDS as two fp16 planes (hi, lo) [128][264]; every layer is
+// Workgroup = 128 pixels x 8 waves.  Activations live in LDS as two fp16 planes (hi, lo) [128][256]; every layer is
 // the GEMM  out^T[feat][px] = sum_k W[feat][k] act[px][k]  on v_mfma_f32_16x16x32_f16 with the exact fp16 hi/lo
 // operand split of conv.hip (hi*hi + hi*lo + lo*hi, fp32 accumulate: every product exact, dropped term 2^-22).
 // A operand = weights, pre-packed by the host in fragment order (16 B per lane, streamed from L2, one k-step ahead);
-// B operand = activations (ds_read_b128, row pitch 264 halves: conflict-free); D^T puts 4 consecutive features of
+// B operand = activations (ds_read_b128, 16-byte slots XOR-swizzled by the pixel: conflict-free); D^T puts 4 consecutive features of
 // one pixel in a lane, so bias + ReLU + split + one 8-byte LDS store per plane write the next layer's input.
 // Wave w owns feature tiles w, w + 8 (16 features each) for all 128 pixels: 64 accumulator registers.
 #include <cmath>
+#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace aadff {
 namespace pn {
 
-constexpr int TP = 128;                 // pixels per workgroup
 constexpr int NWV = 8, NTH = 64 * NWV;
-constexpr int AP = 264;                 // activation row pitch in halves (256 + 8: ds_read_b128 conflict-free)
+constexpr int AP = 256;                 // activation row pitch in halves; 16-byte slots XOR-swizzled by the pixel (swz)
 constexpr int MAXL = AADFF_PSFNET_MAX_LAYERS;
 
 typedef _Float16 half8v __attribute__((ext_vector_type(8)));
@@ -36,16 +37,33 @@ struct Layers {
     int boff[MAXL];                     // offset of the layer's (padded) bias, in floats
 };
 
+// LDS offset (halves) of feature `f` of pixel `px`: the 16-byte slot index is XORed with px & 15.  The MFMA B-fragment
+// read (lane = pixel px & 15, k-group kg: slot 4 s + kg) then touches every bank once per ds_read_b128 lane group
+// (unswizzled with a padded pitch it is 2-way: SQ_LDS_BANK_CONFLICT was 49 % of the LDS cycles), and the write-back
+// (lane = pixel, 4 features = half a slot) is 2-way instead of 4-way.
+__device__ __forceinline__ int swz(int px, int f) { return px * AP + ((((f >> 3) ^ px) & 15) << 3 | (f & ~127) | (f & 7)); }
+
+// x = hi + lo with hi = fp16(x) (RNE) and lo = fp16(x - hi): v_cvt_pk_f16_f32 for two hi halves, then one
+// v_fma_mix{lo,hi}_f16 per lo half (fp16 hi * -1 + fp32 x, rounded once to fp16) -- the compiler emits convert-back,
+// subtract and convert instead (20 instead of 10 VALU per four values of the layer write-back).
 __device__ __forceinline__ void split4(float4v v, half4v& h, half4v& l) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        h[i] = (_Float16)v[i];
-        l[i] = (_Float16)(v[i] - (float)h[i]);
-    }
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    const half2v h01 = {(_Float16)v[0], (_Float16)v[1]}, h23 = {(_Float16)v[2], (_Float16)v[3]};
+    unsigned l01, l23;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(l01) : "v"(__builtin_bit_cast(unsigned, h01)), "v"(v[0]), "v"(v[1]));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(l23) : "v"(__builtin_bit_cast(unsigned, h23)), "v"(v[2]), "v"(v[3]));
+    const half2v q01 = __builtin_bit_cast(half2v, l01), q23 = __builtin_bit_cast(half2v, l23);
+    h = (half4v){h01[0], h01[1], h23[0], h23[1]};
+    l = (half4v){q01[0], q01[1], q23[0], q23[1]};
 }
 
 // mode 0: psf_out[P][nout] (normalised PSFs); mode 1: out[N][C][H][W] = per-pixel PSF gather over img
-__global__ __launch_bounds__(NTH) void psfnet_fused_kernel(const float* __restrict__ inp, long P, const uint4v* __restrict__ wpack,
+// TP = pixels per workgroup (128: one workgroup per CU; 64: two, which overlap each other's write-back phases at
+// twice the weight traffic from L2)
+template <int TP>
+__global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(const float* __restrict__ inp, long P, const uint4v* __restrict__ wpack,
                                                            const float* __restrict__ bias, Layers L, int nout, int mode,
                                                            float* __restrict__ psf_out, const float* __restrict__ img,
                                                            float* __restrict__ out, int C, int H, int W, int ks) {
@@ -62,52 +80,66 @@ __global__ __launch_bounds__(NTH) void psfnet_fused_kernel(const float* __restri
         if (g4 == 0 && p0 + px < P) v = *reinterpret_cast<const float4v*>(inp + (p0 + px) * 4);
         half4v h, l;
         split4(v, h, l);
-        *reinterpret_cast<half4v*>(&act[0][px * AP + 4 * g4]) = h;
-        *reinterpret_cast<half4v*>(&act[1][px * AP + 4 * g4]) = l;
+        *reinterpret_cast<half4v*>(&act[0][swz(px, 4 * g4)]) = h;
+        *reinterpret_cast<half4v*>(&act[1][swz(px, 4 * g4)]) = l;
     }
     __syncthreads();
 
-    float4v acc[2][8];
+    constexpr int NPT = TP / 16;                                                // pixel tiles
+    float4v acc[2][NPT];
 #pragma unroll 1
     for (int l = 0; l < L.n; ++l) {
         const int nks = L.kpad[l] >> 5, ntile = L.npad[l] >> 4;
         const bool t0 = wave < ntile, t1 = wave + NWV < ntile;                  // this wave's feature tiles: wave, wave + 8
         const bool last = l == L.n - 1;
-        if (t0) {
+        // accumulators start from the bias: D^T rows 4 kg + i of tile t are features 16 t + 4 kg + i
+        auto kloop = [&](auto ntc) {
+            constexpr int NTL = decltype(ntc)::value;                           // feature tiles of this wave in this layer: 1 or 2
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NTL; ++j) {
+                const float4v b = *reinterpret_cast<const float4v*>(bias + L.boff[l] + 16 * (wave + NWV * j) + 4 * kg);
 #pragma unroll
-                for (int p = 0; p < 8; ++p) acc[j][p] = (float4v){0.f, 0.f, 0.f, 0.f};
-            // packed weights: [tile][k-step][plane][lane] x 16 B
-            const uint4v* w0 = wpack + L.woff[l] + ((size_t)wave * nks * 2) * 64 + lane;
-            const uint4v* w1 = wpack + L.woff[l] + ((size_t)(wave + NWV) * nks * 2) * 64 + lane;
-            uint4v a0h = w0[0], a0l = w0[64], a1h = a0h, a1l = a0l;
-            if (t1) { a1h = w1[0]; a1l = w1[64]; }
+                for (int p = 0; p < NPT; ++p) acc[j][p] = b;
+            }
+            // packed weights: [tile][k-step][plane][lane] x 16 B, streamed from L2 two k-steps ahead
+            const uint4v* wq[2];
+            uint4v ah[2], al[2], nh[2], nl[2];
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                wq[j] = wpack + L.woff[l] + ((size_t)(wave + NWV * j) * nks * 2) * 64 + lane;
+                ah[j] = wq[j][0]; al[j] = wq[j][64];
+                const int s1 = nks > 1 ? 1 : 0;
+                nh[j] = wq[j][s1 * 128]; nl[j] = wq[j][s1 * 128 + 64];
+            }
 #pragma unroll 1
             for (int s = 0; s < nks; ++s) {
-                const uint4v c0h = a0h, c0l = a0l, c1h = a1h, c1l = a1l;
-                if (s + 1 < nks) {                                               // next k-step's weights (L2 latency)
-                    a0h = w0[(s + 1) * 128]; a0l = w0[(s + 1) * 128 + 64];
-                    if (t1) { a1h = w1[(s + 1) * 128]; a1l = w1[(s + 1) * 128 + 64]; }
-                }
-                const half8v th0 = __builtin_bit_cast(half8v, c0h), tl0 = __builtin_bit_cast(half8v, c0l);
-                const half8v th1 = __builtin_bit_cast(half8v, c1h), tl1 = __builtin_bit_cast(half8v, c1l);
-                const int boffs = lo4 * AP + 32 * s + 8 * kg;
+                half8v th[2], tl[2];
 #pragma unroll
-                for (int p = 0; p < 8; ++p) {
+                for (int j = 0; j < NTL; ++j) {
+                    th[j] = __builtin_bit_cast(half8v, ah[j]); tl[j] = __builtin_bit_cast(half8v, al[j]);
+                    ah[j] = nh[j]; al[j] = nl[j];
+                }
+                {
+                    const int s2 = s + 2 < nks ? s + 2 : nks - 1;              // clamped: the tail re-reads the last step
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) { nh[j] = wq[j][s2 * 128]; nl[j] = wq[j][s2 * 128 + 64]; }
+                }
+                const int boffs = swz(lo4, 32 * s + 8 * kg);                    // (16 p + lo4) & 15 == lo4
+#pragma unroll
+                for (int p = 0; p < NPT; ++p) {
                     const half8v bh = *reinterpret_cast<const half8v*>(&act[0][16 * p * AP + boffs]);
                     const half8v bl = *reinterpret_cast<const half8v*>(&act[1][16 * p * AP + boffs]);
-                    acc[0][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th0, bh, acc[0][p], 0, 0, 0);
-                    acc[0][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th0, bl, acc[0][p], 0, 0, 0);
-                    acc[0][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl0, bh, acc[0][p], 0, 0, 0);
-                    if (t1) {
-                        acc[1][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th1, bh, acc[1][p], 0, 0, 0);
-                        acc[1][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th1, bl, acc[1][p], 0, 0, 0);
-                        acc[1][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl1, bh, acc[1][p], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) {
+                        acc[j][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th[j], bh, acc[j][p], 0, 0, 0);
+                        acc[j][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th[j], bl, acc[j][p], 0, 0, 0);
+                        acc[j][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl[j], bh, acc[j][p], 0, 0, 0);
                     }
                 }
             }
-        }
+        };
+        if (t1) kloop(std::integral_constant<int, 2>{});
+        else if (t0) kloop(std::integral_constant<int, 1>{});
         __syncthreads();                                                        // every wave is done reading this layer's input
         if (!last) {
             // D^T[feat = 16 tile + 4 kg + i][px = 16 p + lo4]: bias, ReLU, split, 8-byte stores
@@ -116,15 +148,14 @@ __global__ __launch_bounds__(NTH) void psfnet_fused_kernel(const float* __restri
                 for (int j = 0; j < 2; ++j) {
                     if (j == 1 && !t1) break;
                     const int f0 = 16 * (wave + NWV * j) + 4 * kg;
-                    const float4v b = *reinterpret_cast<const float4v*>(bias + L.boff[l] + f0);
 #pragma unroll
-                    for (int p = 0; p < 8; ++p) {
-                        float4v v = acc[j][p] + b;
+                    for (int p = 0; p < NPT; ++p) {
+                        float4v v = acc[j][p];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
                         half4v h, lo;
                         split4(v, h, lo);
-                        const int o = (16 * p + lo4) * AP + f0;
+                        const int o = swz(16 * p + lo4, f0);
                         *reinterpret_cast<half4v*>(&act[0][o]) = h;
                         *reinterpret_cast<half4v*>(&act[1][o]) = lo;
                     }
@@ -136,8 +167,8 @@ __global__ __launch_bounds__(NTH) void psfnet_fused_kernel(const float* __restri
                 const int gw = (kn - nn) >> 2;
                 for (int e = tid; e < TP * gw; e += NTH) {
                     const int px = e / gw, g4 = e - px * gw;
-                    *reinterpret_cast<half4v*>(&act[0][px * AP + nn + 4 * g4]) = (half4v){0, 0, 0, 0};
-                    *reinterpret_cast<half4v*>(&act[1][px * AP + nn + 4 * g4]) = (half4v){0, 0, 0, 0};
+                    *reinterpret_cast<half4v*>(&act[0][swz(px, nn + 4 * g4)]) = (half4v){0, 0, 0, 0};
+                    *reinterpret_cast<half4v*>(&act[1][swz(px, nn + 4 * g4)]) = (half4v){0, 0, 0, 0};
                 }
             }
         } else {
@@ -149,10 +180,9 @@ __global__ __launch_bounds__(NTH) void psfnet_fused_kernel(const float* __restri
                 for (int j = 0; j < 2; ++j) {
                     if (j == 1 && !t1) break;
                     const int f0 = 16 * (wave + NWV * j) + 4 * kg;
-                    const float4v b = *reinterpret_cast<const float4v*>(bias + L.boff[l] + f0);
 #pragma unroll
-                    for (int p = 0; p < 8; ++p) {
-                        float4v v = acc[j][p] + b;
+                    for (int p = 0; p < NPT; ++p) {
+                        float4v v = acc[j][p];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = 1.f / (1.f + expf(-v[i]));
                         *reinterpret_cast<float4v*>(&psf[(16 * p + lo4) * PP + f0]) = v;
@@ -167,34 +197,42 @@ __global__ __launch_bounds__(NTH) void psfnet_fused_kernel(const float* __restri
     {
         const float* psf = reinterpret_cast<const float*>(&act[0][0]);
         constexpr int PP = 132;
-        const int px = tid >> 2, q = tid & 3;
+        constexpr int TPP = NTH / TP;                                           // threads per pixel: 4 or 8
+        const int px = tid / TPP, q = tid % TPP;
         const long gp = p0 + px;
         const float* row = psf + px * PP;
         float sum = 0.f;
-        for (int t = q; t < nout; t += 4) sum += row[t];
-        sum += __shfl_xor(sum, 1, kWave);
-        sum += __shfl_xor(sum, 2, kWave);
+        for (int t = q; t < nout; t += TPP) sum += row[t];
+#pragma unroll
+        for (int m = 1; m < TPP; m <<= 1) sum += __shfl_xor(sum, m, kWave);
         const float inv = 1.f / fmaxf(sum, 1e-12f);
         if (gp < P) {
             if (mode == 0) {
                 float* o = psf_out + gp * nout;
-                for (int t = q; t < nout; t += 4) o[t] = row[t] * inv;
+                for (int t = q; t < nout; t += TPP) o[t] = row[t] * inv;
             } else {
                 const long hw = (long)H * W;
                 const long nimg = gp / hw;
                 const int rem = (int)(gp - nimg * hw);
                 const int y = rem / W, x = rem - y * W;
                 const int pad = ks >> 1;
+                // thread q of the pixel takes tap columns q, q + TPP, ... of every tap row: clamped columns once
+                constexpr int MAXV = (11 + TPP - 1) / TPP;                      // ks <= 11 (n_out <= 128)
+                int xv[MAXV];
+#pragma unroll
+                for (int k = 0; k < MAXV; ++k) xv[k] = min(max(x + q + k * TPP - pad, 0), W - 1);
                 for (int c = 0; c < C; ++c) {
                     const float* plane = img + (nimg * C + c) * hw;
                     float a = 0.f;
-                    for (int t = q; t < nout; t += 4) {
-                        const int u = t / ks, v = t - u * ks;
-                        const int yy = min(max(y + u - pad, 0), H - 1), xx = min(max(x + v - pad, 0), W - 1);
-                        a = fmaf(row[t], plane[(size_t)yy * W + xx], a);
+                    for (int u = 0; u < ks; ++u) {
+                        const float* ir = plane + (size_t)min(max(y + u - pad, 0), H - 1) * W;
+                        const float* pr = row + u * ks;
+#pragma unroll
+                        for (int k = 0; k < MAXV; ++k)
+                            if (q + k * TPP < ks) a = fmaf(pr[q + k * TPP], ir[xv[k]], a);
                     }
-                    a += __shfl_xor(a, 1, kWave);
-                    a += __shfl_xor(a, 2, kWave);
+#pragma unroll
+                    for (int m = 1; m < TPP; m <<= 1) a += __shfl_xor(a, m, kWave);
                     if (q == 0) out[(nimg * C + c) * hw + rem] = a * inv;
                 }
             }
@@ -236,10 +274,16 @@ int aadff_psfnet_forward(const float* inp, long P, const void* wpack, const floa
     AADFF_CHECK_ARG(mode == 0 || ks * ks == nout, "psfnet_forward: ks %d does not match %d outputs", ks, nout);
     if (P == 0) return 0;
     AADFF_CHECK_ARG(mode == 0 || P % ((long)H * W) == 0, "psfnet_forward: P is not a whole number of images");
-    const long nwg = (P + pn::TP - 1) / pn::TP;
+    int tp = 64;                       // measured at 1024^2: 64 -> 3.09 ms, 128 -> 3.46 ms
+    if (const char* e = getenv("AADFF_PSFNET_TP")) tp = atoi(e) == 128 ? 128 : 64;
+    const long nwg = (P + tp - 1) / tp;
     AADFF_CHECK_ARG(nwg < (1L << 31), "psfnet_forward: too many pixels");
-    hipLaunchKernelGGL(pn::psfnet_fused_kernel, dim3((unsigned)nwg), dim3(pn::NTH), 0, (hipStream_t)stream, inp, P,
-                       reinterpret_cast<const pn::uint4v*>(wpack), bias, L, nout, mode, psf_out, img, out, C, H, W, ks);
+    if (tp == 128)
+        hipLaunchKernelGGL(pn::psfnet_fused_kernel<128>, dim3((unsigned)nwg), dim3(pn::NTH), 0, (hipStream_t)stream, inp, P,
+                           reinterpret_cast<const pn::uint4v*>(wpack), bias, L, nout, mode, psf_out, img, out, C, H, W, ks);
+    else
+        hipLaunchKernelGGL(pn::psfnet_fused_kernel<64>, dim3((unsigned)nwg), dim3(pn::NTH), 0, (hipStream_t)stream, inp, P,
+                           reinterpret_cast<const pn::uint4v*>(wpack), bias, L, nout, mode, psf_out, img, out, C, H, W, ks);
     AADFF_CHECK_LAUNCH();
     return 0;
 }
