@@ -8,6 +8,7 @@ import torch
 from . import _abi
 
 MAX_WIDTH, MAX_OUT = 256, 128
+EVENT_HOOK = None      # optional callable(start: bool) recording a torch.cuda.Event around the kernel launch (bench.py)
 
 
 def linears_of(mlp):
@@ -72,6 +73,10 @@ def forward(packed, inp, mode, img=None, ks=0):
         x = _abi.f32c(img, dev)
         N, Cc, H, W = x.shape
         out = torch.empty_like(x)
+        if EVENT_HOOK is not None:
+            EVENT_HOOK(True)
         _abi.call("aadff_psfnet_forward", _abi.ptr(inp), P, _abi.ptr(packed.wpack), _abi.ptr(packed.bias), packed.n,
                   packed.ins, packed.outs, 1, None, _abi.ptr(x), _abi.ptr(out), Cc, H, W, ks, st)
+        if EVENT_HOOK is not None:
+            EVENT_HOOK(False)
         return out

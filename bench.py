@@ -76,7 +76,12 @@ def main():
     ap.add_argument("--gather", action="store_true", help="all-gather the rendered stacks over RCCL (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--device-rng", action="store_true", help="draw pupil samples on the GPU (not sample-comparable)")
+    ap.add_argument("--mode", choices=("m1", "m2"), default="m1",
+                    help="m1 (default, BASELINE.json metric): ray-traced PSF grid + patch convolution; "
+                         "m2: RGB-D stack through the PSF surrogate network (PSFNet.render, SURVEY.md 8f-1)")
     args = ap.parse_args()
+    if args.mode == "m2":
+        return main_m2(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,6 +180,73 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(lens_path, img_h, dbar, fds)
         print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main_m2(args):
+    """M2: [1,3,1024,1024] RGB + depth map -> 10 slices by PSFNet.render (fused MLP + gather kernel), random-init
+    weights of the reference architecture (4 -> 64 -> 256 -> 8x256 -> 121).  Not the BASELINE.json metric."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    from aadff import psfnet_pack
+    from aadff.dist import init_from_env
+    from aadff.focal_stack import render_focal_stack_m2
+    from aadff.synth import mlp_state_dict, synth_depth_mm, synth_rgb
+    from deeplens.psfnet import PSFNet
+    init_from_env(backend="nccl", device=dev)
+    net = PSFNet(os.path.join(REPO, "lenses", "rf50mm", "lens.json"), sensor_res=(H, W), kernel_size=KS, device=dev)
+    net.psfnet.load_state_dict({k: torch.from_numpy(v) for k, v in mlp_state_dict(seed=4321).items()})
+    img = torch.from_numpy(synth_rgb(H, W, seed=1234 + rank))[None].to(dev)
+    depth_m = (torch.from_numpy(synth_depth_mm(H, W, seed=5678 + rank))[None, None] / 1e3).to(dev)
+    steps = min(args.steps, 20) if args.steps == 200 else args.steps        # a step is ~31 ms
+    warm = min(args.warmup, 3)
+    evs = []
+
+    def hook(start):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        evs.append(e)
+
+    for _ in range(warm):
+        render_focal_stack_m2(net, img, depth_m, S)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    psfnet_pack.EVENT_HOOK = hook
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        render_focal_stack_m2(net, img, depth_m, S)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    psfnet_pack.EVENT_HOOK = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kms = float(np.mean([evs[i].elapsed_time(evs[i + 1]) for i in range(0, len(evs), 2)]))
+    flop_px = 2 * (4 * 64 + 64 * 256 + 8 * 256 * 256 + 256 * KS * KS)       # fp32-equivalent flops per pixel
+    issued = 3 * flop_px * H * W / (kms * 1e-3) / 1e12                      # fp16 MFMA flops of the hi/lo split
+    if rank == 0:
+        print(json.dumps({
+            "metric": "focal-stack MP/s (M2: RGB-D through PSFNet.render, 1024^2 x 10 slices)",
+            "value": round(world * S * H * W / 1e6 * steps / dt, 2), "unit": "MP/s", "n_gpus": world, "steps": steps,
+            "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "1024x1024 synthetic RGB + depth map, 10 focus distances (linear rule), PSFNet MLP "
+                                   "4-64-256-8x256-121 with random-init weights, per-pixel 11x11 gather",
+                       "arithmetic": "fp32 operands as exact fp16 hi/lo pairs on MFMA, fp32 accumulate (2e-7 from torch fp32)"},
+            "roofline": {"kernel": "psfnet_fused_kernel<64> (one launch per slice)", "bound": "mfma", "achieved": round(issued, 1),
+                         "peak": 2500.0, "unit": "TFLOP/s", "frac": round(issued / 2500.0, 4), "traffic": None,
+                         "kernel_ms": round(kms, 4), "fp32_equivalent_tflops": round(issued / 3, 1)}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
