@@ -322,7 +322,7 @@ __device__ __forceinline__ i2 valid_loose2(const aadff_surface_t& s, f2 r2) {
     return s.k_gt_m1 ? (r2 < s.r2_shape) : (r2 > 0.f);
 }
 template <bool STRICT>
-__device__ __forceinline__ f2 newton_step2(const aadff_surface_t& s, const Ray2& r, f2 dxy2, f2 od, f2& t) {
+__device__ __forceinline__ f2 newton_step2(const aadff_surface_t& s, const Ray2& r, f2 dxy2, f2 od, f2& t, f2* slope_out = nullptr) {
     const f2 px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t;
     f2 r2 = px * px + py * py;
     const i2 m = STRICT ? valid_strict2(s, r2) : valid_loose2(s, r2);
@@ -335,19 +335,26 @@ __device__ __forceinline__ f2 newton_step2(const aadff_surface_t& s, const Ray2&
     f2 step = ft * vrcp(dfdt + kEps);
     step = vmin(vmax(step, f2s(-kStepBound)), f2s(kStepBound));
     t -= step;
+    if (slope_out) *slope_out = slope;
     return ft;
 }
+template <bool SPHERE = false>                                  // SPHERE: kind SPHERIC implies k == 0 (Aspheric.kind())
 __device__ __forceinline__ i2 conic_root2(const aadff_surface_t& s, const Ray2& r, f2 t0, f2& p0x, f2& p0y, f2& tau) {
     p0x = r.ox + r.dx * t0; p0y = r.oy + r.dy * t0;
     const f2 rho2 = p0x * p0x + p0y * p0y;
     const f2 beta = s.c * (p0x * r.dx + p0y * r.dy) - r.dz;
-    const f2 A = s.c * (1.f + s.k * r.dz * r.dz);
+    const f2 A = SPHERE ? f2s(s.c) : s.c * (1.f + s.k * r.dz * r.dz);
     const f2 disc = beta * beta - A * (s.c * rho2);
     const f2 root = vsqrt(vmax(disc, f2s(0.f)));
     tau = (s.c * rho2) * vrcp(vsel(beta < 0.f, root - beta, -(root + beta)));
     return disc >= 0.f;
 }
-__device__ __forceinline__ void newton2(const aadff_surface_t& s, const Ray2& r, i2 alive, f2& t_out, i2& valid_out, int& nan_flag) {
+// slope_out: d sag / d r^2 of the last (strict) step, i.e. one converged Newton update (<= 5e-5 mm, typically 1e-7)
+// before the hit point; the fused kernels reuse it for the surface normal instead of evaluating the asphere again
+// (relative change of the slope over that update <= 2e-6: below the fp32 noise of the trace; -DAADFF_NORMAL_REEVAL
+// restores the literal evaluation at the hit point, surfaces.py:589-630).
+__device__ __forceinline__ void newton2(const aadff_surface_t& s, const Ray2& r, i2 alive, f2& t_out, i2& valid_out, int& nan_flag,
+                                        f2* slope_out = nullptr) {
     const f2 dxy2 = r.dx * r.dx + r.dy * r.dy;
     const f2 od = r.dx * r.ox + r.dy * r.oy;
     const f2 t0 = (s.d - r.oz) * vrcp(r.dz);
@@ -367,24 +374,13 @@ __device__ __forceinline__ void newton2(const aadff_surface_t& s, const Ray2& r,
     }
     const f2 t1 = t - t0;
     t = t0 + t1;
-    ft = newton_step2<true>(s, r, dxy2, od, t);
+    ft = newton_step2<true>(s, r, dxy2, od, t, slope_out);
     const f2 px = r.ox + r.dx * t, py = r.oy + r.dy * t;
     valid_out = valid_strict2(s, px * px + py * py) & (vabs(ft) < kTolTight) & (t > 0.f);
     t_out = t;
 }
-__device__ __forceinline__ i2 refract2(const aadff_surface_t& s, Ray2& r, bool forward) {
-    f2 nx, ny, nz;
-    if (s.kind == AADFF_SURF_STOP) {
-        nx = f2s(0.f); ny = f2s(0.f); nz = f2s(-1.f);
-    } else if (s.kind == AADFF_SURF_SPHERIC) {
-        nx = s.c * r.ox; ny = s.c * r.oy; nz = s.c * (r.oz - s.d) - 1.f;
-    } else {
-        f2 sag, g;
-        sag_and_slope2(s, r.ox * r.ox + r.oy * r.oy, sag, g);
-        nx = g * 2.f * r.ox; ny = g * 2.f * r.oy;
-        const f2 inv = vrsq(vmax(nx * nx + ny * ny + 1.f, f2s(1e-24f)));
-        nx *= inv; ny *= inv; nz = -inv;
-    }
+// vector Snell refraction at a surface with unit normal (nx, ny, nz) (surfaces.py:633-679)
+__device__ __forceinline__ i2 refract_dir2(const aadff_surface_t& s, Ray2& r, bool forward, f2 nx, f2 ny, f2 nz) {
     const float sgn = forward ? -1.f : 1.f;
     const float eta = forward ? s.eta_fwd : s.eta_bwd;
     const float eta2 = forward ? s.eta_fwd2 : s.eta_bwd2;
@@ -398,26 +394,37 @@ __device__ __forceinline__ i2 refract2(const aadff_surface_t& s, Ray2& r, bool f
 __device__ __forceinline__ void react2(const aadff_surface_t& s, Ray2& r, bool forward, int& nan_flag) {
     const i2 alive = r.ra > 0.f;
     if (!any2(alive)) return;
-    f2 t, px, py, pz;
     i2 valid;
     if (s.kind == AADFF_SURF_STOP) {
-        t = (s.d - r.oz) * vrcp(r.dz);
-        px = r.ox + t * r.dx; py = r.oy + t * r.dy; pz = r.oz + t * r.dz;
-        valid = (px * px + py * py) <= s.r * s.r;           // sqrt(x^2+y^2) <= r (surfaces.py:418)
+        const f2 t = (s.d - r.oz) * vrcp(r.dz);
+        r.ox += t * r.dx; r.oy += t * r.dy; r.oz += t * r.dz;
+        valid = alive & ((r.ox * r.ox + r.oy * r.oy) <= s.r * s.r);     // sqrt(x^2+y^2) <= r (surfaces.py:418)
+        if (forward ? s.refract_fwd : s.refract_bwd) valid &= refract_dir2(s, r, forward, f2s(0.f), f2s(0.f), f2s(-1.f));
     } else if (s.kind == AADFF_SURF_SPHERIC) {
         const f2 t0 = (s.d - r.oz) * vrcp(r.dz);
         f2 p0x, p0y, tau;
-        const i2 hit = conic_root2(s, r, t0, p0x, p0y, tau);
-        t = t0 + tau;
-        px = p0x + r.dx * tau; py = p0y + r.dy * tau; pz = s.d + r.dz * tau;
-        valid = hit & ((px * px + py * py) <= s.r2) & (t >= 0.f);
+        const i2 hit = conic_root2<true>(s, r, t0, p0x, p0y, tau);
+        const f2 t = t0 + tau;
+        r.ox = p0x + r.dx * tau; r.oy = p0y + r.dy * tau; r.oz = s.d + r.dz * tau;
+        valid = alive & hit & ((r.ox * r.ox + r.oy * r.oy) <= s.r2) & (t >= 0.f);
+        valid &= refract_dir2(s, r, forward, s.c * r.ox, s.c * r.oy, s.c * (r.oz - s.d) - 1.f);
     } else {
+        f2 t, g;
+#ifndef AADFF_NORMAL_REEVAL
+        newton2(s, r, alive, t, valid, nan_flag, &g);
+        r.ox += t * r.dx; r.oy += t * r.dy; r.oz += t * r.dz;
+#else
         newton2(s, r, alive, t, valid, nan_flag);
-        px = r.ox + t * r.dx; py = r.oy + t * r.dy; pz = r.oz + t * r.dz;
+        r.ox += t * r.dx; r.oy += t * r.dy; r.oz += t * r.dz;
+        f2 sag;
+        sag_and_slope2(s, r.ox * r.ox + r.oy * r.oy, sag, g);
+#endif
+        f2 nx = g * 2.f * r.ox, ny = g * 2.f * r.oy;
+        const f2 inv = vrsq(vmax(nx * nx + ny * ny + 1.f, f2s(1e-24f)));
+        nx *= inv; ny *= inv;
+        valid &= alive;
+        valid &= refract_dir2(s, r, forward, nx, ny, -inv);
     }
-    r.ox = px; r.oy = py; r.oz = pz;
-    valid &= alive;
-    if (s.kind != AADFF_SURF_STOP || (forward ? s.refract_fwd : s.refract_bwd)) valid &= refract2(s, r, forward);
     r.ra = vsel(valid, r.ra, f2s(0.f));
 }
 __device__ __forceinline__ void trace_forward2(const aadff_surface_t* __restrict__ surf, int n_surf, Ray2& r, int& nan_flag) {
