@@ -283,6 +283,7 @@ typedef int i2 __attribute__((ext_vector_type(2)));
 
 struct Ray2 {
     f2 ox, oy, oz, dx, dy, dz, ra;
+    i2 alive;          // validity while tracing (a lane mask: no per-surface compare/select); ra = alive ? 1 : 0 afterwards
 };
 __device__ __forceinline__ f2 f2s(float a) { return (f2){a, a}; }
 __device__ __forceinline__ f2 vsqrt(f2 a) { return (f2){fsqrt(a.x), fsqrt(a.y)}; }
@@ -392,7 +393,7 @@ __device__ __forceinline__ i2 refract_dir2(const aadff_surface_t& s, Ray2& r, bo
     return valid;
 }
 __device__ __forceinline__ void react2(const aadff_surface_t& s, Ray2& r, bool forward, int& nan_flag) {
-    const i2 alive = r.ra > 0.f;
+    const i2 alive = r.alive;
     if (!any2(alive)) return;
     i2 valid;
     if (s.kind == AADFF_SURF_STOP) {
@@ -425,10 +426,12 @@ __device__ __forceinline__ void react2(const aadff_surface_t& s, Ray2& r, bool f
         valid &= alive;
         valid &= refract_dir2(s, r, forward, nx, ny, -inv);
     }
-    r.ra = vsel(valid, r.ra, f2s(0.f));
+    r.alive = valid;
 }
+// in: r.alive; out: r.alive and r.ra = alive ? 1 : 0
 __device__ __forceinline__ void trace_forward2(const aadff_surface_t* __restrict__ surf, int n_surf, Ray2& r, int& nan_flag) {
     for (int i = 0; i < n_surf; ++i) react2(surf[i], r, true, nan_flag);
+    r.ra = vsel(r.alive, f2s(1.f), f2s(0.f));
 }
 __device__ __forceinline__ void disc_sample2(f2 u_theta, f2 u_r, float R2, f2& x, f2& y) {
     const f2 rr = vsqrt(u_r * R2);
@@ -450,7 +453,7 @@ __device__ __forceinline__ Ray2 trace_pair_to_sensor(float px, float py, float p
     r.dx = tx - px; r.dy = ty - py; r.dz = f2s(tz - pz);
     const f2 inv = vrsq(vmax(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz, f2s(1e-24f)));
     r.dx *= inv; r.dy *= inv; r.dz *= inv;
-    r.ra = vsel(active, f2s(1.f), f2s(0.f));
+    r.alive = active;
     trace_forward2(surf, n_surf, r, nan_flag);
     const f2 t = (d_sensor - r.oz) * vrcp(r.dz);
     r.ox += r.dx * t; r.oy += r.dy * t; r.oz += r.dz * t;
@@ -833,7 +836,7 @@ __global__ __launch_bounds__(NT) void refocus_kernel(const float* __restrict__ d
             r.dx = x2; r.dy = y2; r.dz = f2s(lc.first_d - dep);               // o - (0,0,depth)
             const f2 inv = vrsq(vmax(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz, f2s(1e-24f)));
             r.dx *= inv; r.dy *= inv; r.dz *= inv;
-            r.ra = vsel(act, f2s(1.f), f2s(0.f));
+            r.alive = act;
             trace_forward2(surf, lc.n_surf, r, nan_flag);
             f2 t = (r.dx * r.ox + r.dy * r.oy) * vrcp(r.dx * r.dx + r.dy * r.dy);
             t = t * r.ra;
