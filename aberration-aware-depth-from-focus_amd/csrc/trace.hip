@@ -394,7 +394,9 @@ __device__ __forceinline__ i2 refract_dir2(const aadff_surface_t& s, Ray2& r, bo
 }
 __device__ __forceinline__ void react2(const aadff_surface_t& s, Ray2& r, bool forward, int& nan_flag) {
     const i2 alive = r.alive;
-    if (!any2(alive)) return;
+    // wave-uniform skip only: a per-lane early return turns the whole surface body into a divergent region whose
+    // results are merged back with ~12 v_mov per surface (dead lanes just compute values nobody reads)
+    if (!__any(any2(alive))) return;
     i2 valid;
     if (s.kind == AADFF_SURF_STOP) {
         const f2 t = (s.d - r.oz) * vrcp(r.dz);
@@ -430,7 +432,7 @@ __device__ __forceinline__ void react2(const aadff_surface_t& s, Ray2& r, bool f
 }
 // in: r.alive; out: r.alive and r.ra = alive ? 1 : 0
 __device__ __forceinline__ void trace_forward2(const aadff_surface_t* __restrict__ surf, int n_surf, Ray2& r, int& nan_flag) {
-    for (int i = 0; i < n_surf; ++i) react2(surf[i], r, true, nan_flag);
+    for (int i = 0; i < n_surf; ++i) react2(surf[i], r, true, nan_flag);   // (unrolling by two: 2 % slower, code size)
     r.ra = vsel(r.alive, f2s(1.f), f2s(0.f));
 }
 __device__ __forceinline__ void disc_sample2(f2 u_theta, f2 u_r, float R2, f2& x, f2& y) {
