@@ -322,28 +322,32 @@ __device__ __forceinline__ i2 valid_strict2(const aadff_surface_t& s, f2 r2) {
 __device__ __forceinline__ i2 valid_loose2(const aadff_surface_t& s, f2 r2) {
     return s.k_gt_m1 ? (r2 < s.r2_shape) : (r2 > 0.f);
 }
+// Paired core, vertex-plane form: every surface first moves the ray IN PLACE to the vertex plane z = d (origin p0,
+// parameter tau from there: no cancellation for far objects), the kind-specific code only produces tau, a validity
+// mask and the normal, and the common tail advances and refracts the ray in place -- the loop-carried ray state is
+// never defined inside a branch, which saves the ~12 register copies per surface the branchy form cost.
 template <bool STRICT>
-__device__ __forceinline__ f2 newton_step2(const aadff_surface_t& s, const Ray2& r, f2 dxy2, f2 od, f2& t, f2* slope_out = nullptr) {
-    const f2 px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t;
+__device__ __forceinline__ f2 newton_step2(const aadff_surface_t& s, const Ray2& r, f2 dxy2, f2 od, f2& tau, f2* slope_out = nullptr) {
+    const f2 px = r.ox + r.dx * tau, py = r.oy + r.dy * tau;
     f2 r2 = px * px + py * py;
     const i2 m = STRICT ? valid_strict2(s, r2) : valid_loose2(s, r2);
     r2 = vsel(m, r2, f2s(0.f));
     f2 sag, slope;
     sag_and_slope2(s, r2, sag, slope);
-    const f2 ft = sag + s.d - pz;
-    const f2 dr2dt = 2.f * (dxy2 * t + od);
+    const f2 ft = sag - r.dz * tau;                      // sag + d - p_z with p_z = d + dz tau
+    const f2 dr2dt = 2.f * (dxy2 * tau + od);
     const f2 dfdt = slope * dr2dt - r.dz;
     f2 step = ft * vrcp(dfdt + kEps);
     step = vmin(vmax(step, f2s(-kStepBound)), f2s(kStepBound));
-    t -= step;
+    tau -= step;
     if (slope_out) *slope_out = slope;
     return ft;
 }
+// conic root from the vertex-plane point (r.ox, r.oy, d)
 template <bool SPHERE = false>                                  // SPHERE: kind SPHERIC implies k == 0 (Aspheric.kind())
-__device__ __forceinline__ i2 conic_root2(const aadff_surface_t& s, const Ray2& r, f2 t0, f2& p0x, f2& p0y, f2& tau) {
-    p0x = r.ox + r.dx * t0; p0y = r.oy + r.dy * t0;
-    const f2 rho2 = p0x * p0x + p0y * p0y;
-    const f2 beta = s.c * (p0x * r.dx + p0y * r.dy) - r.dz;
+__device__ __forceinline__ i2 conic_root2(const aadff_surface_t& s, const Ray2& r, f2& tau) {
+    const f2 rho2 = r.ox * r.ox + r.oy * r.oy;
+    const f2 beta = s.c * (r.ox * r.dx + r.oy * r.dy) - r.dz;
     const f2 A = SPHERE ? f2s(s.c) : s.c * (1.f + s.k * r.dz * r.dz);
     const f2 disc = beta * beta - A * (s.c * rho2);
     const f2 root = vsqrt(vmax(disc, f2s(0.f)));
@@ -353,32 +357,30 @@ __device__ __forceinline__ i2 conic_root2(const aadff_surface_t& s, const Ray2& 
 // slope_out: d sag / d r^2 of the last (strict) step, i.e. one converged Newton update (<= 5e-5 mm, typically 1e-7)
 // before the hit point; the fused kernels reuse it for the surface normal instead of evaluating the asphere again
 // (relative change of the slope over that update <= 2e-6: below the fp32 noise of the trace; -DAADFF_NORMAL_REEVAL
-// restores the literal evaluation at the hit point, surfaces.py:589-630).
-__device__ __forceinline__ void newton2(const aadff_surface_t& s, const Ray2& r, i2 alive, f2& t_out, i2& valid_out, int& nan_flag,
+// restores the literal evaluation at the hit point, surfaces.py:589-630).  r is at the vertex plane; t0 = distance
+// travelled to get there (the reference's t > 0 test is on t0 + tau).
+__device__ __forceinline__ void newton2(const aadff_surface_t& s, const Ray2& r, i2 alive, f2 t0, f2& tau_out, i2& valid_out, int& nan_flag,
                                         f2* slope_out = nullptr) {
     const f2 dxy2 = r.dx * r.dx + r.dy * r.dy;
     const f2 od = r.dx * r.ox + r.dy * r.oy;
-    const f2 t0 = (s.d - r.oz) * vrcp(r.dz);
-    f2 t = t0;
+    f2 tau = f2s(0.f);
 #ifndef AADFF_NEWTON_PLANE_START
     {
-        f2 p0x, p0y, tau;
-        const i2 hit = conic_root2(s, r, t0, p0x, p0y, tau);
-        t = vsel(hit, t0 + tau, t0);
+        f2 tc;
+        const i2 hit = conic_root2(s, r, tc);
+        tau = vsel(hit, tc, f2s(0.f));
     }
 #endif
     f2 ft = f2s(kMaxT);
     for (int it = 0; it < kNewtonMaxIter; ++it) {
         if (!__any(any2(alive & (vabs(ft) > kTolLoose)))) break;
-        ft = newton_step2<false>(s, r, dxy2, od, t);
+        ft = newton_step2<false>(s, r, dxy2, od, tau);
         if (any2(alive & (ft != ft))) nan_flag = 1;
     }
-    const f2 t1 = t - t0;
-    t = t0 + t1;
-    ft = newton_step2<true>(s, r, dxy2, od, t, slope_out);
-    const f2 px = r.ox + r.dx * t, py = r.oy + r.dy * t;
-    valid_out = valid_strict2(s, px * px + py * py) & (vabs(ft) < kTolTight) & (t > 0.f);
-    t_out = t;
+    ft = newton_step2<true>(s, r, dxy2, od, tau, slope_out);
+    const f2 px = r.ox + r.dx * tau, py = r.oy + r.dy * tau;
+    valid_out = valid_strict2(s, px * px + py * py) & (vabs(ft) < kTolTight) & (t0 + tau > 0.f);
+    tau_out = tau;
 }
 // vector Snell refraction at a surface with unit normal (nx, ny, nz) (surfaces.py:633-679)
 __device__ __forceinline__ i2 refract_dir2(const aadff_surface_t& s, Ray2& r, bool forward, f2 nx, f2 ny, f2 nz) {
@@ -397,37 +399,38 @@ __device__ __forceinline__ void react2(const aadff_surface_t& s, Ray2& r, bool f
     // wave-uniform skip only: a per-lane early return turns the whole surface body into a divergent region whose
     // results are merged back with ~12 v_mov per surface (dead lanes just compute values nobody reads)
     if (!__any(any2(alive))) return;
+    // to the vertex plane, in place
+    const f2 t0 = (s.d - r.oz) * vrcp(r.dz);
+    r.ox += r.dx * t0; r.oy += r.dy * t0;
+    f2 tau, nx, ny, nz;
     i2 valid;
-    if (s.kind == AADFF_SURF_STOP) {
-        const f2 t = (s.d - r.oz) * vrcp(r.dz);
-        r.ox += t * r.dx; r.oy += t * r.dy; r.oz += t * r.dz;
-        valid = alive & ((r.ox * r.ox + r.oy * r.oy) <= s.r * s.r);     // sqrt(x^2+y^2) <= r (surfaces.py:418)
-        if (forward ? s.refract_fwd : s.refract_bwd) valid &= refract_dir2(s, r, forward, f2s(0.f), f2s(0.f), f2s(-1.f));
-    } else if (s.kind == AADFF_SURF_SPHERIC) {
-        const f2 t0 = (s.d - r.oz) * vrcp(r.dz);
-        f2 p0x, p0y, tau;
-        const i2 hit = conic_root2<true>(s, r, t0, p0x, p0y, tau);
-        const f2 t = t0 + tau;
-        r.ox = p0x + r.dx * tau; r.oy = p0y + r.dy * tau; r.oz = s.d + r.dz * tau;
-        valid = alive & hit & ((r.ox * r.ox + r.oy * r.oy) <= s.r2) & (t >= 0.f);
-        valid &= refract_dir2(s, r, forward, s.c * r.ox, s.c * r.oy, s.c * (r.oz - s.d) - 1.f);
+    if (s.kind == AADFF_SURF_SPHERIC) {
+        const i2 hit = conic_root2<true>(s, r, tau);
+        valid = hit & (t0 + tau >= 0.f);
+        r.ox += r.dx * tau; r.oy += r.dy * tau; r.oz = s.d + r.dz * tau;
+        valid &= (r.ox * r.ox + r.oy * r.oy) <= s.r2;
+        nx = s.c * r.ox; ny = s.c * r.oy; nz = s.c * (r.oz - s.d) - 1.f;
+    } else if (s.kind == AADFF_SURF_STOP) {
+        r.oz = f2s(s.d);
+        valid = (r.ox * r.ox + r.oy * r.oy) <= s.r * s.r;           // sqrt(x^2+y^2) <= r (surfaces.py:418)
+        nx = f2s(0.f); ny = f2s(0.f); nz = f2s(-1.f);
     } else {
-        f2 t, g;
+        f2 g;
 #ifndef AADFF_NORMAL_REEVAL
-        newton2(s, r, alive, t, valid, nan_flag, &g);
-        r.ox += t * r.dx; r.oy += t * r.dy; r.oz += t * r.dz;
+        newton2(s, r, alive, t0, tau, valid, nan_flag, &g);
+        r.ox += r.dx * tau; r.oy += r.dy * tau; r.oz = s.d + r.dz * tau;
 #else
-        newton2(s, r, alive, t, valid, nan_flag);
-        r.ox += t * r.dx; r.oy += t * r.dy; r.oz += t * r.dz;
+        newton2(s, r, alive, t0, tau, valid, nan_flag);
+        r.ox += r.dx * tau; r.oy += r.dy * tau; r.oz = s.d + r.dz * tau;
         f2 sag;
         sag_and_slope2(s, r.ox * r.ox + r.oy * r.oy, sag, g);
 #endif
-        f2 nx = g * 2.f * r.ox, ny = g * 2.f * r.oy;
+        nx = g * 2.f * r.ox; ny = g * 2.f * r.oy;
         const f2 inv = vrsq(vmax(nx * nx + ny * ny + 1.f, f2s(1e-24f)));
-        nx *= inv; ny *= inv;
-        valid &= alive;
-        valid &= refract_dir2(s, r, forward, nx, ny, -inv);
+        nx *= inv; ny *= inv; nz = -inv;
     }
+    valid &= alive;
+    if (s.kind != AADFF_SURF_STOP || (forward ? s.refract_fwd : s.refract_bwd)) valid &= refract_dir2(s, r, forward, nx, ny, nz);
     r.alive = valid;
 }
 // in: r.alive; out: r.alive and r.ra = alive ? 1 : 0
