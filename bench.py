@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="all-gather the rendered stacks over RCCL (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--device-rng", action="store_true", help="draw pupil samples on the GPU (not sample-comparable)")
+    ap.add_argument("--spinup-s", type=float, default=0.3, help="untimed device spin-up before the warm-up steps [s]")
     ap.add_argument("--mode", choices=("m1", "m2"), default="m1",
                     help="m1 (default, BASELINE.json metric): ray-traced PSF grid + patch convolution; "
                          "m2: RGB-D stack through the PSF surrogate network (PSFNet.render, SURVEY.md 8f-1)")
@@ -129,6 +130,13 @@ def main():
             torch.cuda.current_stream(dev).wait_stream(comm)   # next step overwrites plan.out
         return out
 
+    # device spin-up (untimed, before the warm-up steps): a fresh box needs ~0.2 s under load before the shader
+    # clock settles; a cold first run otherwise reads 10 % low (0.51 vs 0.46 ms/step with identical code)
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup_s:
+        for i in range(16):
+            step(i, False)
+        torch.cuda.synchronize(dev)
     for i in range(args.warmup):
         step(i, False)
     torch.cuda.synchronize(dev)
