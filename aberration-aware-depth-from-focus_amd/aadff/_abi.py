@@ -22,7 +22,8 @@ class Surface(C.Structure):
                 ("r2", C.c_float), ("r2_shape", C.c_float),
                 ("eta_fwd", C.c_float), ("eta_fwd2", C.c_float), ("eta_bwd", C.c_float), ("eta_bwd2", C.c_float),
                 ("kind", C.c_int), ("n_ai", C.c_int), ("refract_fwd", C.c_int), ("refract_bwd", C.c_int),
-                ("k_gt_m1", C.c_int), ("ai", C.c_float * MAX_AI), ("dai", C.c_float * MAX_AI)]
+                ("k_gt_m1", C.c_int), ("ai", C.c_float * MAX_AI), ("dai", C.c_float * MAX_AI),
+                ("cos2_min_fwd", C.c_float), ("cos2_min_bwd", C.c_float)]
 
 
 class LensState(C.Structure):
@@ -44,7 +45,7 @@ class Stage(C.Structure):
 
 
 assert C.sizeof(Stage) == 40
-assert C.sizeof(Surface) == 124 and C.sizeof(LensState) == 32 and C.sizeof(LensConst) == 52
+assert C.sizeof(Surface) == 132 and C.sizeof(LensState) == 32 and C.sizeof(LensConst) == 52
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 

@@ -388,8 +388,10 @@ __device__ __forceinline__ i2 refract_dir2(const aadff_surface_t& s, Ray2& r, bo
     const float eta = forward ? s.eta_fwd : s.eta_bwd;
     const float eta2 = forward ? s.eta_fwd2 : s.eta_bwd2;
     const f2 cosi = sgn * (r.dx * nx + r.dy * ny + r.dz * nz);
-    const f2 sin2 = eta2 * (1.f - cosi * cosi);
-    const i2 valid = (cosi * cosi > 0.1f) & (sin2 < 1.f);
+    const f2 cos2 = cosi * cosi;
+    const f2 sin2 = eta2 * (1.f - cos2);
+    // cos^2 i > 0.1 and eta^2 (1 - cos^2 i) < 1  <=>  cos^2 i > max(0.1, 1 - 1/eta^2)  (host-computed per surface)
+    const i2 valid = cos2 > (forward ? s.cos2_min_fwd : s.cos2_min_bwd);
     const f2 g = sgn * (vsqrt(vmax(1.f - sin2, f2s(0.f))) - eta * cosi);
     r.dx = eta * r.dx + g * nx; r.dy = eta * r.dy + g * ny; r.dz = eta * r.dz + g * nz;
     return valid;

@@ -80,6 +80,7 @@ class Aspheric(Surface):
         n1, n2 = self.mat1.ior(wvln), self.mat2.ior(wvln)
         ef, eb = n1 / n2, n2 / n1
         s.eta_fwd, s.eta_fwd2, s.eta_bwd, s.eta_bwd2 = ef, ef ** 2, eb, eb ** 2
+        s.cos2_min_fwd, s.cos2_min_bwd = max(0.1, 1.0 - 1.0 / ef ** 2), max(0.1, 1.0 - 1.0 / eb ** 2)
         is_stop = s.kind == _abi.SURF_STOP
         s.refract_fwd = int(not (is_stop and ef == 1))
         s.refract_bwd = int(not (is_stop and eb == 1))

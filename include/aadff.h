@@ -39,7 +39,7 @@ enum { AADFF_SURF_STOP = 0, AADFF_SURF_SPHERIC = 1, AADFF_SURF_ASPHERIC = 2 };
 
 /* One surface at ONE wavelength.  Host code fills it (deeplens/optics.py: LensTable);
  * values that the reference forms in float64 Python arithmetic and then feeds to fp32
- * tensor ops are rounded to fp32 exactly once, here.  124 bytes. */
+ * tensor ops are rounded to fp32 exactly once, here.  132 bytes. */
 typedef struct aadff_surface {
     float d;            /* vertex z [mm]                            surfaces.py:11-14 */
     float c;            /* curvature 1/roc                          surfaces.py:304   */
@@ -58,6 +58,8 @@ typedef struct aadff_surface {
     int   k_gt_m1;      /* k > -1 selects the shape-domain test     surfaces.py:727,738 */
     float ai[AADFF_MAX_AI];   /* a2, a4, ... (coefficient of r^(2(j+1)))       surfaces.py:799 */
     float dai[AADFF_MAX_AI];  /* (j+1) * ai[j] in fp32: derivative coefficients surfaces.py:823 */
+    float cos2_min_fwd; /* max(0.1, 1 - 1/eta_fwd^2): the two refraction validity tests of surfaces.py:660-663   */
+    float cos2_min_bwd; /* (cos^2 i > 0.1 and eta^2 (1 - cos^2 i) < 1) as ONE threshold on cos^2 i (fused kernels) */
 } aadff_surface_t;
 
 /* Per-focus-setting lens state; lives on the device so a whole stack is rendered
