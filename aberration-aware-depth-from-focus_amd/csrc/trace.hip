@@ -291,6 +291,13 @@ __device__ __forceinline__ f2 vrcp(f2 a) { return (f2){frcp(a.x), frcp(a.y)}; }
 __device__ __forceinline__ f2 vrsq(f2 a) { return (f2){frsq(a.x), frsq(a.y)}; }
 __device__ __forceinline__ f2 vmax(f2 a, f2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ f2 vmin(f2 a, f2 b) { return __builtin_elementwise_min(a, b); }
+// max(x, 0) as ONE v_max_f32 per component (the generic form first canonicalises x: two instructions)
+__device__ __forceinline__ f2 vmax0(f2 a) {
+    float x, y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(x) : "v"(a.x));
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(a.y));
+    return (f2){x, y};
+}
 __device__ __forceinline__ f2 vabs(f2 a) { return __builtin_elementwise_abs(a); }
 __device__ __forceinline__ f2 vsel(i2 m, f2 a, f2 b) { return (f2){m.x ? a.x : b.x, m.y ? a.y : b.y}; }
 __device__ __forceinline__ bool any2(i2 m) { return (m.x | m.y) != 0; }
@@ -350,7 +357,7 @@ __device__ __forceinline__ i2 conic_root2(const aadff_surface_t& s, const Ray2& 
     const f2 beta = s.c * (r.ox * r.dx + r.oy * r.dy) - r.dz;
     const f2 A = SPHERE ? f2s(s.c) : s.c * (1.f + s.k * r.dz * r.dz);
     const f2 disc = beta * beta - A * (s.c * rho2);
-    const f2 root = vsqrt(vmax(disc, f2s(0.f)));
+    const f2 root = vsqrt(vmax0(disc));
     tau = (s.c * rho2) * vrcp(vsel(beta < 0.f, root - beta, -(root + beta)));
     return disc >= 0.f;
 }
@@ -392,7 +399,7 @@ __device__ __forceinline__ i2 refract_dir2(const aadff_surface_t& s, Ray2& r, bo
     const f2 sin2 = eta2 * (1.f - cos2);
     // cos^2 i > 0.1 and eta^2 (1 - cos^2 i) < 1  <=>  cos^2 i > max(0.1, 1 - 1/eta^2)  (host-computed per surface)
     const i2 valid = cos2 > (forward ? s.cos2_min_fwd : s.cos2_min_bwd);
-    const f2 g = sgn * (vsqrt(vmax(1.f - sin2, f2s(0.f))) - eta * cosi);
+    const f2 g = sgn * (vsqrt(vmax0(1.f - sin2)) - eta * cosi);
     r.dx = eta * r.dx + g * nx; r.dy = eta * r.dy + g * ny; r.dz = eta * r.dz + g * nz;
     return valid;
 }
