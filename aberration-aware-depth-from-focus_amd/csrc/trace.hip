@@ -20,6 +20,7 @@ constexpr int kNewtonMaxIter = 10;       // deeplens/surfaces.py:26
 constexpr float kTolTight = 10e-6f;      // deeplens/surfaces.py:27
 constexpr float kTolLoose = 50e-6f;      // deeplens/surfaces.py:28
 constexpr float kStepBound = 5.f;        // deeplens/surfaces.py:29
+constexpr float kStepConverged = 1e-3f;  // fused kernels: a Newton update below 1 um ends the loop (see newton2)
 constexpr int AADFF_SPHERIC_CLOSED_FORM = AADFF_SURF_SPHERIC;
 constexpr float kTwoPiHi = 3.14159274101257324f;   // (float)np.pi
 
@@ -334,7 +335,8 @@ __device__ __forceinline__ i2 valid_loose2(const aadff_surface_t& s, f2 r2) {
 // mask and the normal, and the common tail advances and refracts the ray in place -- the loop-carried ray state is
 // never defined inside a branch, which saves the ~12 register copies per surface the branchy form cost.
 template <bool STRICT>
-__device__ __forceinline__ f2 newton_step2(const aadff_surface_t& s, const Ray2& r, f2 dxy2, f2 od, f2& tau, f2* slope_out = nullptr) {
+__device__ __forceinline__ f2 newton_step2(const aadff_surface_t& s, const Ray2& r, f2 dxy2, f2 od, f2& tau, f2* slope_out = nullptr,
+                                           f2* step_out = nullptr) {
     const f2 px = r.ox + r.dx * tau, py = r.oy + r.dy * tau;
     f2 r2 = px * px + py * py;
     const i2 m = STRICT ? valid_strict2(s, r2) : valid_loose2(s, r2);
@@ -348,6 +350,7 @@ __device__ __forceinline__ f2 newton_step2(const aadff_surface_t& s, const Ray2&
     step = vmin(vmax(step, f2s(-kStepBound)), f2s(kStepBound));
     tau -= step;
     if (slope_out) *slope_out = slope;
+    if (step_out) *step_out = step;
     return ft;
 }
 // conic root from the vertex-plane point (r.ox, r.oy, d)
@@ -378,10 +381,18 @@ __device__ __forceinline__ void newton2(const aadff_surface_t& s, const Ray2& r,
         tau = vsel(hit, tc, f2s(0.f));
     }
 #endif
-    f2 ft = f2s(kMaxT);
+    // The reference leaves its loop when the residual BEFORE the last update is below 5e-5 mm, i.e. it spends one
+    // whole evaluation confirming a converged point, then takes its extra (strict) step.  A Newton update shorter than
+    // kStepConverged leaves a residual of order (curvature) x step^2 << 5e-5 mm, so the confirming evaluation is
+    // skipped (hit points move by < 1e-9 mm); the strict step's own |residual| < 1e-5 test still guards every ray.
+    f2 ft = f2s(kMaxT), step = f2s(kMaxT);
     for (int it = 0; it < kNewtonMaxIter; ++it) {
+#ifndef AADFF_NEWTON_LITERAL_EXIT
+        if (!__any(any2(alive & (vabs(ft) > kTolLoose) & (vabs(step) > kStepConverged)))) break;
+#else
         if (!__any(any2(alive & (vabs(ft) > kTolLoose)))) break;
-        ft = newton_step2<false>(s, r, dxy2, od, tau);
+#endif
+        ft = newton_step2<false>(s, r, dxy2, od, tau, nullptr, &step);
         if (any2(alive & (ft != ft))) nan_flag = 1;
     }
     ft = newton_step2<true>(s, r, dxy2, od, tau, slope_out);
