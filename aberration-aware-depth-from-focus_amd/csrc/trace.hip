@@ -453,6 +453,10 @@ __device__ __forceinline__ void react2(const aadff_surface_t& s, Ray2& r, bool f
     if (s.kind != AADFF_SURF_STOP || (forward ? s.refract_fwd : s.refract_bwd)) valid &= refract_dir2(s, r, forward, nx, ny, nz);
     r.alive = valid;
 }
+// surfaces [first, last) forward; r.alive in/out (r.ra not touched)
+__device__ __forceinline__ void trace_part2(const aadff_surface_t* __restrict__ surf, int first, int last, Ray2& r, int& nan_flag) {
+    for (int i = first; i < last; ++i) react2(surf[i], r, true, nan_flag);
+}
 // in: r.alive; out: r.alive and r.ra = alive ? 1 : 0
 __device__ __forceinline__ void trace_forward2(const aadff_surface_t* __restrict__ surf, int n_surf, Ray2& r, int& nan_flag) {
     for (int i = 0; i < n_surf; ++i) react2(surf[i], r, true, nan_flag);   // (unrolling by two: 2 % slower, code size)
@@ -614,6 +618,7 @@ struct StageArgs {
 #define AADFF_PSF_THREADS 512
 #endif
 constexpr int kPsfThreads = AADFF_PSF_THREADS, kPsfWaves = kPsfThreads / 64;
+constexpr int kCompactMax = 2048;         // rays per compaction chunk of the main pass (48 KB of LDS)
 __global__ __launch_bounds__(kPsfThreads) void psf_points_kernel(const float* __restrict__ points, int N, int L,
                                                           const aadff_surface_t* __restrict__ surf_main,
                                                           const aadff_surface_t* __restrict__ surf_chief,
@@ -625,6 +630,10 @@ __global__ __launch_bounds__(kPsfThreads) void psf_points_kernel(const float* __
                                                           float* centre_out, int* flags, StageArgs stage) {
     __shared__ float hist[AADFF_MAX_KS * AADFF_MAX_KS];
     __shared__ float red[3 * kPsfWaves];
+#if !defined(AADFF_PSF_SCALAR) && !defined(AADFF_PSF_NO_COMPACT)
+    __shared__ float cbuf[6][kCompactMax];               // survivors of the first surfaces: origin and direction
+    __shared__ int c_count;
+#endif
     const int n = blockIdx.x, l = blockIdx.y;
     int s = blockIdx.z;
     const int tid = threadIdx.x, kk = g.ks * g.ks;
@@ -717,9 +726,69 @@ __global__ __launch_bounds__(kPsfThreads) void psf_points_kernel(const float* __
     }
 
     const aadff_surface_t* tab = surf_main + (size_t)l * lc.n_surf;
+#if !defined(AADFF_PSF_SCALAR) && !defined(AADFF_PSF_NO_COMPACT)
+    int split = lc.n_surf / 2;                            // compaction point: two surfaces behind the stop
+    for (int i = 0; i < lc.n_surf; ++i)
+        if (tab[i].kind == AADFF_SURF_STOP) { split = min(i + 2, lc.n_surf); break; }
+#endif
     const float* ut = u_main + (size_t)s * main_ss + (size_t)l * main_sl;
     const float* ur = ut + spp;
 #ifndef AADFF_PSF_SCALAR
+#ifndef AADFF_PSF_NO_COMPACT
+    // Main pass in two phases with the survivors compacted in between: a third of the rays of an off-axis point die
+    // at the apertures right behind the stop, scattered over all lanes, so no wave ever finishes early; after the
+    // compaction the remaining surfaces (both aspheres of rf50mm) run on full waves only.  Chunks of kCompactMax rays.
+    for (int c0 = 0; c0 < spp; c0 += kCompactMax) {
+        const int cn = min(spp - c0, kCompactMax);
+        if (tid == 0) c_count = 0;
+        __syncthreads();
+        for (int i = tid; i < cn; i += 2 * kPsfThreads) {
+            const int i1 = i + kPsfThreads;
+            const i2 act = {-1, i1 < cn ? -1 : 0};
+            const int j1 = act.y ? i1 : i;
+            f2 x2, y2;
+            disc_sample2((f2){ut[c0 + i], ut[c0 + j1]}, (f2){ur[c0 + i], ur[c0 + j1]}, lc.enp_r2, x2, y2);
+            Ray2 r;
+            r.ox = f2s(px); r.oy = f2s(py); r.oz = f2s(depth);
+            r.dx = x2 - px; r.dy = y2 - py; r.dz = f2s(lc.enp_z - depth);
+            const f2 inv = vrsq(vmax(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz, f2s(1e-24f)));
+            r.dx *= inv; r.dy *= inv; r.dz *= inv;
+            r.alive = act;
+            trace_part2(tab, 0, split, r, nan_flag);
+            // append the survivors: one LDS atomic per wave, slots by ballot prefix
+            const unsigned long long bx = __ballot(r.alive.x != 0), by = __ballot(r.alive.y != 0);
+            const int nx = __popcll(bx), ny = __popcll(by);
+            int base = 0;
+            if ((tid & 63) == 0) base = atomicAdd(&c_count, nx + ny);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+            if (r.alive.x) {
+                const int k = base + __popcll(bx & below);
+                cbuf[0][k] = r.ox.x; cbuf[1][k] = r.oy.x; cbuf[2][k] = r.oz.x; cbuf[3][k] = r.dx.x; cbuf[4][k] = r.dy.x; cbuf[5][k] = r.dz.x;
+            }
+            if (r.alive.y) {
+                const int k = base + nx + __popcll(by & below);
+                cbuf[0][k] = r.ox.y; cbuf[1][k] = r.oy.y; cbuf[2][k] = r.oz.y; cbuf[3][k] = r.dx.y; cbuf[4][k] = r.dy.y; cbuf[5][k] = r.dz.y;
+            }
+        }
+        __syncthreads();
+        const int ns = c_count;
+        for (int q = tid; 2 * q < ns; q += kPsfThreads) {
+            const bool two = 2 * q + 1 < ns;
+            const int k0 = 2 * q, k1 = two ? k0 + 1 : k0;
+            Ray2 r;
+            r.ox = (f2){cbuf[0][k0], cbuf[0][k1]}; r.oy = (f2){cbuf[1][k0], cbuf[1][k1]}; r.oz = (f2){cbuf[2][k0], cbuf[2][k1]};
+            r.dx = (f2){cbuf[3][k0], cbuf[3][k1]}; r.dy = (f2){cbuf[4][k0], cbuf[4][k1]}; r.dz = (f2){cbuf[5][k0], cbuf[5][k1]};
+            r.alive = (i2){-1, two ? -1 : 0};
+            trace_part2(tab, split, lc.n_surf, r, nan_flag);
+            const f2 t = (st.d_sensor - r.oz) * vrcp(r.dz);
+            r.ox += r.dx * t; r.oy += r.dy * t;
+            splat_hit(hist, g, r.ox.x, r.oy.x, r.alive.x ? 1.f : 0.f, cx, cy);
+            splat_hit(hist, g, r.ox.y, r.oy.y, r.alive.y ? 1.f : 0.f, cx, cy);
+        }
+        __syncthreads();                                  // cbuf / c_count are reused by the next chunk
+    }
+#else
     for (int i = tid; i < spp; i += 2 * kPsfThreads) {
         const int i1 = i + kPsfThreads;
         const i2 act = {-1, i1 < spp ? -1 : 0};
@@ -730,6 +799,7 @@ __global__ __launch_bounds__(kPsfThreads) void psf_points_kernel(const float* __
         splat_hit(hist, g, r.ox.x, r.oy.x, r.ra.x, cx, cy);
         splat_hit(hist, g, r.ox.y, r.oy.y, r.ra.y, cx, cy);
     }
+#endif
 #else
     for (int i = tid; i < spp; i += kPsfThreads) {
         float x2, y2;
