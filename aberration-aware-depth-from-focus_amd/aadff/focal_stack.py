@@ -173,13 +173,15 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
                       plan.lc, _abi.ptr(plan.states), C.c_void_p(ub + 4 * plan.o_main), spp, plan.per, plan.per_l,
                       C.c_void_p(ub + 4 * plan.o_chief), GEO_SPP, plan.per, plan.per_l, ks, 1, 1,
                       _abi.ptr(plan.psf_maps), None, _abi.ptr(plan.flags), C.byref(stage), st)
-            plan.staged()
         if plan.conv_events is not None:
             plan.conv_events[0].record()
         _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(plan.psf_maps), _abi.ptr(plan.out), B, C_, S,
                   H, W, grid, ks, st)
         if plan.conv_events is not None:
             plan.conv_events[1].record()
+        if stage is not None:
+            plan.staged()        # pinned-slot guard: recorded behind the conv launch (an event record between the PSF and
+                                 # conv launches widens that queue gap by ~4 us)
     if update_lens:      # the reference leaves the lens focused at the last distance
         nb = C.sizeof(_abi.LensState)
         lens._state_device().copy_(plan.states[(S - 1) * nb:S * nb])
