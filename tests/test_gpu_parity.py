@@ -354,6 +354,24 @@ def test_psf_single_point_and_nocenter(golden_dir, repo_root):
     assert rel_l2(p.cpu().numpy(), g["nocenter_psf"]) <= PSF_TOL
 
 
+@pytest.mark.parametrize("spp", [3000, 4096])
+def test_psf_more_rays_than_one_compaction_chunk_vs_oracle(repo_root, spp):
+    """spp above the 2048-ray compaction chunk of the fused kernel's main pass (the training path uses 4096) and a
+    ragged last chunk, against the oracle on the same host-RNG stream."""
+    pts = torch.tensor([[0.0, 0.0, -1500.0], [0.7, -0.5, -900.0], [-0.95, 0.95, -4000.0]])
+    ora = OracleLens(lens_path(repo_root), sensor_res=(512, 512))
+    torch.manual_seed(21)
+    ora.refocus(-1500.0)
+    want = ora.psf(pts, ks=11, spp=spp).numpy()
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(512, 512), device=DEV)
+    torch.manual_seed(21)
+    lens.refocus(-1500.0)
+    got = lens.psf(pts, ks=11, spp=spp).cpu().numpy()
+    assert got.shape == want.shape == (3, 11, 11)
+    assert rel_l2(got, want) <= PSF_TOL
+    assert got.sum((1, 2)) == pytest.approx(1.0, abs=1e-5)
+
+
 def test_psf_rgb_layout_matches_psf_map(repo_root):
     lens = Lensgroup(lens_path(repo_root), sensor_res=(256, 256), device=DEV)
     torch.manual_seed(1)
