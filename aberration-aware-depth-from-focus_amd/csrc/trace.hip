@@ -575,7 +575,7 @@ __device__ __forceinline__ void splat_hit(float* hist, const SplatGeom& g, float
 __global__ __launch_bounds__(256) void psf_splat_kernel(const float* __restrict__ o, const float* __restrict__ ra,
                                                          const float* __restrict__ centre, int spp, int N,
                                                          SplatGeom g, float* psf_raw, float* psf) {
-    __shared__ float hist[AADFF_MAX_KS * AADFF_MAX_KS];
+    extern __shared__ float hist[];                      // ks * ks floats (dynamic: ks up to AADFF_MAX_KS = 51)
     __shared__ float red[4];
     const int n = blockIdx.x, kk = g.ks * g.ks;
     for (int e = threadIdx.x; e < kk; e += blockDim.x) hist[e] = 0.f;
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(kPsfThreads) void psf_points_kernel(const float* __
                                                           long main_sl, const float* __restrict__ u_chief,
                                                           int spp_chief, long chief_ss, long chief_sl, SplatGeom g, int centre_mode, int map_grid, float* psf,
                                                           float* centre_out, int* flags, StageArgs stage) {
-    __shared__ float hist[AADFF_MAX_KS * AADFF_MAX_KS];
+    extern __shared__ float hist[];                      // ks * ks floats (dynamic: ks up to AADFF_MAX_KS = 51)
     __shared__ float red[3 * kPsfWaves];
 #if !defined(AADFF_PSF_SCALAR) && !defined(AADFF_PSF_NO_COMPACT)
     __shared__ float cbuf[6][kCompactMax];               // survivors of the first surfaces: origin and direction
@@ -1051,7 +1051,7 @@ int aadff_psf_splat(const float* o, const float* ra, const float* centre, int sp
                     float* psf_raw_or_null, float* psf, aadff_stream_t stream) {
     AADFF_CHECK_ARG(o && ra && centre && psf, "psf_splat: NULL pointer");
     AADFF_CHECK_ARG(spp > 0 && N > 0 && ks >= 1 && ks <= AADFF_MAX_KS, "psf_splat: bad sizes spp=%d N=%d ks=%d", spp, N, ks);
-    hipLaunchKernelGGL(psf_splat_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, o, ra, centre, spp, N,
+    hipLaunchKernelGGL(psf_splat_kernel, dim3(N), dim3(256), (size_t)ks * ks * sizeof(float), (hipStream_t)stream, o, ra, centre, spp, N,
                        make_splat_geom(pixel_size, ks), psf_raw_or_null, psf);
     AADFF_CHECK_LAUNCH();
     return 0;
@@ -1093,7 +1093,7 @@ static int psf_points_launch(const float* points, int S, int N, int L, const aad
         sa.counters = stage->counters;
         sa.target = stage->generation * (unsigned)sa.copy_wgs;
     }
-    hipLaunchKernelGGL(psf_points_kernel, dim3(N, L, sa.src ? S + 1 : S), dim3(kPsfThreads), 0, (hipStream_t)stream, points, N, L, surf_main,
+    hipLaunchKernelGGL(psf_points_kernel, dim3(N, L, sa.src ? S + 1 : S), dim3(kPsfThreads), (size_t)ks * ks * sizeof(float), (hipStream_t)stream, points, N, L, surf_main,
                        surf_chief, lc, states, u_main, spp, main_stride_s, main_stride_l, u_chief, spp_chief, chief_stride_s,
                        chief_stride_l, make_splat_geom(lc.pixel_size, ks),
                        centre_mode, map_grid, psf, centre_out_or_null, flags_or_null, sa);

@@ -28,7 +28,7 @@ extern "C" {
 #define AADFF_EUNSUPPORTED (-2)  /* parameter outside what the kernels were built for */
 
 #define AADFF_MAX_GRID   64      /* PSF grid per side (reference uses 7..11)          */
-#define AADFF_MAX_KS     31      /* PSF kernel size, odd                              */
+#define AADFF_MAX_KS     51      /* PSF kernel size, odd (psf_map default: optics.py:1006) */
 #define AADFF_MAX_SURF   32      /* surfaces per lens                                 */
 #define AADFF_MAX_AI     8       /* even-asphere coefficients a2..a16                 */
 

@@ -372,6 +372,23 @@ def test_psf_more_rays_than_one_compaction_chunk_vs_oracle(repo_root, spp):
     assert got.sum((1, 2)) == pytest.approx(1.0, abs=1e-5)
 
 
+def test_psf_map_signature_defaults_ks51(repo_root):
+    """Lensgroup.psf_map() with the reference's defaults (grid 7, ks 51, optics.py:1006) and render_psf_map on it
+    (generic-ks convolution kernel) against the oracle on the same RNG stream, at a reduced ray count."""
+    ora = OracleLens(lens_path(repo_root), sensor_res=(256, 256))
+    torch.manual_seed(5)
+    want = ora.psf_map(depth=-1500.0, spp=256).numpy()
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(256, 256), device=DEV)
+    torch.manual_seed(5)
+    got = lens.psf_map(depth=-1500.0, spp=256)
+    assert got.shape == (3, 7 * 51, 7 * 51)
+    assert rel_l2(got.cpu().numpy(), want) <= 2 * PSF_TOL          # 256 rays over 51x51 bins: one ray = 0.4 % of a PSF
+    img = tt(synth_rgb(256, 256))[None]
+    ref = oconv.render_psf_map(img, tt(want), 7).numpy()
+    out = rp.render_psf_map(img.to(DEV), got, 7).cpu().numpy()
+    assert rel_l2(out, ref) <= IMG_TOL
+
+
 def test_psf_rgb_layout_matches_psf_map(repo_root):
     lens = Lensgroup(lens_path(repo_root), sensor_res=(256, 256), device=DEV)
     torch.manual_seed(1)
