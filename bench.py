@@ -77,12 +77,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--device-rng", action="store_true", help="draw pupil samples on the GPU (not sample-comparable)")
     ap.add_argument("--spinup-s", type=float, default=0.3, help="untimed device spin-up before the warm-up steps [s]")
-    ap.add_argument("--mode", choices=("m1", "m2"), default="m1",
+    ap.add_argument("--mode", choices=("m1", "m2", "fit"), default="m1",
                     help="m1 (default, BASELINE.json metric): ray-traced PSF grid + patch convolution; "
-                         "m2: RGB-D stack through the PSF surrogate network (PSFNet.render, SURVEY.md 8f-1)")
+                         "m2: RGB-D stack through the PSF surrogate network (PSFNet.render, SURVEY.md 8f-1); "
+                         "fit: 1_fit_psfnet.py training iterations (ray-traced targets + MLP step, BASELINE config 3)")
     args = ap.parse_args()
     if args.mode == "m2":
         return main_m2(args)
+    if args.mode == "fit":
+        return main_fit(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -257,6 +260,54 @@ def main_m2(args):
                          "kernel_ms": round(kms, 4), "fp32_equivalent_tflops": round(issued / 3, 1)}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def main_fit(args):
+    """1_fit_psfnet.py training loop (reference: deeplens/psfnet.py:79-170): per iteration a random focus distance
+    (refocus kernel), bs = 128 random points, their ray-traced PSFs (fused trace/PSF kernel, spp 2048, ks 11) as targets,
+    one MLP forward/backward/AdamW step in torch (bf16 autocast on the MLP).  Not the BASELINE.json metric."""
+    import torch.nn as nn
+    from aadff.synth import mlp_state_dict
+    from deeplens.psfnet import PSFNet
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    net = PSFNet(os.path.join(REPO, "lenses", "rf50mm", "lens.json"), sensor_res=(512, 512), kernel_size=KS, device=dev)
+    net.psfnet.load_state_dict({k: torch.from_numpy(v) for k, v in mlp_state_dict(seed=4321).items()})
+    bs, spp = 128, SPP
+    cri = nn.MSELoss()
+    optim = torch.optim.AdamW(net.psfnet.parameters(), 1e-4)
+    steps = min(args.steps, 100) if args.steps == 200 else args.steps
+    t_data = [0.0]
+
+    def it(i):
+        torch.manual_seed(i)
+        t0 = time.perf_counter()
+        inp, psf = net.get_training_data(bs=bs, spp=spp)
+        inp, psf = inp.to(dev), psf.to(dev)
+        t_data[0] += time.perf_counter() - t0
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = net.psfnet(inp)
+        optim.zero_grad()
+        loss = cri(pred.float(), psf)
+        loss.backward()
+        optim.step()
+
+    for i in range(min(args.warmup, 10)):
+        it(i)
+    torch.cuda.synchronize(dev)
+    t_data[0] = 0.0
+    t0 = time.perf_counter()
+    for i in range(steps):
+        it(i)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "PSFNet fit iterations/s (bs 128 ray-traced PSF targets, spp 2048, ks 11, bf16 MLP step)",
+        "value": round(steps / dt, 2), "unit": "it/s", "n_gpus": 1, "steps": steps, "warmup": min(args.warmup, 10),
+        "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 targets / bf16 MLP", "data": "synthetic",
+        "config": {"workload": "rf50mm, 512x512 sensor, reference sampling of (x, y, z, focus), random-init MLP 4-64-256-8x256-121",
+                   "host_data_ms_per_step": round(t_data[0] / steps * 1e3, 4)}}), flush=True)
 
 
 if __name__ == "__main__":
