@@ -266,17 +266,16 @@ def main_fit(args):
     """1_fit_psfnet.py training loop (reference: deeplens/psfnet.py:79-170): per iteration a random focus distance
     (refocus kernel), bs = 128 random points, their ray-traced PSFs (fused trace/PSF kernel, spp 2048, ks 11) as targets,
     one MLP forward/backward/AdamW step in torch (bf16 autocast on the MLP).  Not the BASELINE.json metric."""
-    import torch.nn as nn
     from aadff.synth import mlp_state_dict
     from deeplens.psfnet import PSFNet
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     net = PSFNet(os.path.join(REPO, "lenses", "rf50mm", "lens.json"), sensor_res=(512, 512), kernel_size=KS, device=dev)
     net.psfnet.load_state_dict({k: torch.from_numpy(v) for k, v in mlp_state_dict(seed=4321).items()})
+    from deeplens.psfnet import _TrainStep
     bs, spp = 128, SPP
-    cri = nn.MSELoss()
-    optim = torch.optim.AdamW(net.psfnet.parameters(), 1e-4)
     steps = min(args.steps, 100) if args.steps == 200 else args.steps
+    step = _TrainStep(net.psfnet, 1e-4, 10000, bs, KS * KS, dev, True, os.environ.get("AADFF_FIT_GRAPH", "1") != "0")
     t_data = [0.0]
 
     def it(i):
@@ -285,12 +284,7 @@ def main_fit(args):
         inp, psf = net.get_training_data(bs=bs, spp=spp)
         inp, psf = inp.to(dev), psf.to(dev)
         t_data[0] += time.perf_counter() - t0
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            pred = net.psfnet(inp)
-        optim.zero_grad()
-        loss = cri(pred.float(), psf)
-        loss.backward()
-        optim.step()
+        step(inp, psf)
 
     for i in range(min(args.warmup, 10)):
         it(i)

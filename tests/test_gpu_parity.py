@@ -618,6 +618,39 @@ def test_train_psfnet_runs_and_checkpoints(repo_root, tmp_path):
         assert getattr(net2, k) == pytest.approx(getattr(Lensgroup(lens_path(repo_root), sensor_res=(480, 640), device=DEV), k), rel=1e-6)
 
 
+def test_graph_captured_training_step_matches_eager(repo_root):
+    """train_psfnet's HIP-graph step (static buffers, capturable AdamW, closed-form cosine schedule) follows the
+    eager torch loop with CosineAnnealingLR: same weights after 8 iterations on the same data."""
+    from deeplens.psfnet import _TrainStep
+    rng = np.random.Generator(np.random.PCG64(9))
+    data = [(tt(rng.random((32, 4), dtype=np.float32)).to(DEV), tt(rng.random((32, 121), dtype=np.float32)).to(DEV) / 121)
+            for _ in range(8)]
+    sd0 = {k: tt(v) for k, v in mlp_state_dict(seed=77).items()}
+    nets = []
+    for mode in ("graph", "eager", "reference"):
+        net = PSFNet(lens_path(repo_root), sensor_res=(64, 64), kernel_size=11, device=DEV)
+        net.psfnet.load_state_dict(sd0)
+        if mode == "reference":
+            opt = torch.optim.AdamW(net.psfnet.parameters(), 1e-3)
+            sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=20, eta_min=0)
+            for inp, psf in data:
+                pred = net.psfnet(inp)
+                opt.zero_grad()
+                torch.nn.functional.mse_loss(pred.float(), psf).backward()
+                opt.step()
+                sch.step()
+        else:
+            step = _TrainStep(net.psfnet, 1e-3, 20, 32, 121, torch.device(DEV), False, mode == "graph")
+            for inp, psf in data:
+                step(inp, psf)
+            assert (step.graph is not None) == (mode == "graph")
+        torch.cuda.synchronize()
+        nets.append({k: v.detach().cpu().numpy() for k, v in net.psfnet.state_dict().items()})
+    for k in nets[0]:
+        assert rel_l2(nets[0][k], nets[2][k]) <= 1e-4 or np.abs(nets[0][k] - nets[2][k]).max() <= 1e-6, k
+        assert rel_l2(nets[1][k], nets[2][k]) <= 1e-4 or np.abs(nets[1][k] - nets[2][k]).max() <= 1e-6, k
+
+
 def test_render_single_img_psf_branch(repo_root):
     """Lensgroup.render_single_img(method='psf'): 7x7 grid, ks 21 - the only in-repo caller of render_psf_map
     in the reference (deeplens/optics.py:779-783)."""
