@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--device-rng", action="store_true", help="draw pupil samples on the GPU (not sample-comparable)")
     ap.add_argument("--spinup-s", type=float, default=0.3, help="untimed device spin-up before the warm-up steps [s]")
+    ap.add_argument("--conv-events-every", type=int, default=8,
+                    help="bracket the conv launch with HIP events on every n-th timed step (an event pair costs ~6 us of queue gap)")
     ap.add_argument("--mode", choices=("m1", "m2", "fit"), default="m1",
                     help="m1 (default, BASELINE.json metric): ray-traced PSF grid + patch convolution; "
                          "m2: RGB-D stack through the PSF surrogate network (PSFNet.render, SURVEY.md 8f-1); "
@@ -113,7 +115,9 @@ def main():
         lens.sampler = DeviceSampler(dev, seed=rank)
     img = img_h.to(dev)
     plan = StackPlan(lens, S, H, W, 1, 3, GRID, KS, SPP)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events bracket the conv launch on every `--conv-events-every`-th timed step
+    ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for i in range(0, args.steps, max(1, args.conv_events_every))}
 
     gathered = comm = None
     if world > 1 and args.gather:
@@ -122,7 +126,7 @@ def main():
 
     def step(i, timed):
         torch.manual_seed(i)
-        if timed:
+        if timed and i in ev:
             plan.conv_events = ev[i]
         out = render_focal_stack_m1(lens, img, dbar, fds, GRID, KS, SPP, plan=plan, update_lens=False)
         plan.conv_events = None
@@ -159,7 +163,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    conv_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    conv_ms = float(np.mean([a.elapsed_time(b) for a, b in ev.values()]))
     achieved = ALG_BYTES_PER_SLICE * S / (conv_ms * 1e-3)
     traffic = None
     tpath = os.path.join(REPO, "profiles", "conv_traffic.json")
