@@ -56,7 +56,8 @@ class StackPlan:
     """Pre-allocated device buffers, cached lens tables and a pinned-host ring for the pupil
     samples of repeated M1 stacks of one shape.  The ring lets the host draw step i+1's
     samples while the GPU renders step i (copies are asynchronous from pinned memory)."""
-    RING = 3
+    RING = 8           # pinned/device uniform blocks in flight
+    GUARD_EVERY = 4    # staged path: one guard event per 4 steps protects the reuse of a pinned block RING steps later
 
     def __init__(self, lens, S, H, W, B=1, C_=3, grid=11, ks=11, spp=GEO_SPP):
         dev = lens._gpu()
@@ -74,6 +75,7 @@ class StackPlan:
         self.u_dev = [torch.empty(S * self.per, dtype=torch.float32, device=dev) for _ in range(self.RING)]
         self.u_pin = [torch.empty(S * self.per, dtype=torch.float32).pin_memory() for _ in range(self.RING)]
         self.u_evt = [None] * self.RING
+        self.guards = {}
         self.turn = 0
         # staged upload (aadff_refocus_staged + aadff_psf_points_staged): the first STAGE_FIRST states' draws are
         # copied behind the focus traces, the rest by leading workgroups of the PSF launch
@@ -105,9 +107,15 @@ class StackPlan:
         """(pinned host block, device block) of this step's uniforms WITHOUT the upload: the caller hands
         both to aadff_refocus_staged, which copies inside the refocus launch, then calls `staged()`."""
         k = self.turn % self.RING
+        last = self.turn - self.RING                # step that last used this block
         self.turn += 1
         if self.u_evt[k] is not None:
-            self.u_evt[k].synchronize()          # the launch that last read this pinned slot has finished
+            self.u_evt[k].synchronize()          # (copy path) the upload that last used this pinned slot has finished
+            self.u_evt[k] = None
+        if last >= 0:
+            g = self.guards.get(last // self.GUARD_EVERY)     # recorded at step 4 m + 3 >= last, at least 4 steps ago
+            if g is not None:
+                g.synchronize()
         if hasattr(sampler, "rand_into"):
             sampler.rand_into(self.u_pin[k])
         else:
@@ -115,9 +123,16 @@ class StackPlan:
         return self.u_pin[k], self.u_dev[k]
 
     def staged(self):
-        k = (self.turn - 1) % self.RING
-        self.u_evt[k] = torch.cuda.Event()
-        self.u_evt[k].record()
+        """End of a staged step: every GUARD_EVERY-th step records the event later reuses of the pinned blocks wait on
+        (an event record per step costs ~3 us of queue gap)."""
+        step = self.turn - 1
+        if step % self.GUARD_EVERY == self.GUARD_EVERY - 1:
+            e = torch.cuda.Event()
+            e.record()
+            m = step // self.GUARD_EVERY
+            self.guards[m] = e
+            for old in [q for q in self.guards if q < m - self.RING // self.GUARD_EVERY - 1]:
+                del self.guards[old]
 
     def geometry(self, focus, depth_plane_mm):
         key = (tuple(focus), float(depth_plane_mm))
