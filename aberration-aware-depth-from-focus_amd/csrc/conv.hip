@@ -268,7 +268,7 @@ template <int KS, int NW, int SPW>
 __global__ __launch_bounds__(64 * NW) void conv_psf_map_mfma_kernel(
     const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, int C, int S, int H, int W,
     int grid, int ntx, int nty, PatchBounds pb) {
-    constexpr int PAD = KS / 2, TWP = TW + KS - 1, THP = TH + KS - 1, P = 48, KK = KS * KS;
+    constexpr int PAD = KS / 2, TWP = TW + KS - 1, THP = TH + KS - 1, P = 48;
     static_assert(16 + KS - 1 <= 32 && TWP <= P, "Toeplitz band must fit K = 32");
     __shared__ __attribute__((aligned(16))) _Float16 Ahi[THP * P];
     __shared__ __attribute__((aligned(16))) _Float16 Alo[THP * P];

@@ -21,8 +21,7 @@ constexpr float kTolTight = 10e-6f;      // deeplens/surfaces.py:27
 constexpr float kTolLoose = 50e-6f;      // deeplens/surfaces.py:28
 constexpr float kStepBound = 5.f;        // deeplens/surfaces.py:29
 constexpr float kStepConverged = 1e-3f;  // fused kernels: a Newton update below 1 um ends the loop (see newton2)
-constexpr int AADFF_SPHERIC_CLOSED_FORM = AADFF_SURF_SPHERIC;
-constexpr float kTwoPiHi = 3.14159274101257324f;   // (float)np.pi
+[[maybe_unused]] constexpr float kTwoPiHi = 3.14159274101257324f;   // (float)np.pi (libm sin/cos builds)
 
 struct Ray {
     float ox, oy, oz, dx, dy, dz, ra;
