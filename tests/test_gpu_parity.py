@@ -389,6 +389,37 @@ def test_psf_map_signature_defaults_ks51(repo_root):
     assert rel_l2(out, ref) <= IMG_TOL
 
 
+@pytest.mark.parametrize("variant", ["conic", "hyperbolic", "degree5", "degree8"])
+def test_conic_and_hyperbolic_aspheres_vs_oracle(repo_root, tmp_path, variant):
+    """Branches rf50mm does not reach: an asphere with conic constant k != 0 (shape-domain test k > -1, Newton start
+    from the conic root) and one with k <= -1 (no shape-domain limit); refocus scalars, PSFs and the in-place /
+    compacted fused trace against the oracle on the same RNG stream."""
+    d = json.load(open(lens_path(repo_root)))
+    if variant == "conic":
+        d["surfaces"][2].update({"type": "Aspheric", "k": -0.6, "ai": [0.0, 1.5e-6, -2e-9, 0.0, 0.0, 0.0]})
+        d["surfaces"][8]["k"] = 0.35
+    elif variant == "hyperbolic":
+        d["surfaces"][8]["k"] = -1.5
+        d["surfaces"][9]["k"] = -1.0
+    elif variant == "degree5":                                   # five even-asphere coefficients (reference: surfaces.py:314)
+        d["surfaces"][8]["ai"] = d["surfaces"][8]["ai"][:5]
+    else:                                                        # eight: the kernels' AADFF_MAX_AI Horner branch
+        d["surfaces"][9]["ai"] = list(d["surfaces"][9]["ai"]) + [3e-16, -1e-18]
+    path = str(tmp_path / "lens.json")
+    json.dump(d, open(path, "w"))
+    pts = torch.tensor([[0.0, 0.0, -2000.0], [0.6, 0.6, -1200.0], [-0.9, 0.3, -5000.0], [0.2, -0.98, -800.0]])
+    ora = OracleLens(path, sensor_res=(512, 512))
+    torch.manual_seed(13)
+    ora.refocus(-1800.0)
+    want = ora.psf(pts, ks=11, spp=2048).numpy()
+    lens = Lensgroup(path, sensor_res=(512, 512), device=DEV)
+    torch.manual_seed(13)
+    lens.refocus(-1800.0)
+    assert lens.d_sensor == pytest.approx(ora.d_sensor, rel=1e-5) and lens.hfov == pytest.approx(ora.hfov, rel=1e-5)
+    got = lens.psf(pts, ks=11, spp=2048).cpu().numpy()
+    assert rel_l2(got, want) <= PSF_TOL
+
+
 def test_psf_rgb_layout_matches_psf_map(repo_root):
     lens = Lensgroup(lens_path(repo_root), sensor_res=(256, 256), device=DEV)
     torch.manual_seed(1)
