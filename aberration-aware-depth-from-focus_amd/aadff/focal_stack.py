@@ -134,6 +134,14 @@ class StackPlan:
             for old in [q for q in self.guards if q < m - self.RING // self.GUARD_EVERY - 1]:
                 del self.guards[old]
 
+    def check_flags(self):
+        """Raise the reference's errors for anything the kernels of earlier steps flagged (synchronises)."""
+        from deeplens.optics import raise_psf_flags
+        bits = int(self.flags.item())
+        if bits:
+            self.flags.zero_()
+        raise_psf_flags(bits)
+
     def geometry(self, focus, depth_plane_mm):
         key = (tuple(focus), float(depth_plane_mm))
         if key != self._geo_key:
@@ -155,7 +163,8 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
     S = len(focus)
     B, C_, H, W = img.shape
     assert tuple(lens.sensor_res) == (H, W), "lens.sensor_res must match the image"
-    if plan is None:
+    own_plan = plan is None
+    if own_plan:
         plan = StackPlan(lens, S, H, W, B, C_, grid, ks, spp)
     dev = plan.dev
     with torch.cuda.device(dev):
@@ -201,6 +210,8 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
         nb = C.sizeof(_abi.LensState)
         lens._state_device().copy_(plan.states[(S - 1) * nb:S * nb])
         lens._state_stale = True
+    if own_plan:
+        plan.check_flags()                               # one-shot calls: same sync point as the reference's asserts
     return (plan.out, plan.psf_maps) if return_maps else plan.out
 
 

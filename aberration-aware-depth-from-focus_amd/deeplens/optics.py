@@ -31,6 +31,16 @@ from .surfaces import Aspheric, pack_table, trace_ray_object
 from .utils import *             # noqa: F401,F403
 
 
+def raise_psf_flags(bits):
+    """Flags word of aadff_psf_points -> the reference's errors (bit 0: NaN in a Newton residual, surfaces.py:555-558;
+    bit 1: no valid chief ray for some point, optics.py:901; bit 3: staged upload timed out)."""
+    if bits & 1:
+        raise FloatingPointError("found nan in ft in non-diff newton method.")
+    if bits & 8:
+        raise RuntimeError("aadff: staged upload of the pupil samples timed out")
+    assert not bits & 2, "No sampled rays is valid."
+
+
 class Lensgroup(DeepObj):
     def __init__(self, filename=None, sensor_res=(1024, 1024), use_roc=False, post_computation=True, device=DEVICE):
         self.device = torch.device(device) if not isinstance(device, torch.device) else device
@@ -366,6 +376,8 @@ class Lensgroup(DeepObj):
                       _abi.ptr(u_main), spp, 2 * L * spp, 2 * spp, _abi.ptr(u_chief), GEO_SPP, 2 * L * GEO_SPP, 2 * GEO_SPP,
                       ks, int(bool(center)), int(map_layout),
                       _abi.ptr(out), None, _abi.ptr(flags), _abi.stream_ptr(dev))
+        if getattr(self, "check_flags", True):
+            raise_psf_flags(int(flags.item()))          # the reference asserts inside psf_center (optics.py:901): same sync point
         return out.to(self.device) if self.device.type != "cuda" else out
 
     def psf(self, points, ks=31, wvln=DEFAULT_WAVE, spp=GEO_SPP, center=True):

@@ -420,6 +420,17 @@ def test_conic_and_hyperbolic_aspheres_vs_oracle(repo_root, tmp_path, variant):
     assert rel_l2(got, want) <= PSF_TOL
 
 
+def test_no_valid_chief_ray_raises_like_the_reference(repo_root):
+    """A point far outside the field loses every chief ray: the reference asserts "No sampled rays is valid."
+    (optics.py:901); the kernels flag it and the Python mirror raises the same AssertionError."""
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(256, 256), device=DEV)
+    torch.manual_seed(0)
+    with pytest.raises(AssertionError, match="No sampled rays is valid"):
+        lens.psf(torch.tensor([[40.0, 40.0, -300.0]]), ks=11, spp=256)
+    torch.manual_seed(0)
+    assert lens.psf(torch.tensor([[0.1, 0.1, -1500.0]]), ks=11, spp=256).shape == (1, 11, 11)      # the lens is still usable
+
+
 def test_psf_rgb_layout_matches_psf_map(repo_root):
     lens = Lensgroup(lens_path(repo_root), sensor_res=(256, 256), device=DEV)
     torch.manual_seed(1)
