@@ -288,6 +288,8 @@ def render_focal_stack_m2(lens, img, depth_m, n_stack):
     the 'linear' rule, slices via lens.render(img, -depth*1e3, -f*1e3)
     (reference: 2_aber_aware_dff_aif.py:104-114)."""
     fds = select_focus_dist(depth_m, n_stack)
+    if hasattr(lens, "render_stack") and len(img.shape) == 4:        # PSFNet: the whole stack in one fused launch
+        return lens.render_stack(img, -depth_m * 1e3, -fds * 1e3), fds
     return torch.stack([lens.render(img, -depth_m * 1e3, -fds[:, i] * 1e3) for i in range(n_stack)], dim=2), fds
 
 

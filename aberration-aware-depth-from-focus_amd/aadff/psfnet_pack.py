@@ -58,8 +58,9 @@ class PackedMLP:
         return tuple((p.data_ptr(), p._version) for l in linears_of(mlp) for p in (l.weight, l.bias))
 
 
-def forward(packed, inp, mode, img=None, ks=0):
-    """mode 0: [P,4] -> [P,n_out] normalised PSFs; mode 1: img [N,C,H,W] + inp [N*H*W,4] -> [N,C,H,W]."""
+def forward(packed, inp, mode, img=None, ks=0, slices=0):
+    """mode 0: [P,4] -> [P,n_out] normalised PSFs; mode 1: img [N,C,H,W] + inp [N*H*W,4] -> [N,C,H,W], or with
+    slices = S: inp [N*S*H*W,4] (rows ordered [n][slice][y][x]) -> [N,C,S,H,W] in one launch."""
     dev = inp.device
     inp = _abi.f32c(inp, dev).reshape(-1, 4)
     P = inp.shape[0]
@@ -68,15 +69,15 @@ def forward(packed, inp, mode, img=None, ks=0):
         if mode == 0:
             out = torch.empty((P, packed.n_out), dtype=torch.float32, device=dev)
             _abi.call("aadff_psfnet_forward", _abi.ptr(inp), P, _abi.ptr(packed.wpack), _abi.ptr(packed.bias), packed.n,
-                      packed.ins, packed.outs, 0, _abi.ptr(out), None, None, 0, 0, 0, 0, st)
+                      packed.ins, packed.outs, 0, _abi.ptr(out), None, None, 0, 0, 0, 0, 0, st)
             return out
         x = _abi.f32c(img, dev)
         N, Cc, H, W = x.shape
-        out = torch.empty_like(x)
+        out = torch.empty((N, Cc, slices, H, W), dtype=torch.float32, device=dev) if slices else torch.empty_like(x)
         if EVENT_HOOK is not None:
             EVENT_HOOK(True)
         _abi.call("aadff_psfnet_forward", _abi.ptr(inp), P, _abi.ptr(packed.wpack), _abi.ptr(packed.bias), packed.n,
-                  packed.ins, packed.outs, 1, None, _abi.ptr(x), _abi.ptr(out), Cc, H, W, ks, st)
+                  packed.ins, packed.outs, 1, None, _abi.ptr(x), _abi.ptr(out), Cc, H, W, ks, int(slices), st)
         if EVENT_HOOK is not None:
             EVENT_HOOK(False)
         return out

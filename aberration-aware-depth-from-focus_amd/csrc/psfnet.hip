@@ -12,6 +12,7 @@
 // B operand = activations (ds_read_b128, 16-byte slots XOR-swizzled by the pixel: conflict-free); D^T puts 4 consecutive features of
 // one pixel in a lane, so bias + ReLU + split + one 8-byte LDS store per plane write the next layer's input.
 // Wave w owns feature tiles w, w + 8 (16 features each) for all 128 pixels: 64 accumulator registers.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -66,7 +67,7 @@ template <int TP>
 __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(const float* __restrict__ inp, long P, const uint4v* __restrict__ wpack,
                                                            const float* __restrict__ bias, Layers L, int nout, int mode,
                                                            float* __restrict__ psf_out, const float* __restrict__ img,
-                                                           float* __restrict__ out, int C, int H, int W, int ks) {
+                                                           float* __restrict__ out, int C, int H, int W, int ks, int out_slices) {
     __shared__ __attribute__((aligned(16))) _Float16 act[2][TP * AP];          // 135 168 B; reused for the fp32 PSFs at the end
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -212,8 +213,11 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
                 for (int t = q; t < nout; t += TPP) o[t] = row[t] * inv;
             } else {
                 const long hw = (long)H * W;
-                const long nimg = gp / hw;
+                const long nimg = gp / hw;                  // image index; with out_slices = S it is (b, slice): b * S + slice
                 const int rem = (int)(gp - nimg * hw);
+                const long bimg = out_slices > 0 ? nimg / out_slices : nimg;
+                const long sl = out_slices > 0 ? nimg - bimg * out_slices : 0;
+                const long oslices = out_slices > 0 ? out_slices : 1;
                 const int y = rem / W, x = rem - y * W;
                 const int pad = ks >> 1;
                 // thread q of the pixel takes tap columns q, q + TPP, ... of every tap row: clamped columns once
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
 #pragma unroll
                 for (int k = 0; k < MAXV; ++k) xv[k] = min(max(x + q + k * TPP - pad, 0), W - 1);
                 for (int c = 0; c < C; ++c) {
-                    const float* plane = img + (nimg * C + c) * hw;
+                    const float* plane = img + (bimg * C + c) * hw;
                     float a = 0.f;
                     for (int u = 0; u < ks; ++u) {
                         const float* ir = plane + (size_t)min(max(y + u - pad, 0), H - 1) * W;
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
                     }
 #pragma unroll
                     for (int m = 1; m < TPP; m <<= 1) a += __shfl_xor(a, m, kWave);
-                    if (q == 0) out[(nimg * C + c) * hw + rem] = a * inv;
+                    if (q == 0) out[((bimg * C + c) * oslices + sl) * hw + rem] = a * inv;
                 }
             }
         }
@@ -249,7 +253,8 @@ extern "C" {
 
 int aadff_psfnet_forward(const float* inp, long P, const void* wpack, const float* bias, int n_layers,
                          const int* in_features, const int* out_features, int mode, float* psf_out,
-                         const float* img, float* out, int C, int H, int W, int ks, aadff_stream_t stream) {
+                         const float* img, float* out, int C, int H, int W, int ks, int out_slices,
+                         aadff_stream_t stream) {
     AADFF_CHECK_ARG(inp && wpack && bias && in_features && out_features, "psfnet_forward: NULL pointer");
     AADFF_CHECK_ARG(n_layers >= 1 && n_layers <= AADFF_PSFNET_MAX_LAYERS, "psfnet_forward: %d layers outside [1,%d]", n_layers, AADFF_PSFNET_MAX_LAYERS);
     AADFF_CHECK_ARG(P >= 0 && P < (1L << 40), "psfnet_forward: bad P");
@@ -274,16 +279,18 @@ int aadff_psfnet_forward(const float* inp, long P, const void* wpack, const floa
     AADFF_CHECK_ARG(mode == 0 || ks * ks == nout, "psfnet_forward: ks %d does not match %d outputs", ks, nout);
     if (P == 0) return 0;
     AADFF_CHECK_ARG(mode == 0 || P % ((long)H * W) == 0, "psfnet_forward: P is not a whole number of images");
+    AADFF_CHECK_ARG(out_slices >= 0 && (mode == 0 || out_slices == 0 || (P / ((long)H * W)) % out_slices == 0),
+                    "psfnet_forward: %ld images are not a whole number of %d-slice stacks", P / std::max(1L, (long)H * W), out_slices);
     int tp = 64;                       // measured at 1024^2: 64 -> 3.09 ms, 128 -> 3.46 ms
     if (const char* e = getenv("AADFF_PSFNET_TP")) tp = atoi(e) == 128 ? 128 : 64;
     const long nwg = (P + tp - 1) / tp;
     AADFF_CHECK_ARG(nwg < (1L << 31), "psfnet_forward: too many pixels");
     if (tp == 128)
         hipLaunchKernelGGL(pn::psfnet_fused_kernel<128>, dim3((unsigned)nwg), dim3(pn::NTH), 0, (hipStream_t)stream, inp, P,
-                           reinterpret_cast<const pn::uint4v*>(wpack), bias, L, nout, mode, psf_out, img, out, C, H, W, ks);
+                           reinterpret_cast<const pn::uint4v*>(wpack), bias, L, nout, mode, psf_out, img, out, C, H, W, ks, out_slices);
     else
         hipLaunchKernelGGL(pn::psfnet_fused_kernel<64>, dim3((unsigned)nwg), dim3(pn::NTH), 0, (hipStream_t)stream, inp, P,
-                           reinterpret_cast<const pn::uint4v*>(wpack), bias, L, nout, mode, psf_out, img, out, C, H, W, ks);
+                           reinterpret_cast<const pn::uint4v*>(wpack), bias, L, nout, mode, psf_out, img, out, C, H, W, ks, out_slices);
     AADFF_CHECK_LAUNCH();
     return 0;
 }

@@ -183,6 +183,26 @@ class PSFNet(Lensgroup):
         psf = self._pred_chunked(o)
         return local_psf_render(img, psf, self.kernel_size)
 
+    @torch.no_grad()
+    def render_stack(self, img, depth, foc_dists):
+        """[N,C,S,H,W] focal stack of img [N,C,H,W] for depth [N,1,H,W] (mm, < 0) and focus distances [N,S] (mm, < 0):
+        the loop `stack([render(img, depth, foc_dists[:, i]) for i], dim=2)` of 2_aber_aware_dff_aif.py:104-114 as
+        ONE fused launch when the fused kernel applies, else that loop."""
+        dev = next(self.psfnet.parameters()).device
+        N, C, H, W = img.shape
+        foc_dists = foc_dists.to(dev).reshape(N, -1)
+        S = foc_dists.shape[1]
+        packed = self._fused(dev)
+        if packed is None:
+            return torch.stack([self.render(img, depth, foc_dists[:, i]) for i in range(S)], dim=2)
+        from aadff import psfnet_pack
+        z = self.depth2z(depth.to(dev)).reshape(N, 1, H, W).expand(N, S, H, W)
+        x, y = self._field_grid(H, W, dev)
+        foc_z = self.depth2z(foc_dists).reshape(N, S, 1, 1).expand(N, S, H, W)
+        o = torch.stack((x.expand(N, S, H, W), y.expand(N, S, H, W), z, foc_z), -1).float()
+        out = psfnet_pack.forward(packed, o.reshape(-1, 4), 1, img=img.to(dev), ks=self.kernel_size, slices=S)
+        return out.to(img.device)
+
     def _field_grid(self, H, W, dev):
         """x = linspace(-1,1,W) over columns, y = linspace(1,-1,H) over rows (reference: psfnet.py:427-431),
         cached per (H, W, device)."""

@@ -202,6 +202,8 @@ int aadff_psf_points_staged(const float* points, int S, int N, int L,
  * -> mode 0: psf_out[P][n_out] (PSFNet.pred, deeplens/psfnet.py:375-390, psfnet_arch.py:24-47), or
  *    mode 1: out[N][C][H][W] = per-pixel PSF gather over img (PSFNet.render + local_psf_render,
  *            deeplens/psfnet.py:393-441, deeplens/render_psf.py:76-107; P = N*H*W, ks*ks = n_out).
+ *            out_slices = S > 0: a whole focal stack in one launch (2_aber_aware_dff_aif.py:104-114): inp holds
+ *            P = B*S*H*W rows ordered [b][slice][y][x], img is [B][C][H][W], out is [B][C][S][H][W].
  * Layer l maps in_features[l] -> out_features[l] (widths <= 256, in_features[0] == 4, n_out <= 128).
  * wpack: the weights as exact fp16 (hi, lo) pairs in MFMA fragment order, per layer
  *   [out tile 16][k-step 32][plane hi|lo][lane 64][8 halves]: lane (m = lane&15, kg = lane>>4) holds
@@ -210,7 +212,8 @@ int aadff_psf_points_staged(const float* points, int S, int N, int L,
 #define AADFF_PSFNET_MAX_LAYERS 16
 int aadff_psfnet_forward(const float* inp, long P, const void* wpack, const float* bias, int n_layers,
                          const int* in_features, const int* out_features, int mode, float* psf_out,
-                         const float* img, float* out, int C, int H, int W, int ks, aadff_stream_t stream);
+                         const float* img, float* out, int C, int H, int W, int ks, int out_slices,
+                         aadff_stream_t stream);
 
 /* Refocus S lens states in one launch: trace spp rays from (0,0,depth[s]) (green table),
  * least-squares axis crossing -> d_sensor, then hfov/foclen/fnum.  Replaces

@@ -549,6 +549,18 @@ def test_fused_render_equals_torch_mlp_plus_gather(psfnet64):
     assert rel_l2(fused.cpu().numpy(), ref.cpu().numpy()) <= 2e-6
 
 
+def test_render_stack_equals_per_slice_render(psfnet64):
+    """PSFNet.render_stack (a whole [N,C,S,H,W] stack in one fused launch) == stacking render() slice by slice."""
+    rng = np.random.Generator(np.random.PCG64(81))
+    img = tt(rng.random((2, 3, 64, 64), dtype=np.float32)).to(DEV)
+    depth = -tt(rng.random((2, 1, 64, 64), dtype=np.float32) * 4000 + 300).to(DEV)
+    fds = -tt(np.sort(rng.random((2, 5), dtype=np.float32) * 4000 + 400, axis=1)).to(DEV)
+    stack = psfnet64.render_stack(img, depth, fds)
+    assert stack.shape == (2, 3, 5, 64, 64)
+    for i in range(5):
+        assert (stack[:, :, i] - psfnet64.render(img, depth, fds[:, i])).abs().max().item() <= 1e-6, i
+
+
 def test_psfnet_render_golden(g67, psfnet64):
     img = tt(synth_rgb(64, 64, seed=11))[None].to(DEV)
     depth = -tt(synth_depth_mm(64, 64, seed=12))[None, None].to(DEV)
