@@ -60,21 +60,31 @@ class _TrainStep:
         else:
             self.inp.copy_(inp)
             self.psf.copy_(psf)
-            if self.t < 3:                                   # eager warm-up on a side stream (torch's capture recipe)
-                side = torch.cuda.Stream(self.dev)
-                side.wait_stream(torch.cuda.current_stream(self.dev))
-                with torch.cuda.stream(side):
+            if self.t < 3:                                   # eager warm-up on the capture stream (torch's capture recipe)
+                self.side = getattr(self, "side", None) or torch.cuda.Stream(self.dev)
+                self.side.wait_stream(torch.cuda.current_stream(self.dev))
+                with torch.cuda.stream(self.side):
                     self.optim.zero_grad(set_to_none=True)
                     pred = self._body(self.inp, self.psf)
-                torch.cuda.current_stream(self.dev).wait_stream(side)
+                torch.cuda.current_stream(self.dev).wait_stream(self.side)
             else:
                 if self.graph is None:                       # capture records only: the replay below runs this step
-                    self.graph = torch.cuda.CUDAGraph()
+                    graph = torch.cuda.CUDAGraph()
                     self.optim.zero_grad(set_to_none=True)
-                    with torch.cuda.graph(self.graph):
-                        self.pred = self._body(self.inp, self.psf)
-                self.graph.replay()
-                pred = self.pred
+                    try:
+                        with torch.cuda.graph(graph, stream=self.side):
+                            self.pred = self._body(self.inp, self.psf)
+                        self.graph = graph
+                    except RuntimeError as e:                 # capture refused: run this and all later steps eagerly
+                        import logging
+                        logging.getLogger(__name__).warning("train step not graph-capturable (%s): running eagerly", e)
+                        self.use_graph, self.graph = "eager-static", None
+                if self.graph is not None:
+                    self.graph.replay()
+                    pred = self.pred
+                else:
+                    self.optim.zero_grad(set_to_none=True)
+                    pred = self._body(self.inp, self.psf)
         self.t += 1
         new_lr = 0.5 * self.lr0 * (1.0 + math.cos(math.pi * min(self.t, self.T) / self.T))
         for g in self.optim.param_groups:
