@@ -259,6 +259,7 @@ class PSFNet(Lensgroup):
         for i in tqdm(range(iters + 1)):
             inp, psf = self.get_training_data(bs=bs, spp=spp)
             pred = step(inp.to(dev), psf.to(dev))
+            self._packed = None        # graph replays update the weights without bumping tensor versions: repack on next use
             if (i + 1) % evaluate_every == 0:
                 ks = self.kernel_size
                 psf = psf.to(dev)

@@ -705,6 +705,23 @@ def test_graph_captured_training_step_matches_eager(repo_root):
         assert rel_l2(nets[1][k], nets[2][k]) <= 1e-4 or np.abs(nets[1][k] - nets[2][k]).max() <= 1e-6, k
 
 
+def test_fused_inference_sees_weights_after_graph_training(repo_root, tmp_path):
+    """The packed weights of the fused kernel are rebuilt after train_psfnet (graph replays do not bump tensor versions)."""
+    net = PSFNet(lens_path(repo_root), sensor_res=(64, 64), kernel_size=11, device=DEV)
+    net.psfnet.load_state_dict({k: tt(v) for k, v in mlp_state_dict(seed=4321).items()})
+    x = tt(np.random.Generator(np.random.PCG64(5)).random((50, 4), dtype=np.float32)).to(DEV)
+    with torch.no_grad():
+        before = net.pred(x).clone()
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net.train_psfnet(iters=6, bs=16, lr=1e-3, spp=256, evaluate_every=1000, result_dir=str(tmp_path))
+    with torch.no_grad():
+        fused = net.pred(x)
+        ref = net.psfnet(x).reshape(50, 11, 11)
+    assert (fused - ref).abs().max().item() <= 2e-7
+    assert (fused - before).abs().max().item() > 1e-6          # the weights did move
+
+
 def test_render_single_img_psf_branch(repo_root):
     """Lensgroup.render_single_img(method='psf'): 7x7 grid, ks 21 - the only in-repo caller of render_psf_map
     in the reference (deeplens/optics.py:779-783)."""
