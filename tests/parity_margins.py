@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Print the actual parity errors (not just pass/fail) of the HIP path vs the golden vectors."""
 import os, sys
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root (uses the oracle: lives under tests/)
 sys.path[:0] = [REPO, os.path.join(REPO, "aberration-aware-depth-from-focus_amd")]
 import numpy as np, torch, importlib
 from aadff import _abi
