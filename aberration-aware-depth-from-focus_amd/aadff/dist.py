@@ -1,19 +1,68 @@
 """One process per GPU: shard (scene, slice) units across ranks and, when a single consumer needs
 the whole result, reassemble it with ONE all-gather (RCCL over xGMI on the GPU box, gloo in the CPU
-tests).  The path has no other exchange step: units are independent.
+tests and in the one-GPU rank emulation).  The path has no other exchange step: units are
+independent.
+
+Launching: `spawn_ranks` starts N copies of a script BEFORE anything has touched the GPU (the parent
+never makes a HIP call; a child owns its device).  `--emulate-ranks` puts all N ranks on GPU 0 with
+the gloo backend, because RCCL refuses two ranks on one device: the launcher, the `u = r (mod N)`
+sharding and the gather order are then exercised on a one-GPU box; xGMI is not.
 """
 import os
+import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
 
 
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(argv, world, emulate=False, env=None, timeout=None):
+    """Run `python argv...` as `world` rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) and wait.
+    Returns the largest exit code.  The caller must not have initialised the GPU (no HIP call, no
+    torch.cuda.is_available()): on this pool a GPU-initialised parent must not start GPU children by exec, and a
+    parent that holds a context would also take memory on device 0."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        e = dict(os.environ if env is None else env)
+        e.update(RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0" if emulate else str(r),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this host driver
+        if emulate:
+            e["AADFF_EMULATE_RANKS"] = "1"
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait(timeout=timeout)))
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                 # exact PIDs we started
+    return rc
+
+
+def emulated():
+    return os.environ.get("AADFF_EMULATE_RANKS", "0") == "1"
+
+
 def init_from_env(backend=None, device=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
-    Returns (rank, world).  Single-process runs need no group."""
+    Returns (rank, world).  Single-process runs need no group.  Ranks emulated on one GPU use gloo."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        if emulated():
+            backend = "gloo"
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
@@ -30,11 +79,80 @@ def padded_share(n_units, world):
     return (n_units + world - 1) // world
 
 
+def _host_backend():
+    return dist.get_backend() == "gloo"
+
+
+def all_gather_into(full, local):
+    """dist.all_gather_into_tensor on flat views (gloo only accepts the concatenated form) that also works for
+    device tensors under gloo (staged through the host; only the emulation and the CPU tests take that road)."""
+    assert full.is_contiguous() and local.is_contiguous() and full.numel() == local.numel() * dist.get_world_size()
+    if local.is_cuda and _host_backend():
+        h = torch.empty(full.numel(), dtype=full.dtype)
+        dist.all_gather_into_tensor(h, local.reshape(-1).cpu())
+        full.view(-1).copy_(h)
+    else:
+        dist.all_gather_into_tensor(full.view(-1), local.view(-1))
+
+
+def all_reduce_max(value):
+    """max over ranks of a Python float (timing): a host tensor under gloo, a device tensor under RCCL."""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if _host_backend() else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def unit_order(full, n_units, world, share):
+    """rank-major [world*share, ...] (what the all-gather delivers) -> unit order u = i*world + r."""
+    shape = tuple(full.shape[1:])
+    return full.reshape((world, share) + shape).transpose(0, 1).reshape((world * share,) + shape)[:n_units]
+
+
+class GatherRing:
+    """Overlaps the all-gather of step i with the rendering of step i+1.
+
+    The renderer writes into `slots` output buffers in turn; `submit(buf)` enqueues the all-gather of that
+    buffer on a side stream behind the work already queued on the current stream and returns at once.
+    Before a buffer is handed out again (`acquire`), the current stream waits for the gather that last read
+    it.  With 2 slots the compute stream therefore never waits for the gather of the step just finished."""
+
+    def __init__(self, make_local, world, slots=2, device=None):
+        self.dev = device
+        self.local = [make_local() for _ in range(slots)]
+        self.full = [torch.empty((world,) + tuple(self.local[0].shape), dtype=self.local[0].dtype, device=self.local[0].device)
+                     for _ in range(slots)]
+        self.done = [None] * slots
+        self.stream = torch.cuda.Stream(device)
+        self.turn = 0
+
+    def acquire(self):
+        k = self.turn % len(self.local)
+        if self.done[k] is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self.done[k])
+        return k, self.local[k]
+
+    def submit(self, k):
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.stream):
+            all_gather_into(self.full[k], self.local[k])
+            e = torch.cuda.Event()
+            e.record(self.stream)
+        self.done[k] = e
+        self.turn += 1
+        return self.full[k], e
+
+    def drain(self):
+        torch.cuda.current_stream(self.dev).wait_stream(self.stream)
+
+
 def render_sharded(n_units, render_unit, unit_shape, dtype=torch.float32, device="cpu", gather=True, stream=None):
     """Render this rank's units with `render_unit(u) -> tensor[unit_shape]` and, if `gather`,
     return the full `[n_units, *unit_shape]` tensor on every rank (None otherwise: the consumer is
-    rank-local, e.g. DDP training).  The all-gather is issued on `stream` when given so the caller
-    can overlap it with the next render."""
+    rank-local, e.g. DDP training).  With `stream` the all-gather AND the reorder into unit order run on that
+    side stream and the third return value is the event the consumer must wait on (the caller may render the
+    next batch meanwhile); without it the result is ready on the current stream."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     share = padded_share(n_units, world)
@@ -47,12 +165,16 @@ def render_sharded(n_units, render_unit, unit_shape, dtype=torch.float32, device
     if world == 1:
         return local[:n_units], mine
     full = torch.empty((world * share,) + tuple(unit_shape), dtype=dtype, device=device)
-    if stream is not None:
-        stream.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(stream):
-            dist.all_gather_into_tensor(full, local)
-    else:
-        dist.all_gather_into_tensor(full, local)
-    # rank-major [world, share] -> unit order u = i*world + r
-    full = full.reshape((world, share) + tuple(unit_shape)).transpose(0, 1).reshape((world * share,) + tuple(unit_shape))
-    return full[:n_units], mine
+    if stream is None:
+        all_gather_into(full, local)
+        return unit_order(full, n_units, world, share), mine
+    stream.wait_stream(torch.cuda.current_stream(device))
+    local.record_stream(stream)
+    full.record_stream(stream)
+    with torch.cuda.stream(stream):
+        all_gather_into(full, local)
+        out = unit_order(full, n_units, world, share).contiguous()
+        done = torch.cuda.Event()
+        done.record(stream)
+    out.record_stream(torch.cuda.current_stream(device))        # the consumer stream uses it after waiting on `done`
+    return out, mine, done

@@ -17,17 +17,33 @@ from . import _abi
 from deeplens.basics import DEFAULT_WAVE, GEO_SPP, WAVE_RGB
 
 
-def select_focus_dist(depth, num, mode="linear"):
+def select_focus_dist(depth, num, mode="linear", center=True):
     """`num` focus distances between the min and max VALID (>0) depth of each sample
-    (reference: dff/utils.py:4-50, 'linear' rule).  depth [B,1,H,W] -> [B,num], sorted."""
+    (reference: dff/utils.py:4-50).  depth [B,1,H,W] -> [B,n], sorted.
+    'linear': n = num evenly spaced distances.  'importance': the two extremes plus rejection samples from a
+    triangular density peaking at the mean valid depth, drawn with np.random in the reference's call order; like
+    the reference it works for B = 1 only and returns num - 2 distances (its loop runs `while len < num - 2`,
+    dff/utils.py:33-45).  `center` is accepted and unused, as in the reference."""
     assert num > 3, "Focal stack size is too small"
-    if mode != "linear":
-        raise NotImplementedError("only the 'linear' rule is used by the training scripts")
     dmax = torch.amax(depth, dim=(1, 2, 3))
     big = torch.where(depth > 0, depth, torch.full_like(depth, float("inf")))
     dmin = torch.amin(big, dim=(1, 2, 3))
-    f = torch.stack([dmin + i * (dmax - dmin) / (num - 1) for i in range(num)], dim=1)
-    return torch.sort(f, dim=-1)[0]
+    if mode == "linear":
+        f = [dmin + i * (dmax - dmin) / (num - 1) for i in range(num)]
+    elif mode == "importance":
+        avg = torch.sum(depth, dim=(1, 2, 3)) / torch.sum(depth > 0, dim=(1, 2, 3))
+        f = [dmax, dmin]
+        while len(f) < num - 2:
+            cand = np.random.rand() * (dmax - dmin) + dmin
+            if cand > avg:                                   # B = 1 (bool of a one-element tensor), as in the reference
+                rate = (dmax - cand) / (dmax - avg)
+            else:
+                rate = (cand - dmin) / (avg - dmin)
+            if np.random.rand() < rate:
+                f.append(cand)
+    else:
+        raise NotImplementedError
+    return torch.sort(torch.stack(f, dim=1), dim=-1)[0]
 
 
 def stack_uniform_layout(spp, L=3, spp_chief=GEO_SPP, spp_focus=GEO_SPP):
@@ -66,11 +82,13 @@ class StackPlan:
         self.psf_maps = torch.empty((S, 3, grid * ks, grid * ks), dtype=torch.float32, device=dev)
         self.out = torch.empty((B, C_, S, H, W), dtype=torch.float32, device=dev)
         self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.flags_mirror = torch.zeros(1, dtype=torch.int32).pin_memory()    # aadff_publish_flags target (staged path)
         self.tab_rgb = lens._table(WAVE_RGB)
         self.tab_green = lens._table([DEFAULT_WAVE])
         self.lc = lens._lens_const()
         self.pts_xy = lens.point_source_grid(depth=0.0, grid=grid).reshape(-1, 3)
         self.conv_events = None      # optional (start, end) torch.cuda.Event pair around the conv launch
+        self.psf_events = None       # optional (start, end) pair around the fused trace/PSF launch
         self.per, self.o_main, self.o_chief, self.per_l = stack_uniform_layout(spp)
         self.u_dev = [torch.empty(S * self.per, dtype=torch.float32, device=dev) for _ in range(self.RING)]
         self.u_pin = [torch.empty(S * self.per, dtype=torch.float32).pin_memory() for _ in range(self.RING)]
@@ -116,6 +134,7 @@ class StackPlan:
             g = self.guards.get(last // self.GUARD_EVERY)     # recorded at step 4 m + 3 >= last, at least 4 steps ago
             if g is not None:
                 g.synchronize()
+                self._poll_mirror()                          # flags of every step up to that guard, no extra sync
         if hasattr(sampler, "rand_into"):
             sampler.rand_into(self.u_pin[k])
         else:
@@ -127,6 +146,7 @@ class StackPlan:
         (an event record per step costs ~3 us of queue gap)."""
         step = self.turn - 1
         if step % self.GUARD_EVERY == self.GUARD_EVERY - 1:
+            _abi.call("aadff_publish_flags", _abi.ptr(self.flags), C.c_void_p(self.flags_mirror.data_ptr()), _abi.stream_ptr(self.dev))
             e = torch.cuda.Event()
             e.record()
             m = step // self.GUARD_EVERY
@@ -134,12 +154,23 @@ class StackPlan:
             for old in [q for q in self.guards if q < m - self.RING // self.GUARD_EVERY - 1]:
                 del self.guards[old]
 
+    def _poll_mirror(self):
+        """Pipelined stacks: the flags word as of the last guard step, read from its pinned mirror (the kernels' error
+        conditions reach the host a few steps late instead of never; `check_flags` is the synchronous form)."""
+        bits = int(self.flags_mirror[0])
+        if bits:
+            from deeplens.optics import raise_psf_flags
+            self.flags_mirror[0] = 0
+            self.flags.zero_()
+            raise_psf_flags(bits)
+
     def check_flags(self):
         """Raise the reference's errors for anything the kernels of earlier steps flagged (synchronises)."""
         from deeplens.optics import raise_psf_flags
         bits = int(self.flags.item())
         if bits:
             self.flags.zero_()
+            self.flags_mirror[0] = 0
         raise_psf_flags(bits)
 
     def geometry(self, focus, depth_plane_mm):
@@ -187,6 +218,8 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
             plan.stage_generation += 1
             stage = _abi.Stage(u_pin.data_ptr(), ub, plan.per, first, plan.stage_generation & 0xFFFFFFFF,
                                plan.stage_counters.data_ptr())
+        if plan.psf_events is not None:
+            plan.psf_events[0].record()
         if stage is None:
             _abi.call("aadff_psf_points", _abi.ptr(pts), S, N, 3, _abi.ptr(plan.tab_rgb), _abi.ptr(plan.tab_green),
                       plan.lc, _abi.ptr(plan.states), C.c_void_p(ub + 4 * plan.o_main), spp, plan.per, plan.per_l,
@@ -197,6 +230,8 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
                       plan.lc, _abi.ptr(plan.states), C.c_void_p(ub + 4 * plan.o_main), spp, plan.per, plan.per_l,
                       C.c_void_p(ub + 4 * plan.o_chief), GEO_SPP, plan.per, plan.per_l, ks, 1, 1,
                       _abi.ptr(plan.psf_maps), None, _abi.ptr(plan.flags), C.byref(stage), st)
+        if plan.psf_events is not None:
+            plan.psf_events[1].record()
         if plan.conv_events is not None:
             plan.conv_events[0].record()
         _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(plan.psf_maps), _abi.ptr(plan.out), B, C_, S,
@@ -296,3 +331,116 @@ def render_focal_stack_m2(lens, img, depth_m, n_stack):
 def shard_units(n_units, rank, world):
     """Round-robin unit ownership u = rank (mod world)."""
     return list(range(rank, n_units, world))
+
+
+class PresetSampler:
+    """Replays a block of uniforms drawn earlier (host or device) in place of the lens's sampler."""
+
+    def __init__(self, block):
+        self.block, self.pos, self.on_device = block.reshape(-1), 0, block.is_cuda
+
+    def _take(self, n):
+        out = self.block[self.pos:self.pos + n]
+        assert out.numel() == n, "preset uniforms exhausted"
+        self.pos += n
+        return out
+
+    def rand(self, n):
+        return self._take(int(n))
+
+    def rand_block(self, sizes):
+        return self._take(int(sum(sizes)))
+
+    def rand_into(self, out):
+        out.copy_(self._take(out.numel()))
+        return out
+
+
+class SceneUnitRenderer:
+    """M1 rendering of (scene, slice) units for the sharded configuration (BASELINE.json config 3: 16 scenes x 10
+    slices over 8 GPUs, rank r owns units u = scene*S + slice with u = r (mod world)).
+
+    A unit's pixels must not depend on which rank renders it or on what else that rank renders, so every rank
+    draws the uniforms of the WHOLE stack of a scene in the reference's order (`seed_scene(scene)` then one flat
+    draw: 0.1 ms on the host) and consumes only the rows of the slices it owns.  The slices a rank owns within one
+    scene go through ONE refocus / PSF-grid / convolution launch triple."""
+
+    def __init__(self, lens, scenes, S, grid=11, ks=11, spp=GEO_SPP, seed_scene=None):
+        self.lens, self.scenes, self.S, self.grid, self.ks, self.spp = lens, scenes, S, grid, ks, spp
+        self.seed_scene = seed_scene or (lambda scene: torch.manual_seed(scene))
+        self.per = stack_uniform_layout(spp)[0]
+        self.plans = {}
+
+    def n_units(self):
+        return len(self.scenes) * self.S
+
+    def render(self, units, out=None):
+        """`units`: unit ids in any order -> [len(units), C, H, W] in that order (into `out` when given)."""
+        lens, S = self.lens, self.S
+        by_scene = {}
+        for pos, u in enumerate(units):
+            by_scene.setdefault(u // S, []).append((u % S, pos))
+        img0 = self.scenes[0][0]
+        _, C_, H, W = img0.shape
+        dev = lens._gpu()
+        if out is None:
+            out = torch.empty((len(units), C_, H, W), dtype=torch.float32, device=dev)
+        saved = lens.sampler
+        try:
+            for scene, items in by_scene.items():
+                img, depth_plane_mm, focus = self.scenes[scene]
+                focus = [float(f) for f in np.asarray(focus, dtype=np.float64).reshape(-1)]
+                assert len(focus) == S
+                sl = [k for k, _ in items]
+                self.seed_scene(scene)
+                block = saved.rand_block([S * self.per]).reshape(S, self.per)        # the whole stack's draws
+                lens.sampler = PresetSampler(block[sl].contiguous())
+                n = len(sl)
+                plan = self.plans.get(n)
+                if plan is None:
+                    plan = self.plans[n] = StackPlan(lens, n, H, W, 1, C_, self.grid, self.ks, self.spp)
+                st = render_focal_stack_m1(lens, img, depth_plane_mm, [focus[k] for k in sl], self.grid, self.ks, self.spp,
+                                           plan=plan, update_lens=False)           # [1,C,n,H,W]
+                for i, (_, pos) in enumerate(items):
+                    out[pos].copy_(st[0, :, i])
+        finally:
+            lens.sampler = saved
+        return out
+
+    def check_flags(self):
+        for plan in self.plans.values():
+            plan.check_flags()
+
+
+def render_scenes_sharded(renderer, gather=True, stream=None):
+    """This rank's share of all (scene, slice) units through the HIP renderer and, with `gather`, ONE all-gather that
+    leaves the full `[n_scenes*S, C, H, W]` set in unit order on every rank (aadff.dist.render_sharded semantics)."""
+    import torch.distributed as dist
+    from . import dist as adist
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    n = renderer.n_units()
+    mine = adist.shard_units(n, rank, world)
+    share = adist.padded_share(n, world)
+    img0 = renderer.scenes[0][0]
+    dev = renderer.lens._gpu()
+    local = torch.zeros((share,) + tuple(img0.shape[1:]), dtype=torch.float32, device=dev)
+    renderer.render(mine, out=local[:len(mine)])
+    if not gather:
+        return local, mine
+    if world == 1:
+        return local[:n], mine
+    full = torch.empty((world * share,) + tuple(local.shape[1:]), dtype=torch.float32, device=dev)
+    if stream is None:
+        adist.all_gather_into(full, local)
+        return adist.unit_order(full, n, world, share), mine
+    stream.wait_stream(torch.cuda.current_stream(dev))
+    local.record_stream(stream)
+    full.record_stream(stream)
+    with torch.cuda.stream(stream):
+        adist.all_gather_into(full, local)
+        res = adist.unit_order(full, n, world, share).contiguous()
+        done = torch.cuda.Event()
+        done.record(stream)
+    res.record_stream(torch.cuda.current_stream(dev))
+    return res, mine, done

@@ -616,6 +616,9 @@ struct StageArgs {
 #ifndef AADFF_PSF_THREADS
 #define AADFF_PSF_THREADS 512
 #endif
+#ifndef AADFF_STAGE_SPIN_MAX
+#define AADFF_STAGE_SPIN_MAX (1 << 22)      // x s_sleep(16): ~0.1 s; -DAADFF_STAGE_SPIN_MAX=0 forces the late path (tests)
+#endif
 constexpr int kPsfThreads = AADFF_PSF_THREADS, kPsfWaves = kPsfThreads / 64;
 constexpr int kCompactMax = 2048;         // rays per compaction chunk of the main pass (48 KB of LDS)
 __global__ __launch_bounds__(kPsfThreads) void psf_points_kernel(const float* __restrict__ points, int N, int L,
@@ -629,6 +632,7 @@ __global__ __launch_bounds__(kPsfThreads) void psf_points_kernel(const float* __
                                                           float* centre_out, int* flags, StageArgs stage) {
     extern __shared__ float hist[];                      // ks * ks floats (dynamic: ks up to AADFF_MAX_KS = 51)
     __shared__ float red[3 * kPsfWaves];
+    __shared__ int stage_late;
 #if !defined(AADFF_PSF_SCALAR) && !defined(AADFF_PSF_NO_COMPACT)
     __shared__ float cbuf[6][kCompactMax];               // survivors of the first surfaces: origin and direction
     __shared__ int c_count;
@@ -656,14 +660,23 @@ __global__ __launch_bounds__(kPsfThreads) void psf_points_kernel(const float* __
         }
         s -= 1;
         if (s >= stage.first_slice) {
+            // HIP promises no dispatch order: if the copy workgroups have not delivered this state's block within the
+            // bound (they normally lead by tens of microseconds), do not trace stale samples — read this state's draws
+            // straight from the mapped pinned block over PCIe (slow, still correct) and raise flag bit 3 so the host
+            // learns that the overlap was lost.
             if (tid == 0) {
-                int spins = 0;
+                int spins = 0, late = 0;
                 while ((int)(__hip_atomic_load(stage.counters + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - stage.target) < 0) {
                     __builtin_amdgcn_s_sleep(16);
-                    if (++spins > (1 << 22)) { if (flags) atomicOr(flags, 8); break; }     // never hang the queue
+                    if (++spins > AADFF_STAGE_SPIN_MAX) { if (flags) atomicOr(flags, 8); late = 1; break; }     // never hang the queue
                 }
+                stage_late = late;
             }
             __syncthreads();
+            if (stage_late) {
+                u_main = reinterpret_cast<const float*>(stage.src) + (u_main - reinterpret_cast<const float*>(stage.dst));
+                if (u_chief) u_chief = reinterpret_cast<const float*>(stage.src) + (u_chief - reinterpret_cast<const float*>(stage.dst));
+            }
         }
     }
     const aadff_lens_state_t st = states[s];
@@ -1091,6 +1104,11 @@ static int psf_points_launch(const float* points, int S, int N, int L, const aad
         sa.copy_wgs = (int)std::min<long>(std::min<long>(AADFF_STAGE_COPY_WGS, (long)N * L), (sa.slice_n4 + kPsfThreads - 1) / kPsfThreads);
         sa.counters = stage->counters;
         sa.target = stage->generation * (unsigned)sa.copy_wgs;
+        // the late path re-bases u_main / u_chief from dst_dev onto src_host: both must point into the staged block
+        const float* lo = stage->dst_dev;
+        const float* hi = stage->dst_dev + (long)S * stage->slice_stride;
+        AADFF_CHECK_ARG(u_main >= lo && u_main < hi && (!u_chief || (u_chief >= lo && u_chief < hi)),
+                        "psf_points_staged: u_main/u_chief must point into dst_dev[0 .. S*slice_stride)");
     }
     hipLaunchKernelGGL(psf_points_kernel, dim3(N, L, sa.src ? S + 1 : S), dim3(kPsfThreads), (size_t)ks * ks * sizeof(float), (hipStream_t)stream, points, N, L, surf_main,
                        surf_chief, lc, states, u_main, spp, main_stride_s, main_stride_l, u_chief, spp_chief, chief_stride_s,
@@ -1163,6 +1181,23 @@ int aadff_post_computation(int S, const aadff_surface_t* surf_green, aadff_lens_
     hipLaunchKernelGGL((refocus_kernel<kRefocusThreads, 1>), dim3(S), dim3(kRefocusThreads), 0, (hipStream_t)stream, (const float*)nullptr,
                        (const float*)nullptr, 0, 0L, surf_green, lc, states, 0, S, (const float*)nullptr, (float*)nullptr, 0L,
                        (RefocusScratch*)nullptr);
+    AADFF_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void publish_flags_kernel(const int* __restrict__ flags, int* mirror) {
+    if (threadIdx.x == 0) __hip_atomic_store(mirror, __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int aadff_publish_flags(const int* flags_dev, int* mirror_host, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(flags_dev && mirror_host, "publish_flags: NULL pointer");
+    void* mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, mirror_host, 0) != hipSuccess || !mapped) {
+        (void)hipGetLastError();
+        AADFF_CHECK_ARG(false, "publish_flags: mirror_host is not pinned (device-mapped) host memory");
+    }
+    hipLaunchKernelGGL(publish_flags_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flags_dev, reinterpret_cast<int*>(mapped));
     AADFF_CHECK_LAUNCH();
     return 0;
 }

@@ -33,12 +33,15 @@ from .utils import *             # noqa: F401,F403
 
 def raise_psf_flags(bits):
     """Flags word of aadff_psf_points -> the reference's errors (bit 0: NaN in a Newton residual, surfaces.py:555-558;
-    bit 1: no valid chief ray for some point, optics.py:901; bit 3: staged upload timed out)."""
+    bit 1: no valid chief ray for some point, optics.py:901; bit 3: a staged upload was late and the kernel read the
+    samples over PCIe instead — results are correct, only the overlap was lost, so this one is a warning)."""
     if bits & 1:
         raise FloatingPointError("found nan in ft in non-diff newton method.")
-    if bits & 8:
-        raise RuntimeError("aadff: staged upload of the pupil samples timed out")
     assert not bits & 2, "No sampled rays is valid."
+    if bits & 8:
+        import warnings
+        warnings.warn("aadff: a staged upload of pupil samples arrived late; those PSF workgroups read their samples from "
+                      "pinned host memory (correct, slower)", RuntimeWarning, stacklevel=2)
 
 
 class Lensgroup(DeepObj):

@@ -47,25 +47,37 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(lens_path, img, dbar, fds, budget_s=12.0):
-    """Oracle M1 slices (refocus -> psf_map -> render_psf_map) on the host cores."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(lens_path, img, dbar, fds, budget_s=30.0):
+    """Oracle M1 slices (refocus -> psf_map -> render_psf_map) on the host cores, seed 0 — also the reference
+    pixels of the `parity` block.  Returns (record, [slices])."""
     from oracle import conv as oconv
     from oracle.lens import OracleLens
     torch.set_num_threads(usable_cpus())
     lens = OracleLens(lens_path, sensor_res=(H, W))
     torch.manual_seed(0)
     t0 = time.perf_counter()
-    n = 0
+    slices = []
     for f in fds:
         lens.refocus(float(f))
         pm = lens.psf_map(depth=dbar, grid=GRID, ks=KS, spp=SPP)
-        oconv.render_psf_map(img, pm, GRID)
-        n += 1
+        slices.append(oconv.render_psf_map(img, pm, GRID))
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
+    n = len(slices)
     return {"value": round(n * H * W / 1e6 / dt, 4), "unit": "MP/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} of {S} slices of the same 1024x1024 M1 stack (oracle: refocus+psf_map+render_psf_map), {dt:.1f} s"}
+            "cpu_model": cpu_model(),
+            "sample": f"{n} of {S} slices of the same 1024x1024 M1 stack (oracle: refocus+psf_map+render_psf_map), {dt:.1f} s"}, slices
 
 
 def main():
@@ -74,31 +86,42 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gather", action="store_true", help="all-gather the rendered stacks over RCCL (config 3)")
+    ap.add_argument("--emulate-ranks", action="store_true",
+                    help="run the --gpus N ranks on ONE GPU with the gloo backend (RCCL refuses two ranks per device): "
+                         "exercises launcher, sharding and gather order on a 1-GPU box; not a scaling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--device-rng", action="store_true", help="draw pupil samples on the GPU (not sample-comparable)")
     ap.add_argument("--spinup-s", type=float, default=0.3, help="untimed device spin-up before the warm-up steps [s]")
     ap.add_argument("--conv-events-every", type=int, default=8,
                     help="bracket the conv launch with HIP events on every n-th timed step (an event pair costs ~6 us of queue gap)")
-    ap.add_argument("--mode", choices=("m1", "m2", "fit"), default="m1",
+    ap.add_argument("--mode", choices=("m1", "m2", "fit", "c3"), default="m1",
                     help="m1 (default, BASELINE.json metric): ray-traced PSF grid + patch convolution; "
                          "m2: RGB-D stack through the PSF surrogate network (PSFNet.render, SURVEY.md 8f-1); "
-                         "fit: 1_fit_psfnet.py training iterations (ray-traced targets + MLP step, BASELINE config 3)")
+                         "fit: 1_fit_psfnet.py training iterations (ray-traced targets + MLP step, BASELINE config 3); "
+                         "c3: 16 scenes x 10 slices sharded u = r (mod N) with one all-gather (BASELINE config 3, strong scaling)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Self-launch: one child per rank, started BEFORE this process has made any GPU call (it never makes one).
+        from aadff.dist import spawn_ranks
+        raise SystemExit(spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus, emulate=args.emulate_ranks))
     if args.mode == "m2":
         return main_m2(args)
     if args.mode == "fit":
         return main_fit(args)
+    if args.mode == "c3":
+        return main_c3(args)
 
+    import torch.distributed as dist
+    from aadff import dist as adist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed launch with WORLD_SIZE={args.gpus} (got {world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    import torch.distributed as dist
-    from aadff.dist import init_from_env
-    init_from_env(backend="nccl", device=dev)       # RCCL; no-op for a single process
+    adist.init_from_env(backend="nccl", device=dev)       # RCCL (gloo when ranks are emulated on one GPU); no-op for one process
 
     from aadff.focal_stack import StackPlan, render_focal_stack_m1
     from aadff.sampling import DeviceSampler
@@ -119,83 +142,199 @@ def main():
     ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for i in range(0, args.steps, max(1, args.conv_events_every))}
 
-    gathered = comm = None
+    # --gather: the all-gather of step i runs on a side stream while step i+1 renders into the other output buffer
+    ring = None
     if world > 1 and args.gather:
-        gathered = torch.empty((world,) + tuple(plan.out.shape), dtype=torch.float32, device=dev)
-        comm = torch.cuda.Stream(dev)
+        ring = adist.GatherRing(lambda: torch.empty_like(plan.out), world, slots=2, device=dev)
 
-    def step(i, timed):
+    def step(i, timed=False):
         torch.manual_seed(i)
         if timed and i in ev:
             plan.conv_events = ev[i]
+        if ring is not None:
+            k, plan.out = ring.acquire()
         out = render_focal_stack_m1(lens, img, dbar, fds, GRID, KS, SPP, plan=plan, update_lens=False)
         plan.conv_events = None
-        if comm is not None:
-            comm.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(comm):
-                dist.all_gather_into_tensor(gathered, out)
-            torch.cuda.current_stream(dev).wait_stream(comm)   # next step overwrites plan.out
+        if ring is not None:
+            ring.submit(k)
         return out
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
 
     # device spin-up (untimed, before the warm-up steps): a fresh box needs ~0.2 s under load before the shader
     # clock settles; a cold first run otherwise reads 10 % low (0.51 vs 0.46 ms/step with identical code)
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < args.spinup_s:
         for i in range(16):
-            step(i, False)
+            step(i)
         torch.cuda.synchronize(dev)
     for i in range(args.warmup):
-        step(i, False)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
+        step(i)
+    barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, True)
+    if ring is not None:
+        ring.drain()
+    barrier()
+    dt = adist.all_reduce_max(time.perf_counter() - t0)
+
+    # ---- untimed: kernel error flags of every step so far (NaN residual / no valid chief ray -> the number is void)
+    bits = int(plan.flags.item())
+    plan.flags.zero_()
+    if bits & 3:
+        print(f"bench: kernel flags 0x{bits:x} raised during the timed loop (bit0 NaN in Newton residual, bit1 no valid chief ray)",
+              file=sys.stderr, flush=True)
+        raise SystemExit(3)
+
+    # ---- untimed: per-stack latency as SURVEY.md 8(d) defines it (first host call -> device idle), median of 20
+    lat = []
+    for i in range(20):
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        step(i)
+        if ring is not None:
+            ring.drain()
+        torch.cuda.synchronize(dev)
+        lat.append(time.perf_counter() - t1)
+    # ---- untimed: the fused trace/PSF kernel bracketed by HIP events on its own launch stream
+    pev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for i, e in enumerate(pev):
+        plan.psf_events = e
+        step(i)
+    plan.psf_events = None
     torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
+    psf_ms = float(np.median([a.elapsed_time(b) for a, b in pev]))
+    # ---- untimed: the pixels of a seed-0 step for the parity block
+    step(0)
     torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    got = plan.out[0].cpu().numpy() if rank == 0 else None          # [3,S,H,W]
 
     conv_ms = float(np.mean([a.elapsed_time(b) for a, b in ev.values()]))
     achieved = ALG_BYTES_PER_SLICE * S / (conv_ms * 1e-3)
-    traffic = None
+    traffic = unique = None
     tpath = os.path.join(REPO, "profiles", "conv_traffic.json")
     if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        tj = json.load(open(tpath))
+        traffic, unique = tj.get("hbm_bytes_per_launch"), tj.get("unique_bytes_per_launch")
+    valu = None
+    vpath = os.path.join(REPO, "profiles", "psf_kernel_pmc.json")
+    if os.path.exists(vpath):
+        valu = json.load(open(vpath)).get("valu_busy")
     if rank == 0:
+        n_surf = len(lens.surfaces)
+        steps_per_stack = 3 * (SPP + 2048) * GRID * GRID * n_surf * S         # rays x surfaces
         res = {
             "metric": "focal-stack MP/s (1024^2 x 10 slices, 11x11 PSF grid)",
             "value": round(world * S * H * W / 1e6 * args.steps / dt, 2), "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "latency_ms_p50": round(float(np.median(lat)) * 1e3, 4),
             "config": {"workload": "rf50mm, 1024x1024 synthetic RGB + depth plane, 10 focus distances, 11x11 PSF grid, "
                                    "ks 11, spp 2048 (+2048 chief), mode M1 (refocus -> psf_map -> render_psf_map)",
                        "stacks_per_step_per_gpu": 1, "pupil_samples": "device RNG" if args.device_rng else "host torch RNG, reference call order",
-                       "gather": bool(comm is not None),
-                       "arithmetic": "fp32 ray trace / PSF grid; convolution operands carried as exact hi+lo fp16 pairs "
-                                     "(22-bit significand) on MFMA with fp32 accumulation, <= 5e-7 abs from an fp32 FMA chain"},
+                       "gather": bool(ring is not None), "ranks_emulated_on_one_gpu": adist.emulated(),
+                       "value_is": "pipelined throughput (steps queued back to back); latency_ms_p50 = one stack, host call to device idle",
+                       "arithmetic": "fp32 ray trace / PSF grid; convolution operands carried as fp16 hi+lo pairs "
+                                     "(>= 21-bit significand) on MFMA with fp32 accumulation, <= 2e-6 abs from the reference's fp32 conv2d"},
             "roofline": {"kernel": {"v": "conv_psf_map_kernel<11,5> (packed fp32 FMA)",
-                                    "t": "conv_psf_map_mfma_kernel<11,5> (Toeplitz GEMM, exact fp16x3 operand split, fp32 accumulate)"}.get(
+                                    "t": "conv_psf_map_mfma_kernel<11,5> (Toeplitz GEMM, fp16x3 operand split, fp32 accumulate)"}.get(
                                         os.environ.get("AADFF_CONV_PATH", "s")[0],
-                                        "conv_psf_map_sbatch_kernel<24,3> (slice-batched im2col GEMM on MFMA, exact fp16x3 operand split, "
+                                        "conv_psf_map_sbatch_kernel (slice-batched im2col GEMM on MFMA, fp16x3 operand split, "
                                         "fp32 accumulate)") + ", stack-fused S=10",
                          "bound": "hbm", "achieved": round(achieved / 1e9, 2),
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+                         "traffic_source": "profiles/conv_traffic.json (static: rocprofv3 PMC passes of an earlier run of this command, not measured in this run)",
+                         "frac_stack_fused": round(unique / (conv_ms * 1e-3) / HBM_PEAK, 4) if unique else None,
+                         "stack_fused_bytes_per_launch": unique,
                          "kernel_ms": round(conv_ms, 4), "algorithmic_bytes_per_launch": ALG_BYTES_PER_SLICE * S,
                          "tflops": round(2 * 3 * KS * KS * H * W * S / (conv_ms * 1e-3) / 1e12, 2)},
+            "trace": {"kernel": "psf_points_kernel (fused chief-ray centre + ray trace + LDS histogram + normalise)",
+                      "us_per_stack": round(psf_ms * 1e3, 2), "ray_surface_steps_per_stack": steps_per_stack,
+                      "ray_surface_steps_per_s": round(steps_per_stack / (psf_ms * 1e-3), 0),
+                      "frac_of_step": round(psf_ms / (dt / args.steps * 1e3), 4), "bound": "valu",
+                      "valu_busy": valu, "valu_busy_source": "profiles/psf_kernel_pmc.json (static)" if valu is not None else None},
+            "flags": bits,
         }
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(lens_path, img_h, dbar, fds)
+            res["cpu_baseline"], want = cpu_baseline(lens_path, img_h, dbar, fds)
+            n = len(want)
+            a = got[:, :n].astype(np.float64)
+            b = np.stack([w[0].numpy() for w in want], 1).astype(np.float64)
+            per = [float(np.linalg.norm(a[:, k] - b[:, k]) / np.linalg.norm(b[:, k])) for k in range(n)]
+            res["parity"] = {"rel_l2": float(f"{np.linalg.norm(a - b) / np.linalg.norm(b):.3e}"), "rel_l2_worst_slice": float(f"{max(per):.3e}"),
+                             "slices": n, "tolerance": 1e-4, "against": "oracle (CPU restatement pinned to the reference by tests/golden), seed 0, "
+                                                                       "same image / depth plane / focus distances as the timed steps"}
+            if not res["parity"]["rel_l2"] <= 1e-4:
+                print(json.dumps(res), flush=True)
+                print("bench: parity failed", file=sys.stderr, flush=True)
+                raise SystemExit(4)
         print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_c3(args):
+    """BASELINE.json config 3: 16 scenes x 10 slices = 160 (scene, slice) units, rank r renders u = r (mod N), ONE
+    all-gather reassembles [160,3,1024,1024] on every rank.  Total work is fixed: strong scaling."""
+    import torch.distributed as dist
+    from aadff import dist as adist
+    from aadff.focal_stack import SceneUnitRenderer, render_scenes_sharded
+    from aadff.synth import synth_depth_mm, synth_rgb
+    from deeplens.optics import Lensgroup
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    adist.init_from_env(backend="nccl", device=dev)
+    n_scenes = int(os.environ.get("AADFF_C3_SCENES", "16"))
+    lens = Lensgroup(os.path.join(REPO, "lenses", "rf50mm", "lens.json"), sensor_res=(H, W), device=dev)
+    scenes = []
+    for sc in range(n_scenes):
+        depth = synth_depth_mm(H, W, seed=5678 + sc)
+        scenes.append((torch.from_numpy(synth_rgb(H, W, seed=1234 + sc))[None].to(dev), -float(depth.mean()),
+                       -np.linspace(depth.min(), depth.max(), S)))
+    rend = SceneUnitRenderer(lens, scenes, S, GRID, KS, SPP)
+    steps, warm = (min(args.steps, 10) if args.steps == 200 else args.steps), min(args.warmup, 2)
+    side = torch.cuda.Stream(dev) if world > 1 else None
+
+    def step():
+        r = render_scenes_sharded(rend, gather=True, stream=side)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_event(r[2])
+        return r[0]
+
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        full = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = adist.all_reduce_max(time.perf_counter() - t0)
+    rend.check_flags()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "focal-stack MP/s (config 3: 16 scenes x 10 slices sharded u = r mod N, all-gathered)",
+            "value": round(n_scenes * S * H * W / 1e6 * steps / dt, 2), "unit": "MP/s", "n_gpus": world, "steps": steps, "warmup": warm,
+            "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"rf50mm, {n_scenes} scenes x {S} slices, 1024x1024, 11x11 PSF grid, ks 11, spp 2048, mode M1",
+                       "gather": world > 1, "ranks_emulated_on_one_gpu": adist.emulated(),
+                       "gathered_shape": list(full.shape)}}), flush=True)
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -177,7 +177,8 @@ int aadff_psf_points(const float* points, int S, int N, int L,
  * aadff_psf_points launch: a few leading workgroups copy src_host (PINNED host memory,
  * [S][slice_stride] floats, the layout u_main/u_chief index into) to dst_dev and bump
  * counters[s]; the PSF workgroups of those states wait for counters[s] to reach
- * generation * (number of copy workgroups).  Blocks of states < first_slice must already be
+ * generation * (number of copy workgroups); HIP guarantees no dispatch order, so the wait is bounded and a
+ * workgroup whose block is late reads its draws from src_host directly (flag bit 3 reports the lost overlap).  Blocks of states < first_slice must already be
  * in dst_dev (aadff_refocus_staged with n_u = first_slice*slice_stride puts them there, hidden
  * behind the focus traces).  counters: [S] device words zeroed once; generation = 1, 2, 3 ...
  * for successive launches on the same counters (same S, N, L, slice_stride each time). */
@@ -243,6 +244,13 @@ int aadff_refocus_staged(const float* depth, int S, const float* u_host, float* 
  * that assigns d_sensor).  Replaces post_computation, deeplens/optics.py:178-187. */
 int aadff_post_computation(int S, const aadff_surface_t* surf_green, aadff_lens_const_t lc,
                            aadff_lens_state_t* states, aadff_stream_t stream);
+
+/* Copy the flags word the PSF / refocus kernels OR into (bit 0: NaN in a Newton residual — the reference exits,
+ * deeplens/surfaces.py:555-558; bit 1: no valid chief ray, the assert of deeplens/optics.py:901; bit 3: a staged
+ * upload arrived late and the samples were read over PCIe instead) to a PINNED host word from inside the stream:
+ * the host can then poll the reference's error conditions of pipelined stacks without a device synchronisation
+ * (it reads the mirror after an event it waits on anyway).  One 64-thread launch. */
+int aadff_publish_flags(const int* flags_dev, int* mirror_host, aadff_stream_t stream);
 
 /* ------------------------------------------------------------------ host helper */
 

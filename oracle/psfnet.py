@@ -130,3 +130,26 @@ def focal_stack_m1_layered(lens, img, depth_mm, focus_mm, layers=4, grid=11, ks=
             acc = acc + (idx == l).to(img.dtype) * render_psf_map(img, pm, grid)
         slices.append(acc)
     return torch.stack(slices, dim=2)
+
+
+FOC_D_ARR = np.array([-500, -600, -700, -800, -900, -1000, -1250, -1500, -1750, -2000,
+                      -2500, -3000, -4000, -5000, -6000, -8000, -10000, -12000, -15000, -20000])    # psfnet.py:34-38
+
+
+def training_data(lens, bs, spp, ks=11, d_min=-DMIN, d_max=-DMAX):
+    """psfnet.py:135-170 get_training_data: one focus distance (np.random.choice over the 20-entry table), refocus,
+    x, y ~ U(-1,1), z ~ clamped Gaussian around foc_z, ray-traced PSFs at one wavelength.  RNG order: np choice,
+    refocus draws, rand x, rand y, randn z, psf draws.  Returns (inp [bs,4], psf [bs,ks*ks])."""
+    foc_z_arr = (FOC_D_ARR - d_min) / (d_max - d_min)
+    foc_z = np.random.choice(foc_z_arr)
+    lens.refocus(foc_z * (d_max - d_min) + d_min)
+    x = (torch.rand(bs) - 0.5) * 2
+    y = (torch.rand(bs) - 0.5) * 2
+    zg = torch.clamp(torch.randn(bs), min=-3, max=3)
+    z = torch.zeros_like(zg)
+    z[zg > 0] = (1 - foc_z) * zg[zg > 0] / 3 + foc_z
+    z[zg < 0] = foc_z * zg[zg < 0] / 3 + foc_z
+    inp = torch.stack((x, y, z, torch.full_like(x, foc_z)), dim=-1)
+    points = torch.stack((x, y, z * (d_max - d_min) + d_min), dim=-1)
+    psf = lens.psf(points=points, ks=ks, spp=spp)
+    return inp, psf.view(bs, -1)

@@ -24,3 +24,23 @@ def golden_dir():
 @pytest.fixture(scope="session")
 def repo_root():
     return REPO
+
+
+# Parity margins: tests record (name, measured, tolerance); the terminal summary prints them so every run (also `-q`)
+# shows how much of each tolerance is used, not only pass/fail.
+_MARGINS = []
+
+
+@pytest.fixture(scope="session")
+def margin():
+    def record(name, value, tol):
+        _MARGINS.append((name, float(value), float(tol)))
+        assert value <= tol, f"{name}: {value:.3e} exceeds {tol:.1e}"
+    return record
+
+
+def pytest_terminal_summary(terminalreporter):
+    if _MARGINS:
+        terminalreporter.section("parity margins (measured / tolerance)")
+        for name, v, tol in _MARGINS:
+            terminalreporter.write_line(f"{name:<62s} {v:.3e} / {tol:.1e}  ({100 * v / tol:5.1f} % of budget)")

@@ -81,6 +81,7 @@ from deeplens.optics import Lensgroup  # noqa: E402
 from deeplens.basics import Ray, Material, WAVE_RGB, DEFAULT_WAVE, GEO_SPP  # noqa: E402
 from deeplens.monte_carlo import forward_integral  # noqa: E402
 import importlib  # noqa: E402
+import importlib.util  # noqa: E402
 ref_render = importlib.import_module("deeplens.render_psf")  # the package re-exports a same-named function
 from deeplens.psfnet import PSFNet, ThinLens  # noqa: E402
 from deeplens.psfnet_arch import MLP  # noqa: E402
@@ -338,13 +339,106 @@ def g8_focal_stack_m1():
                         crop=stack[:, :, 96:160, 96:160], sums=stack.astype(np.float64).sum((2, 3)))
 
 
+def g9_stack_m1_full():
+    """The bench workload itself (BASELINE.json configs[1]): rf50mm, 1024^2, 10 focus distances, grid 11, ks 11,
+    spp 2048, seed 0 — same image / depth plane / focus list as bench.py.  Stored: PSF maps, d_sensor per slice,
+    three 64x64 crops per slice (patch seam, centre, corner), 16x16 block means of every slice, fp64 sums."""
+    H = W = 1024
+    lens = Lensgroup(filename=f"{REF}/lenses/rf50mm/lens.json", sensor_res=(H, W), device=CPU)
+    img = torch.from_numpy(synth_rgb(H, W, seed=1234))[None]
+    depth = synth_depth_mm(H, W, seed=5678)
+    dbar = -float(depth.mean())
+    fds = -np.linspace(depth.min(), depth.max(), 10)
+    torch.manual_seed(0)
+    maps, dsens, crops, blocks, sums = [], [], {"seam": [], "centre": [], "corner": []}, [], []
+    for f in fds:
+        lens.refocus(float(f))
+        pm = lens.psf_map(depth=dbar, grid=11, ks=11, spp=GEO_SPP)
+        sl = ref_render.render_psf_map(img, pm, 11)[0].numpy()           # [3,H,W]
+        maps.append(pm.numpy())
+        dsens.append(lens.d_sensor)
+        crops["seam"].append(sl[:, 61:125, 154:218])                       # patch borders at 93 and 186
+        crops["centre"].append(sl[:, 480:544, 480:544])
+        crops["corner"].append(sl[:, 960:1024, 960:1024])
+        blocks.append(sl.astype(np.float64).reshape(3, 64, 16, 64, 16).mean((2, 4)).astype(np.float32))
+        sums.append(sl.astype(np.float64).sum((1, 2)))
+    np.savez_compressed(f"{HERE}/g9_stack_m1_1024.npz", fds=fds, dbar=np.float64(dbar), d_sensor=np.array(dsens),
+                        psf_maps=np.stack(maps), sums=np.stack(sums), block_means=np.stack(blocks, 1),
+                        **{f"crop_{k}": np.stack(v, 1) for k, v in crops.items()})
+
+
+def g10_training_data():
+    """PSFNet.get_training_data (deeplens/psfnet.py:135-170): two consecutive calls after np.random.seed(0);
+    torch.manual_seed(0), bs 16, spp 256, sensor 480x640 (the resolution 1_fit_psfnet.py:18 uses)."""
+    lens = PSFNet(filename=f"{REF}/lenses/rf50mm/lens.json", sensor_res=(480, 640), kernel_size=11, device="cpu")
+    np.random.seed(0)
+    torch.manual_seed(0)
+    out = {}
+    for i in range(2):
+        inp, psf = lens.get_training_data(bs=16, spp=256)
+        out[f"inp_{i}"], out[f"psf_{i}"], out[f"d_sensor_{i}"] = inp.numpy(), psf.numpy(), np.float64(lens.d_sensor)
+    np.savez_compressed(f"{HERE}/g10_training_data.npz", **out)
+
+
+def g11_ckpt_activation_range():
+    """Per-layer max |pre-activation| and max |weight| of the SHIPPED checkpoint (ckpt/rf50mm/PSFNet480x640_ks11.pkl,
+    the net 0_warm_up.py:10 loads) over the G7 render inputs and a dense (x, y, z, foc_z) lattice.  Numbers only —
+    no weights are stored.  They bound the operands of the fused kernel's fp16 hi/lo split (psfnet.hip)."""
+    sd = torch.load(f"{REF}/ckpt/rf50mm/PSFNet480x640_ks11.pkl", map_location="cpu")
+    net = MLP(in_features=4, out_features=121, hidden_features=256, hidden_layers=8)
+    net.load_state_dict(sd)
+    net.eval()
+    lens = PSFNet(filename=f"{REF}/lenses/rf50mm/lens.json", sensor_res=(64, 64), kernel_size=11, device="cpu")
+    depth = -torch.from_numpy(synth_depth_mm(64, 64, seed=12))
+    x, y = torch.meshgrid(torch.linspace(-1, 1, 64), torch.linspace(1, -1, 64), indexing="xy")
+    rows = []
+    for f in (-500., -800., -1500., -3000., -5000.):
+        rows.append(torch.stack((x, y, lens.depth2z(depth), lens.depth2z(torch.full_like(depth, f))), -1).reshape(-1, 4))
+    g = torch.linspace(0, 1, 13)
+    lat = torch.stack(torch.meshgrid(g * 2 - 1, g * 2 - 1, g, g, indexing="ij"), -1).reshape(-1, 4)
+    inp = torch.cat(rows + [lat], 0).float()
+    rec = {"n_inputs": int(inp.shape[0]), "layers": []}
+    h = inp
+    with torch.no_grad():
+        for m in net.net:
+            h = m(h)
+            if isinstance(m, torch.nn.Linear):
+                rec["layers"].append({"out_features": m.out_features, "max_abs_preact": float(h.abs().max()),
+                                      "max_abs_weight": float(m.weight.abs().max()), "max_abs_bias": float(m.bias.abs().max()),
+                                      "min_abs_weight_nonzero": float(m.weight.abs()[m.weight != 0].min())})
+        rec["psf_sum_min"] = float(h.sum(-1).min())
+        rec["psf_sum_max"] = float(h.sum(-1).max())
+    with open(f"{HERE}/g11_ckpt_activation_range.json", "w") as f:
+        json.dump(rec, f, indent=1)
+
+
+def g12_select_focus_dist():
+    """dff/utils.py:4-50 select_focus_dist: 'linear' on a batch of 2 and 'importance' (B = 1, np.random.seed(3))."""
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    spec = importlib.util.spec_from_file_location("ref_dff_utils", f"{REF}/dff/utils.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    d = torch.from_numpy(np.stack([synth_depth_mm(32, 48, seed=21), synth_depth_mm(32, 48, seed=22)]))[:, None] / 1e3
+    d[0, 0, :4, :4] = 0.0                                                 # invalid pixels
+    out = {"depth": d.numpy(), "linear_8": mod.select_focus_dist(d, 8, "linear").numpy()}
+    np.random.seed(3)
+    out["importance_8"] = mod.select_focus_dist(d[:1], 8, "importance").numpy()
+    out["importance_np_state_after"] = np.float64(np.random.rand())
+    np.savez_compressed(f"{HERE}/g12_select_focus_dist.npz", **out)
+
+
+ALL = [("G1", lambda: g1_scalars()), ("G2/G3", lambda: g2_g3_trace_and_splat()), ("G4", lambda: g4_psf_map()),
+       ("G5", lambda: g5_conv()), ("G6/G7", lambda: g6_g7_psfnet()), ("G8", lambda: g8_focal_stack_m1()),
+       ("G9", lambda: g9_stack_m1_full()), ("G10", lambda: g10_training_data()),
+       ("G11", lambda: g11_ckpt_activation_range()), ("G12", lambda: g12_select_focus_dist())]
+
 if __name__ == "__main__":
-    for n in ("rf50mm", "50mm_f2.8"):
-        restate_lens_json(n)
-    g1_scalars(); print("G1 done")
-    g2_g3_trace_and_splat(); print("G2/G3 done")
-    g4_psf_map(); print("G4 done")
-    g5_conv(); print("G5 done")
-    g6_g7_psfnet(); print("G6/G7 done")
-    g8_focal_stack_m1(); print("G8 done")
+    want = {a.upper() for a in sys.argv[1:]}            # e.g. `make_golden.py G9 G10`; no arguments = everything
+    if not want:
+        for n in ("rf50mm", "50mm_f2.8"):
+            restate_lens_json(n)
+    for name, fn in ALL:
+        if not want or any(w in name.split("/") for w in want):
+            fn()
+            print(name, "done", flush=True)
     os.system(f"ls -la {HERE}")

@@ -70,3 +70,33 @@ def test_single_process_path_needs_no_group():
 def test_uneven_unit_counts_are_padded():
     assert padded_share(15, 2) == 8 and padded_share(160, 8) == 20 and padded_share(7, 8) == 1
     assert sorted(shard_units(15, 0, 2) + shard_units(15, 1, 2)) == list(range(15))
+
+
+_RANK_SCRIPT = '''
+import os, sys, torch, torch.distributed as dist
+sys.path[:0] = [r"{repo}", r"{pkg}"]
+from aadff import dist as adist
+rank, world = adist.init_from_env(backend="gloo")
+assert os.environ["LOCAL_RANK"] == ("0" if adist.emulated() else str(rank))
+full = torch.empty(world, 3)
+adist.all_gather_into(full, torch.full((3,), float(rank)))
+assert torch.equal(full[:, 0], torch.arange(world, dtype=torch.float32))
+assert adist.all_reduce_max(float(rank)) == world - 1
+open(os.path.join(r"{out}", "ok_%d" % rank), "w").write(str(world))
+dist.barrier(); dist.destroy_process_group()
+if len(sys.argv) > 1 and rank == 1: sys.exit(int(sys.argv[1]))
+'''
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("emulate", [False, True])
+def test_spawn_ranks_launcher(tmp_path, emulate, repo_root):
+    """bench.py --gpus N without a launcher: aadff.dist.spawn_ranks starts N rank processes with the torchrun environment,
+    waits for them and reports a failing rank."""
+    from aadff.dist import spawn_ranks
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT.format(repo=repo_root, pkg=os.path.join(repo_root, "aberration-aware-depth-from-focus_amd"), out=tmp_path))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "AADFF_EMULATE_RANKS")}
+    assert spawn_ranks([str(script)], 2, emulate=emulate, env=env, timeout=120) == 0
+    assert sorted(os.listdir(tmp_path)) == ["ok_0", "ok_1", "rank.py"]
+    assert spawn_ranks([str(script), "7"], 2, emulate=emulate, env=env, timeout=120) == 7

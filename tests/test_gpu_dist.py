@@ -1,0 +1,54 @@
+"""Multi-rank GPU path on a ONE-GPU box (run with `-m gpu`): the self-launcher, the u = r (mod N) sharding of (scene, slice)
+units through the HIP stack renderer and the all-gather order, with the ranks emulated on GPU 0 over gloo (RCCL refuses two
+ranks per device; the same code takes the RCCL branch when every rank has its own GPU).
+
+This module never touches the GPU itself: every GPU process is a child started before any HIP call of this process
+(alphabetically it also runs before the other -m gpu modules)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from aadff.dist import spawn_ranks          # noqa: E402  (imports torch, makes no GPU call)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+@pytest.mark.timeout(900)
+def test_sharded_units_two_emulated_ranks_equal_single_rank(tmp_path):
+    worker = os.path.join(HERE, "dist_gpu_worker.py")
+    args = [worker, "--out", str(tmp_path), "--scenes", "4", "--res", "128", "--slices", "10"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    assert subprocess.call([sys.executable] + args, env=env, timeout=600) == 0                 # world 1
+    assert spawn_ranks(args, 2, emulate=True, env=env, timeout=600) == 0                       # world 2 on one GPU
+    one = np.load(tmp_path / "full_w1.npy")
+    two = np.load(tmp_path / "full_w2.npy")
+    plain = np.load(tmp_path / "plain_stacks.npy")
+    assert one.shape == two.shape == plain.shape == (40, 3, 128, 128)
+    # a unit's inputs do not depend on who renders it; the PSF histogram uses float atomics (sum-order noise ~1e-7),
+    # the convolution of identical maps is deterministic
+    d12 = np.abs(one - two).reshape(40, -1).max(1)
+    d1p = np.abs(one - plain).reshape(40, -1).max(1)
+    print(f"\nsharded (2 emulated ranks) vs 1 rank: max |d| per unit <= {d12.max():.2e}; 1 rank units vs plain per-scene stacks <= {d1p.max():.2e}")
+    assert d12.max() <= 5e-6 and d1p.max() <= 5e-6
+    assert float(np.abs(one).mean()) > 0.05                                                      # real pixels, not zeros
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launches_two_emulated_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for extra in ([], ["--gather"]):
+        p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--emulate-ranks", "--steps", "6",
+                            "--warmup", "2", "--spinup-s", "0.05"] + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 2 and rec["config"]["ranks_emulated_on_one_gpu"] and rec["config"]["gather"] == bool(extra)
+        assert rec["value"] > 0 and rec["flags"] & 3 == 0

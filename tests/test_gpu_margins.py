@@ -1,0 +1,158 @@
+"""Parity MARGINS of the HIP path (run with `-m gpu`): the same comparisons as tests/test_gpu_parity.py, but every measured
+error is recorded next to its tolerance and printed in the terminal summary (tests/conftest.py), so a shortcut in a kernel
+that eats into the budget shows up as a number, not only when it finally fails.
+
+Tolerances (SURVEY.md 8c / BASELINE.json north_star): rendered image <= 1e-4 rel-L2 (fp32-vs-fp64 floor 4.7e-5), PSF
+<= 2e-3 rel-L2 (floor 5.2e-4), validity mismatches <= 1e-4 of rays, focus scalars <= 1e-5 relative."""
+import ctypes as C
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from aadff import _abi                                   # noqa: E402
+from aadff.focal_stack import StackPlan, render_focal_stack_m1   # noqa: E402
+from aadff.synth import mlp_state_dict, synth_depth_mm, synth_rgb   # noqa: E402
+from deeplens.optics import Lensgroup                     # noqa: E402
+from deeplens.psfnet import PSFNet, _TrainStep            # noqa: E402
+from oracle import conv as oconv                          # noqa: E402
+
+rp = importlib.import_module("deeplens.render_psf")
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def tt(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def lp(repo_root, name="rf50mm"):
+    return os.path.join(repo_root, "lenses", name, "lens.json")
+
+
+def test_margin_refocus_and_sensor_hits(golden_dir, repo_root, margin):
+    g = np.load(os.path.join(golden_dir, "g2_g3_trace_splat.npz"))
+    lens = Lensgroup(lp(repo_root), sensor_res=(1024, 1024), device=DEV)
+    torch.manual_seed(0)
+    lens.refocus(-2000.0)
+    margin("refocus(-2000) d_sensor, relative", abs(lens.d_sensor - float(g["d_sensor"])) / float(g["d_sensor"]), 1e-5)
+    margin("refocus(-2000) hfov, relative", abs(lens.hfov - float(g["hfov"])) / float(g["hfov"]), 1e-5)
+    pobj, ut, ur = tt(g["points_obj"]).to(DEV), tt(g["u_theta"]).to(DEV), tt(g["u_r"]).to(DEV)
+    pz, pr = lens.entrance_pupil()
+    o = torch.zeros((256, 121, 3), device=DEV)
+    d = torch.zeros_like(o)
+    ra = torch.zeros((256, 121), device=DEV)
+    _abi.call("aadff_trace_points", _abi.ptr(pobj), 121, _abi.ptr(ut), _abi.ptr(ur), 256, float(pz), float(pr),
+              _abi.ptr(lens._table([0.589])), 12, _abi.ptr(lens._state_device()), _abi.ptr(o), _abi.ptr(d), _abi.ptr(ra),
+              _abi.stream_ptr(torch.device(DEV)))
+    rah, want = ra.cpu().numpy() > 0, g["sensor_ra"] > 0
+    both = rah & want
+    err = np.abs(o[..., :2].cpu().numpy() - g["sensor_xy"])[both]
+    margin("sensor hits: validity-mask mismatch fraction", (rah != want).mean(), 1e-4)
+    margin("sensor hits: mean |dxy| [mm] (fp32-vs-fp64 floor 5.3e-6)", err.mean(), 2e-5)
+    margin("sensor hits: max |dxy| [mm] (floor 4.1e-5)", err.max(), 5e-4)
+
+
+@pytest.mark.parametrize("name,res,foc,depth,spp", [("rf50mm", (1024, 1024), -2000.0, -1500.0, 2048),
+                                                    ("50mm_f2.8", (256, 256), -1000.0, -1250.0, 512)])
+def test_margin_psf_map_and_rendered_image(golden_dir, repo_root, margin, name, res, foc, depth, spp):
+    g4 = np.load(os.path.join(golden_dir, "g4_psf_map.npz"))
+    key = name.replace(".", "_")
+    lens = Lensgroup(lp(repo_root, name), sensor_res=res, device=DEV)
+    torch.manual_seed(0)
+    lens.refocus(foc)
+    pm = lens.psf_map(depth=depth, grid=11, ks=11, spp=spp)
+    img = tt(synth_rgb(256, 256))[None]
+    want = oconv.render_psf_map(img, tt(g4[f"{key}_psf_map"]), 11).numpy()
+    got = rp.render_psf_map(img.to(DEV), pm, 11).cpu().numpy()
+    margin(f"psf_map {name}: PSF rel-L2 vs reference (floor 5.2e-4)", rel(pm.cpu().numpy(), g4[f"{key}_psf_map"]), 2e-3)
+    margin(f"psf_map {name}: rendered image rel-L2 (floor 4.7e-5)", rel(got, want), 1e-4)
+
+
+def test_margin_stack_256(golden_dir, repo_root, margin):
+    g8 = np.load(os.path.join(golden_dir, "g8_stack_m1.npz"))
+    lens = Lensgroup(lp(repo_root), sensor_res=(256, 256), device=DEV)
+    img = tt(synth_rgb(256, 256))[None].to(DEV)
+    torch.manual_seed(0)
+    stack, maps = render_focal_stack_m1(lens, img, float(g8["dbar"]), g8["fds"], grid=11, ks=11, spp=2048, return_maps=True)
+    s = stack[0].cpu().numpy()
+    margin("M1 stack 256^2 x 5: PSF maps rel-L2", rel(maps.cpu().numpy(), g8["psf_maps"]), 2e-3)
+    margin("M1 stack 256^2 x 5: image crop rel-L2", rel(s[:, :, 96:160, 96:160], g8["crop"]), 1e-4)
+
+
+def test_margin_bench_config_stack_plan_staged(golden_dir, repo_root, margin):
+    """THE bench workload through THE bench path (BASELINE.json configs[1]: 1024^2, 10 focus distances, grid 11, ks 11,
+    spp 2048; reused StackPlan, pinned ring, staged upload riding on the refocus / PSF launches, slice-batched convolution)
+    against the G9 fixture generated from the reference with the same seed."""
+    g = np.load(os.path.join(golden_dir, "g9_stack_m1_1024.npz"))
+    H = W = 1024
+    S = 10
+    lens = Lensgroup(lp(repo_root), sensor_res=(H, W), device=DEV)
+    img = tt(synth_rgb(H, W, seed=1234))[None].to(DEV)
+    depth = synth_depth_mm(H, W, seed=5678)
+    dbar, fds = -float(depth.mean()), -np.linspace(depth.min(), depth.max(), S)
+    assert dbar == pytest.approx(float(g["dbar"]), abs=1e-9) and fds == pytest.approx(g["fds"], abs=1e-9)
+    plan = StackPlan(lens, S, H, W, 1, 3, 11, 11, 2048)
+    for i in (3, 2, 1, 0, 0):                         # several steps on the ring first; the last two are seed 0
+        torch.manual_seed(i)
+        out = render_focal_stack_m1(lens, img, dbar, fds, 11, 11, 2048, plan=plan, update_lens=False)
+    plan.check_flags()
+    s = out[0].cpu().numpy()                          # [3,S,H,W]
+    maps = plan.psf_maps.cpu().numpy()
+    st = np.frombuffer(plan.states.cpu().numpy().tobytes(), dtype=np.float32).reshape(S, 8)
+    margin("bench config: d_sensor per slice, worst relative", np.abs(st[:, 0] / g["d_sensor"] - 1).max(), 1e-5)
+    margin("bench config: PSF maps rel-L2, worst slice", max(rel(maps[k], g["psf_maps"][k]) for k in range(S)), 2e-3)
+    crops = {"seam": s[:, :, 61:125, 154:218], "centre": s[:, :, 480:544, 480:544], "corner": s[:, :, 960:1024, 960:1024]}
+    for k, v in crops.items():
+        margin(f"bench config: 64x64 crop '{k}' rel-L2, worst slice", max(rel(v[:, j], g[f"crop_{k}"][:, j]) for j in range(S)), 1e-4)
+    bm = s.astype(np.float64).reshape(3, S, 64, 16, 64, 16).mean((3, 5))
+    margin("bench config: 16x16 block means of the whole stack, rel-L2", rel(bm, g["block_means"]), 1e-4)
+    margin("bench config: per-slice per-channel sums, worst relative", np.abs(s.astype(np.float64).sum((2, 3)).T / g["sums"] - 1).max(), 1e-5)
+
+
+def test_margin_training_data(golden_dir, repo_root, margin):
+    """PSFNet.get_training_data vs the reference's (G10): identical network inputs (host RNG order: np choice, refocus
+    draws, rand x, rand y, randn z, psf draws), ray-traced target PSFs within the PSF tolerance."""
+    g = np.load(os.path.join(golden_dir, "g10_training_data.npz"))
+    net = PSFNet(lp(repo_root), sensor_res=(480, 640), kernel_size=11, device=DEV)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    for i in range(2):
+        inp, psf = net.get_training_data(bs=16, spp=256)
+        assert np.array_equal(inp.cpu().numpy(), g[f"inp_{i}"]), "network inputs must be bit-identical (host RNG order)"
+        margin(f"get_training_data call {i}: d_sensor relative", abs(net.d_sensor / float(g[f'd_sensor_{i}']) - 1), 1e-5)
+        margin(f"get_training_data call {i}: target PSFs rel-L2", rel(psf.cpu().numpy(), g[f"psf_{i}"]), 2e-3)
+
+
+def test_bf16_train_step_runs_and_tracks_fp32(repo_root, margin):
+    """Config 4 (1_fit_psfnet.py, bf16): the graph-captured bf16-autocast step that `bench.py --mode fit` times, against
+    the same steps in fp32: the loss must fall and the bf16 trajectory must stay close to the fp32 one."""
+    dev = torch.device(DEV)
+    net = PSFNet(lp(repo_root), sensor_res=(128, 128), kernel_size=11, device=DEV)
+    sd = {k: torch.from_numpy(v) for k, v in mlp_state_dict(seed=4321).items()}
+    np.random.seed(1)
+    torch.manual_seed(1)
+    data = [net.get_training_data(bs=64, spp=256) for _ in range(3)]
+    data = [(a.to(dev), b.to(dev)) for a, b in data]
+    losses = {}
+    for bf16 in (False, True):
+        net.psfnet.load_state_dict(sd)
+        step = _TrainStep(net.psfnet, 1e-3, 100, 64, 121, dev, bf16, True)
+        ls = []
+        for it in range(12):
+            inp, psf = data[it % 3]
+            pred = step(inp, psf)
+            ls.append(float(((pred.float() - psf) ** 2).mean()))
+        torch.cuda.synchronize()
+        assert step.graph is not None or step.use_graph == "eager-static"
+        assert np.isfinite(ls).all() and ls[-1] < ls[0], ls
+        losses[bf16] = np.array(ls)
+    margin("bf16 train step: |loss_bf16/loss_fp32 - 1| after 12 steps", abs(losses[True][-1] / losses[False][-1] - 1), 0.05)

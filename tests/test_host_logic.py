@@ -150,3 +150,30 @@ def test_fast_host_rng_continues_torch_generator_bit_exactly():
     import ctypes as C
     bad = torch.zeros(100, dtype=torch.uint8)
     assert lib.aadff_host_mt19937_uniform_f32(C.c_void_p(bad.data_ptr()), 100, 4, C.c_void_p(torch.empty(4).data_ptr())) == -1
+
+
+def test_select_focus_dist_matches_reference_goldens(golden_dir):
+    """dff/utils.py:4-50: 'linear' on a batch with invalid pixels, 'importance' in the reference's np.random call order
+    (and with its num - 2 quirk)."""
+    g = np.load(os.path.join(golden_dir, "g12_select_focus_dist.npz"))
+    d = torch.from_numpy(g["depth"])
+    assert torch.equal(select_focus_dist(d, 8, "linear"), torch.from_numpy(g["linear_8"]))
+    np.random.seed(3)
+    got = select_focus_dist(d[:1], 8, "importance", center=True)
+    assert got.shape == (1, 6) and torch.equal(got, torch.from_numpy(g["importance_8"]))
+    assert np.random.rand() == float(g["importance_np_state_after"])          # consumed exactly the reference's draws
+    with pytest.raises(NotImplementedError):
+        select_focus_dist(d, 8, "nope")
+
+
+def test_preset_sampler_replays_selected_slices():
+    from aadff.focal_stack import PresetSampler, stack_uniform_layout
+    per = stack_uniform_layout(64)[0]
+    torch.manual_seed(5)
+    block = HostSampler().rand_block([4 * per]).reshape(4, per)
+    ps = PresetSampler(block[[1, 3]].contiguous())
+    out = torch.empty(2 * per)
+    ps.rand_into(out)
+    assert torch.equal(out.reshape(2, per), block[[1, 3]])
+    with pytest.raises(AssertionError):
+        ps.rand(1)

@@ -306,6 +306,43 @@ def test_g8_focal_stack_m1(golden_dir, repo_root):
     assert s.astype(np.float64).sum((2, 3)) == pytest.approx(g["sums"], rel=1e-7)
 
 
+# ----------------------------------------------------------------- G9: the bench workload (first slices)
+def test_g9_bench_stack_first_slices(golden_dir, repo_root):
+    """BASELINE.json configs[1] as bench.py runs it (1024^2, 10 distances, grid 11, spp 2048, seed 0): the first two
+    slices of the reference stack (the RNG stream is sequential, so a prefix is exact; all ten take ~25 s)."""
+    g = np.load(os.path.join(golden_dir, "g9_stack_m1_1024.npz"))
+    H = W = 1024
+    lens = OracleLens(lens_path(repo_root, "rf50mm"), sensor_res=(H, W))
+    img = tt(synth_rgb(H, W, seed=1234))[None]
+    depth = synth_depth_mm(H, W, seed=5678)
+    assert -float(depth.mean()) == pytest.approx(float(g["dbar"]), abs=1e-9)
+    fds = -np.linspace(depth.min(), depth.max(), 10)
+    assert fds == pytest.approx(g["fds"], abs=1e-9)
+    torch.manual_seed(0)
+    stack, maps = opsf.focal_stack_m1(lens, img, float(g["dbar"]), fds[:2], grid=11, ks=11, spp=GEO_SPP)
+    assert np.abs(maps.numpy() - g["psf_maps"][:2]).max() <= ATOL
+    s = stack[0].numpy()                                     # [3,2,H,W]
+    assert np.abs(s[:, :, 61:125, 154:218] - g["crop_seam"][:, :2]).max() <= ATOL
+    assert np.abs(s[:, :, 480:544, 480:544] - g["crop_centre"][:, :2]).max() <= ATOL
+    assert np.abs(s[:, :, 960:1024, 960:1024] - g["crop_corner"][:, :2]).max() <= ATOL
+    bm = s.astype(np.float64).reshape(3, 2, 64, 16, 64, 16).mean((3, 5))
+    assert np.abs(bm - g["block_means"][:, :2]).max() <= ATOL
+    assert s.astype(np.float64).sum((2, 3)).T == pytest.approx(g["sums"][:2], rel=1e-7)
+
+
+# ----------------------------------------------------------------- G10: PSFNet.get_training_data
+def test_g10_training_data(golden_dir, repo_root):
+    g = np.load(os.path.join(golden_dir, "g10_training_data.npz"))
+    lens = OracleLens(lens_path(repo_root, "rf50mm"), sensor_res=(480, 640))
+    np.random.seed(0)
+    torch.manual_seed(0)
+    for i in range(2):
+        inp, psf = opsf.training_data(lens, bs=16, spp=256)
+        assert np.array_equal(inp.numpy(), g[f"inp_{i}"])
+        assert lens.d_sensor == pytest.approx(float(g[f"d_sensor_{i}"]), abs=1e-6)
+        assert np.abs(psf.numpy() - g[f"psf_{i}"]).max() <= ATOL
+
+
 # ----------------------------------------------------------------- plain-C restatement (oracle/conv_ref.c)
 def _c_oracle(repo_root):
     import ctypes

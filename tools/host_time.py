@@ -16,7 +16,7 @@ for _ in range(20): render_focal_stack_m1(lens, img, -1500., fds, plan=plan, upd
 torch.cuda.synchronize()
 # host-only: rand_into cost
 t0 = time.perf_counter()
-for i in range(200): lens.sampler.rand_into(plan.u_pin[i % 3])
+for i in range(200): lens.sampler.rand_into(plan.u_pin[i % plan.RING])
 t_rng = (time.perf_counter() - t0) / 200
 # whole call, GPU-bound pace vs host pace: run N steps and sync at the end
 t0 = time.perf_counter()
