@@ -109,13 +109,28 @@ def test_margin_bench_config_stack_plan_staged(golden_dir, repo_root, margin):
     maps = plan.psf_maps.cpu().numpy()
     st = np.frombuffer(plan.states.cpu().numpy().tobytes(), dtype=np.float32).reshape(S, 8)
     margin("bench config: d_sensor per slice, worst relative", np.abs(st[:, 0] / g["d_sensor"] - 1).max(), 1e-5)
-    margin("bench config: PSF maps rel-L2, worst slice", max(rel(maps[k], g["psf_maps"][k]) for k in range(S)), 2e-3)
+    # The fp32 noise of this algorithm is far from uniform over the stack: slices focused near the depth plane have needle
+    # PSFs (G13, tests/golden/make_floor.py: the reference's own fp32 result is 5e-3 / 1.4e-4 away from the float64
+    # evaluation of the same draws there, 1e-4 / 5e-6 elsewhere).  So: the STACK is held to the north-star budget, every
+    # slice to max(budget, 2 x that slice's floor), and on the stored truth slices the HIP result must be no further
+    # from the float64 truth than 1.5 x the reference's own distance.
+    fl = np.load(os.path.join(golden_dir, "g13_fp32_floor.npz"))
+    psf_err = [rel(maps[k], g["psf_maps"][k]) for k in range(S)]
+    margin("bench config: PSF maps rel-L2 vs reference, whole stack", rel(maps, g["psf_maps"]), 2e-3)
+    for k in range(S):
+        margin(f"bench config: slice {k} PSF map rel-L2 (floor {fl['psf_floor'][k]:.1e})", psf_err[k], max(2e-3, 2 * fl["psf_floor"][k]))
     crops = {"seam": s[:, :, 61:125, 154:218], "centre": s[:, :, 480:544, 480:544], "corner": s[:, :, 960:1024, 960:1024]}
     for k, v in crops.items():
-        margin(f"bench config: 64x64 crop '{k}' rel-L2, worst slice", max(rel(v[:, j], g[f"crop_{k}"][:, j]) for j in range(S)), 1e-4)
+        margin(f"bench config: 64x64 crop '{k}' rel-L2, whole stack", rel(v, g[f"crop_{k}"]), 1e-4)
+        for j in range(S):
+            margin(f"bench config: crop '{k}' slice {j} (image floor {fl['img_floor'][j]:.1e})", rel(v[:, j], g[f"crop_{k}"][:, j]),
+                   max(1e-4, 2 * fl["img_floor"][j]))
     bm = s.astype(np.float64).reshape(3, S, 64, 16, 64, 16).mean((3, 5))
     margin("bench config: 16x16 block means of the whole stack, rel-L2", rel(bm, g["block_means"]), 1e-4)
     margin("bench config: per-slice per-channel sums, worst relative", np.abs(s.astype(np.float64).sum((2, 3)).T / g["sums"] - 1).max(), 1e-5)
+    for i, k in enumerate(fl["truth_slices"]):
+        ours, ref = rel(maps[k], fl["truth_maps"][i]), rel(g["psf_maps"][k], fl["truth_maps"][i])
+        margin(f"bench config: slice {k} PSF distance to float64 truth, HIP / reference ({ref:.1e})", ours / ref, 1.5)
 
 
 def test_margin_training_data(golden_dir, repo_root, margin):
