@@ -304,9 +304,19 @@ __device__ __forceinline__ bool any2(i2 m) { return (m.x | m.y) != 0; }
 
 __device__ __forceinline__ void sag_and_slope2(const aadff_surface_t& s, f2 r2, f2& sag, f2& slope) {
     const f2 a = (1.f + s.k) * r2 * (s.c * s.c);
+#ifndef AADFF_NO_RSQ_SLOPE
+    // 1/sf from one v_rsq and sf = (1 - a) / sf: one transcendental less per ray than sqrt + rcp (callers mask r2 so
+    // that 1 - a >= 1e-9, valid_loose2 / valid_strict2)
+    const f2 om = 1.f - a;
+    const f2 isf = vrsq(om);
+    const f2 sf = om * isf;
+    sag = r2 * s.c * vrcp(1.f + sf);
+    slope = (0.5f * s.c) * isf;
+#else
     const f2 sf = vsqrt(1.f - a);
     sag = r2 * s.c * vrcp(1.f + sf);
     slope = (0.5f * s.c) * vrcp(sf);
+#endif
     if (s.n_ai > 0) {
         f2 ps, pd;
         if (s.n_ai <= 6) {
@@ -360,7 +370,14 @@ __device__ __forceinline__ i2 conic_root2(const aadff_surface_t& s, const Ray2& 
     const f2 A = SPHERE ? f2s(s.c) : s.c * (1.f + s.k * r.dz * r.dz);
     const f2 disc = beta * beta - A * (s.c * rho2);
     const f2 root = vsqrt(vmax0(disc));
+#ifndef AADFF_NO_SIGNXFER
+    // -(beta + sign(beta) root): the sign transfer is one v_bfi per ray where the two-sided form costs a compare and a
+    // select each (beta = -0 exactly would pick the other root; beta is c (p0 . d) - dz with dz ~ 1)
+    const f2 sroot = (f2){__builtin_copysignf(root.x, beta.x), __builtin_copysignf(root.y, beta.y)};
+    tau = (s.c * rho2) * vrcp(-(beta + sroot));
+#else
     tau = (s.c * rho2) * vrcp(vsel(beta < 0.f, root - beta, -(root + beta)));
+#endif
     return disc >= 0.f;
 }
 // slope_out: d sag / d r^2 of the last (strict) step, i.e. one converged Newton update (<= 5e-5 mm, typically 1e-7)
@@ -406,18 +423,26 @@ __device__ __forceinline__ i2 refract_dir2(const aadff_surface_t& s, Ray2& r, bo
     const float eta2 = forward ? s.eta_fwd2 : s.eta_bwd2;
     const f2 cosi = sgn * (r.dx * nx + r.dy * ny + r.dz * nz);
     const f2 cos2 = cosi * cosi;
-    const f2 sin2 = eta2 * (1.f - cos2);
     // cos^2 i > 0.1 and eta^2 (1 - cos^2 i) < 1  <=>  cos^2 i > max(0.1, 1 - 1/eta^2)  (host-computed per surface)
     const i2 valid = cos2 > (forward ? s.cos2_min_fwd : s.cos2_min_bwd);
-    const f2 g = sgn * (vsqrt(vmax0(1.f - sin2)) - eta * cosi);
+#ifndef AADFF_NO_FOLDED_SNELL
+    const f2 k2 = eta2 * cos2 + (1.f - eta2);           // 1 - eta^2 (1 - cos^2 i) as one fma with wave-uniform constants
+#else
+    const f2 k2 = 1.f - eta2 * (1.f - cos2);
+#endif
+    const f2 g = sgn * (vsqrt(vmax0(k2)) - eta * cosi);
     r.dx = eta * r.dx + g * nx; r.dy = eta * r.dy + g * ny; r.dz = eta * r.dz + g * nz;
     return valid;
 }
 __device__ __forceinline__ void react2(const aadff_surface_t& s, Ray2& r, bool forward, int& nan_flag) {
     const i2 alive = r.alive;
+#ifdef AADFF_SURFACE_SKIP
     // wave-uniform skip only: a per-lane early return turns the whole surface body into a divergent region whose
     // results are merged back with ~12 v_mov per surface (dead lanes just compute values nobody reads)
     if (!__any(any2(alive))) return;
+#endif
+    // (no skip at all by default: vignetted rays are scattered over the lanes, a wave with no live ray is a rarity
+    // before the compaction and impossible after it, and the test costs two vector instructions per surface)
     // to the vertex plane, in place
     const f2 t0 = (s.d - r.oz) * vrcp(r.dz);
     r.ox += r.dx * t0; r.oy += r.dy * t0;
@@ -428,7 +453,7 @@ __device__ __forceinline__ void react2(const aadff_surface_t& s, Ray2& r, bool f
         valid = hit & (t0 + tau >= 0.f);
         r.ox += r.dx * tau; r.oy += r.dy * tau; r.oz = s.d + r.dz * tau;
         valid &= (r.ox * r.ox + r.oy * r.oy) <= s.r2;
-        nx = s.c * r.ox; ny = s.c * r.oy; nz = s.c * (r.oz - s.d) - 1.f;
+        nx = s.c * r.ox; ny = s.c * r.oy; nz = (s.c * r.dz) * tau - 1.f;      // c (z - d) - 1 with z - d = dz tau
     } else if (s.kind == AADFF_SURF_STOP) {
         r.oz = f2s(s.d);
         valid = (r.ox * r.ox + r.oy * r.oy) <= s.r * s.r;           // sqrt(x^2+y^2) <= r (surfaces.py:418)
