@@ -867,11 +867,47 @@ struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };   // 16-by
 
 constexpr int LP_NPX = 64, LP_MAXC = 4;
 
-template <int KS>
+// Replicate-clamped image window [C][KS][64+KS-1] of one 64-pixel run into LDS.  Every (channel, row) is one coalesced
+// load of 64 floats plus a KS-1 float tail, and ALL of them are issued before the first is written to LDS: as a loop of
+// dependent load -> store iterations this staging was a chain of ~38 memory latencies per run and, not the PSF stream,
+// set the speed of the gather kernels (measured: 196 -> see DESIGN.md).
+template <int KS, int CN>      // CN > 0: compile-time channel count (no per-channel branches); CN == 0: runtime C <= LP_MAXC
+__device__ __forceinline__ void lp_stage_window(const float* __restrict__ img, float* tl, int b, int C, int H, int W, int y, int x0, int lane) {
+    constexpr int PAD = KS / 2, TWD = LP_NPX + KS - 1;
+    constexpr int MC = CN > 0 ? CN : LP_MAXC;
+    float v0[MC * KS], v1[MC * KS];
+    const int xa = min(max(x0 - PAD + lane, 0), W - 1);
+    const int xb = min(max(x0 - PAD + LP_NPX + lane, 0), W - 1);
+#pragma unroll
+    for (int cc = 0; cc < MC; ++cc) {
+        if (CN > 0 || cc < C) {
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+                const int yy = min(max(y - PAD + u, 0), H - 1);
+                const float* row = img + ((size_t)(b * C + cc) * H + yy) * W;
+                v0[cc * KS + u] = row[xa];
+                v1[cc * KS + u] = lane < KS - 1 ? row[xb] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < MC; ++cc) {
+        if (CN > 0 || cc < C) {
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+                tl[(cc * KS + u) * TWD + lane] = v0[cc * KS + u];
+                if (lane < KS - 1) tl[(cc * KS + u) * TWD + LP_NPX + lane] = v1[cc * KS + u];
+            }
+        }
+    }
+}
+
+template <int KS, int CN>
 __global__ __launch_bounds__(64) void local_psf_kernel(const float* __restrict__ img, const float* __restrict__ psf,
                                                         float* __restrict__ out, int C, int H, int W) {
-    constexpr int KK = KS * KS, PAD = KS / 2, TWD = LP_NPX + KS - 1;
-    __shared__ float tl[LP_MAXC * KS * TWD];
+    constexpr int MC = CN > 0 ? CN : LP_MAXC;
+    constexpr int KK = KS * KS, TWD = LP_NPX + KS - 1;
+    __shared__ float tl[MC * KS * TWD];
     const int lane = threadIdx.x;
     const int x0 = blockIdx.x * LP_NPX, y = blockIdx.y, b = blockIdx.z;
     const int npx = min(LP_NPX, W - x0);
@@ -886,21 +922,15 @@ __global__ __launch_bounds__(64) void local_psf_kernel(const float* __restrict__
     for (int i = 0; i < NB; ++i)
         if (i < NV) wq[i] = *reinterpret_cast<const f4u*>(pp + 4 * i);
 
-    for (int e = lane; e < C * KS * TWD; e += kWave) {
-        const int cc = e / (KS * TWD), rem = e - cc * KS * TWD;
-        const int u = rem / TWD, xx = rem - u * TWD;
-        const int yy = min(max(y - PAD + u, 0), H - 1);
-        const int xs = min(max(x0 - PAD + xx, 0), W - 1);
-        tl[e] = img[((size_t)(b * C + cc) * H + yy) * W + xs];
-    }
+    lp_stage_window<KS, CN>(img, tl, b, C, H, W, y, x0, lane);
     __syncthreads();
 
-    float acc[LP_MAXC] = {0.f, 0.f, 0.f, 0.f};
+    float acc[MC] = {};
     auto tap = [&](int t, float wv) {
         const int u = t / KS, v = t - u * KS;
 #pragma unroll
-        for (int cc = 0; cc < LP_MAXC; ++cc)
-            if (cc < C) acc[cc] = fmaf(tl[(cc * KS + u) * TWD + lane + v], wv, acc[cc]);
+        for (int cc = 0; cc < MC; ++cc)
+            if (CN > 0 || cc < C) acc[cc] = fmaf(tl[(cc * KS + u) * TWD + lane + v], wv, acc[cc]);
     };
 #pragma unroll
     for (int base = 0; base < NV; base += NB) {
@@ -922,9 +952,78 @@ __global__ __launch_bounds__(64) void local_psf_kernel(const float* __restrict__
     for (int i = 0; i < REM; ++i) tap(4 * NV + i, pp[4 * NV + i]);
     if (act) {
 #pragma unroll
-        for (int cc = 0; cc < LP_MAXC; ++cc)
-            if (cc < C) out[((size_t)(b * C + cc) * H + y) * W + x0 + lane] = acc[cc];
+        for (int cc = 0; cc < MC; ++cc)
+            if (CN > 0 || cc < C) out[((size_t)(b * C + cc) * H + y) * W + x0 + lane] = acc[cc];
     }
+}
+
+// LDS-DMA form (default when the rows are 16-byte aligned: W % 4 == 0).  The taps of a 64-pixel run are ONE contiguous
+// block of 64*ks*ks*4 bytes (30 976 B at ks 11), so the run is fetched by `global_load_lds_dwordx4` wave-instructions of
+// 1 KiB each (64 lanes x 16 consecutive bytes: every request a full line, nothing passes through VGPRs) that are all in
+// flight at once, and each lane then reads ITS pixel's taps from LDS at a pitch of ks*ks dwords (odd: the 32 lanes of a
+// ds_read_b32 group hit 32 different banks).  The old form let every lane walk its own 484-byte row with 16-byte loads:
+// one wave-instruction touched 64 different rows.  One wave per workgroup, 40 KB of LDS -> 4 runs (120 KB) in flight
+// per CU while other workgroups of the CU compute.
+typedef const __attribute__((address_space(1))) void* lp_gptr_t;
+typedef __attribute__((address_space(3))) void* lp_lptr_t;
+#ifndef AADFF_LP_DMA_AUX
+#define AADFF_LP_DMA_AUX 0          // 2 = nt (streamed-once hint)
+#endif
+template <int KS, int CN>
+__global__ __launch_bounds__(64) void local_psf_dma_kernel(const float* __restrict__ img, const float* __restrict__ psf,
+                                                            float* __restrict__ out, int C, int H, int W) {
+    constexpr int KK = KS * KS, TWD = LP_NPX + KS - 1;
+    constexpr int RUN_BYTES = LP_NPX * KK * 4, PIECES = (RUN_BYTES + 1023) / 1024;
+    extern __shared__ __attribute__((aligned(16))) float lp_smem[];      // (64*KK + C*KS*TWD) floats: 40 744 B at ks 11, C 3 -> 4 per CU
+    float* wl = lp_smem;
+    float* tl = lp_smem + LP_NPX * KK;
+    const int lane = threadIdx.x;
+    const int x0 = blockIdx.x * LP_NPX, y = blockIdx.y, b = blockIdx.z;
+    const int npx = min(LP_NPX, W - x0);
+    const int bytes = npx * KK * 4;                          // multiple of 16 (W % 4 == 0)
+    const char* src = reinterpret_cast<const char*>(psf + ((size_t)(b * H + y) * W + x0) * KK);
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+        const int off = p * 1024 + lane * 16;
+        if (off < bytes)
+            __builtin_amdgcn_global_load_lds((lp_gptr_t)(src + off), (lp_lptr_t)(reinterpret_cast<char*>(wl) + p * 1024), 16, 0, AADFF_LP_DMA_AUX);
+    }
+    lp_stage_window<KS, CN>(img, tl, b, C, H, W, y, x0, lane);
+    __syncthreads();                                         // also waits for the DMA pieces (vmcnt(0))
+    if (lane >= npx) return;
+    constexpr int MC = CN > 0 ? CN : LP_MAXC;
+    const float* wr = wl + lane * KK;
+    float acc[MC] = {};
+    // One wave per SIMD cannot hide LDS latency by occupancy: read a whole tap row (KS taps + MC*KS window values)
+    // into registers in one burst, one row ahead of the FMAs that consume it.
+    auto load_row = [&](int u, float (&w)[KS], float (&x)[MC][KS]) {
+#pragma unroll
+        for (int v = 0; v < KS; ++v) w[v] = wr[u * KS + v];
+#pragma unroll
+        for (int cc = 0; cc < MC; ++cc)
+            if (CN > 0 || cc < C) {
+#pragma unroll
+                for (int v = 0; v < KS; ++v) x[cc][v] = tl[(cc * KS + u) * TWD + lane + v];
+            }
+    };
+    float w0[KS], x0r[MC][KS], w1[KS], x1r[MC][KS];
+    load_row(0, w0, x0r);
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+        if (u + 1 < KS) {
+            if (u & 1) load_row(u + 1, w0, x0r); else load_row(u + 1, w1, x1r);
+        }
+        asm volatile("" ::: "memory");                       // keep the next row's reads ahead of this row's FMAs
+#pragma unroll
+        for (int v = 0; v < KS; ++v) {
+#pragma unroll
+            for (int cc = 0; cc < MC; ++cc)
+                if (CN > 0 || cc < C) acc[cc] = fmaf((u & 1) ? x1r[cc][v] : x0r[cc][v], (u & 1) ? w1[v] : w0[v], acc[cc]);
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < MC; ++cc)
+        if (CN > 0 || cc < C) out[((size_t)(b * C + cc) * H + y) * W + x0 + lane] = acc[cc];
 }
 
 // any odd ks / any channel count: PSFs through LDS (the previous design), correctness path
@@ -1009,11 +1108,19 @@ int aadff_local_psf_render(const float* img, const float* psf, float* out, int B
     hipStream_t st = (hipStream_t)stream;
     if (C <= LP_MAXC && (ks == 3 || ks == 5 || ks == 7 || ks == 9 || ks == 11 || ks == 13)) {
         dim3 g((W + LP_NPX - 1) / LP_NPX, H, B);
+        // LDS-DMA form needs 16-byte aligned runs (rows of W*ks*ks floats, W % 4 == 0); AADFF_LOCAL_PSF=direct forces the
+        // per-lane streaming form for A/B runs
+        static const bool force_direct = [] { const char* e = std::getenv("AADFF_LOCAL_PSF"); return e && e[0] == 'd'; }();
+        const bool dma = !force_direct && W % 4 == 0 && (reinterpret_cast<uintptr_t>(psf) & 15) == 0;
+        const size_t dlds = (size_t)(64 * ks * ks + C * ks * (64 + ks - 1)) * sizeof(float);
+#define AADFF_LPC(K, CN) do { if (dma) hipLaunchKernelGGL((local_psf_dma_kernel<K, CN>), g, dim3(64), dlds, st, img, psf, out, C, H, W); \
+                              else hipLaunchKernelGGL((local_psf_kernel<K, CN>), g, dim3(64), 0, st, img, psf, out, C, H, W); } while (0)
+#define AADFF_LP(K) case K: if (C == 3) AADFF_LPC(K, 3); else if (C == 1) AADFF_LPC(K, 1); else AADFF_LPC(K, 0); break;
         switch (ks) {
-#define AADFF_LP(K) case K: hipLaunchKernelGGL(local_psf_kernel<K>, g, dim3(64), 0, st, img, psf, out, C, H, W); break;
             AADFF_LP(3) AADFF_LP(5) AADFF_LP(7) AADFF_LP(9) AADFF_LP(11) AADFF_LP(13)
-#undef AADFF_LP
         }
+#undef AADFF_LP
+#undef AADFF_LPC
     } else {
         const int npx = ks <= 15 ? 64 : 16;
         const size_t lds = ((size_t)npx * ks * ks + (size_t)C * ks * (npx + ks - 1)) * sizeof(float);

@@ -402,6 +402,19 @@ __device__ __forceinline__ void newton2(const aadff_surface_t& s, const Ray2& r,
     // kStepConverged leaves a residual of order (curvature) x step^2 << 5e-5 mm, so the confirming evaluation is
     // skipped (hit points move by < 1e-9 mm); the strict step's own |residual| < 1e-5 test still guards every ray.
     f2 ft = f2s(kMaxT), step = f2s(kMaxT);
+#if !defined(AADFF_NEWTON_LITERAL_EXIT) && !defined(AADFF_NEWTON_CHECK_EVERY_STEP)
+    // The first evaluation always runs (the reference enters its loop with ft = MAXT) and the second does whenever any
+    // ray of the batch started more than 5e-5 mm off the surface, which from the conic root of an asphere is every
+    // batch: run both without the wave-wide exit test, then continue under it.  (Steps on converged rays are no-ops
+    // at the 1e-9 level, which is also what the reference's batch-wide loop does to them.)  A NaN residual survives
+    // every later update, so it is tested once, on the strict step's residual.
+    ft = newton_step2<false>(s, r, dxy2, od, tau, nullptr, &step);
+    ft = newton_step2<false>(s, r, dxy2, od, tau, nullptr, &step);
+    for (int it = 2; it < kNewtonMaxIter; ++it) {
+        if (!__any(any2(alive & (vabs(ft) > kTolLoose) & (vabs(step) > kStepConverged)))) break;
+        ft = newton_step2<false>(s, r, dxy2, od, tau, nullptr, &step);
+    }
+#else
     for (int it = 0; it < kNewtonMaxIter; ++it) {
 #ifndef AADFF_NEWTON_LITERAL_EXIT
         if (!__any(any2(alive & (vabs(ft) > kTolLoose) & (vabs(step) > kStepConverged)))) break;
@@ -411,7 +424,9 @@ __device__ __forceinline__ void newton2(const aadff_surface_t& s, const Ray2& r,
         ft = newton_step2<false>(s, r, dxy2, od, tau, nullptr, &step);
         if (any2(alive & (ft != ft))) nan_flag = 1;
     }
+#endif
     ft = newton_step2<true>(s, r, dxy2, od, tau, slope_out);
+    if (any2(alive & (ft != ft))) nan_flag = 1;
     const f2 px = r.ox + r.dx * tau, py = r.oy + r.dy * tau;
     valid_out = valid_strict2(s, px * px + py * py) & (vabs(ft) < kTolTight) & (t0 + tau > 0.f);
     tau_out = tau;
@@ -477,13 +492,109 @@ __device__ __forceinline__ void react2(const aadff_surface_t& s, Ray2& r, bool f
     if (s.kind != AADFF_SURF_STOP || (forward ? s.refract_fwd : s.refract_bwd)) valid &= refract_dir2(s, r, forward, nx, ny, nz);
     r.alive = valid;
 }
+// ---- run-structured forward trace (default in the fused kernels) ---------------------------------------------------
+// Validity is carried as a MARGIN vm (alive <=> vm >= 0) that every test lowers with v_min3_f32 instead of a compare,
+// a mask AND and a select each: r^2 <= R^2 becomes R^2 - r^2, disc >= 0 the discriminant itself, cos^2 i > thr becomes
+// cos^2 i - nextup(thr).  (v_min3 drops NaN operands; a NaN can only come from a ray that an earlier margin already
+// marked dead, and the splat window test rejects NaN positions.)
+__device__ __forceinline__ f2 vmin3(f2 a, f2 b, f2 c) {
+    return (f2){__builtin_fminf(__builtin_fminf(a.x, b.x), c.x), __builtin_fminf(__builtin_fminf(a.y, b.y), c.y)};
+}
+// One spherical surface, forward, unit directions.  Consecutive spheres run in a loop of their own (trace_part2) so the
+// ray lives in the same registers from one sphere to the next; with the three surface kinds behind one switch the
+// compiler merged the branches with 4-7 register copies per surface.
+// The refraction needs no normal vector: with n = (c x, c y, c dz tau - 1) on the sphere, d.n = beta + c tau
+// (beta = c (p0.d) - dz from the root), and  d' = eta d + g n  with  g = -(sqrt(1 - eta^2 (1 - (d.n)^2)) + eta d.n)
+// is  (eta dx + (g c) x,  eta dy + (g c) y,  eta dz + (g c)(dz tau) - g)   (surfaces.py:589-679 restated).
+typedef const __attribute__((address_space(4))) aadff_surface_t* csurf_t;
+__device__ __forceinline__ void sphere_step2(const __attribute__((address_space(4))) aadff_surface_t& s, Ray2& r, f2& vm) {
+    const f2 t0 = (s.d - r.oz) * vrcp(r.dz);
+    r.ox += r.dx * t0; r.oy += r.dy * t0;                               // vertex plane
+    const f2 rho2 = r.ox * r.ox + r.oy * r.oy;
+    const f2 beta = s.c * (r.ox * r.dx + r.oy * r.dy) - r.dz;
+    const f2 crho = s.c * rho2;
+    const f2 disc = beta * beta - s.c * crho;
+    const f2 root = vsqrt(vmax0(disc));
+    const f2 sroot = (f2){__builtin_copysignf(root.x, beta.x), __builtin_copysignf(root.y, beta.y)};
+    const f2 tau = crho * vrcp(-(beta + sroot));
+    const f2 dzt = r.dz * tau;
+    r.ox += r.dx * tau; r.oy += r.dy * tau; r.oz = s.d + dzt;
+    vm = vmin3(vm, disc, t0 + tau);                                     // hit the sphere, t >= 0 (surfaces.py:466-470)
+    const f2 dn = beta + s.c * tau;
+    const f2 cos2 = dn * dn;
+    const float thr = __builtin_bit_cast(float, __builtin_bit_cast(int, s.cos2_min_fwd) + 1);    // cos2 > min <=> cos2 >= nextup(min)
+    vm = vmin3(vm, s.r2 - (r.ox * r.ox + r.oy * r.oy), cos2 - thr);   // inside the aperture; refraction valid (surfaces.py:660-666)
+    const f2 sq = vsqrt(vmax0(s.eta_fwd2 * cos2 + (1.f - s.eta_fwd2)));
+    const f2 g = -(sq + s.eta_fwd * dn);
+    const f2 gc = g * s.c;
+    r.dx = s.eta_fwd * r.dx + gc * r.ox;
+    r.dy = s.eta_fwd * r.dy + gc * r.oy;
+    r.dz = s.eta_fwd * r.dz + (gc * dzt - g);
+}
+// stop / asphere, forward (the general code of react2 with the margin form of validity)
+__device__ __forceinline__ void other_step2(const aadff_surface_t& s, Ray2& r, f2& vm, int& nan_flag) {
+    const f2 t0 = (s.d - r.oz) * vrcp(r.dz);
+    r.ox += r.dx * t0; r.oy += r.dy * t0;
+    if (s.kind == AADFF_SURF_STOP) {
+        r.oz = f2s(s.d);
+        vm = vmin3(vm, s.r * s.r - (r.ox * r.ox + r.oy * r.oy), vm);    // sqrt(x^2+y^2) <= r (surfaces.py:418)
+        if (s.refract_fwd) {
+            const i2 v = refract_dir2(s, r, true, f2s(0.f), f2s(0.f), f2s(-1.f));
+            vm = vsel(v, vm, f2s(-1.f));
+        }
+        return;
+    }
+    f2 tau, g;
+    i2 valid;
+    const i2 alive = vm >= 0.f;
+    if (s.kind == AADFF_SURF_SPHERIC) {                                 // only with -DAADFF_SPHERE_NEWTON-style builds; kept general
+        const i2 hit = conic_root2<true>(s, r, tau);
+        valid = hit & (t0 + tau >= 0.f);
+        r.ox += r.dx * tau; r.oy += r.dy * tau; r.oz = s.d + r.dz * tau;
+        valid &= (r.ox * r.ox + r.oy * r.oy) <= s.r2;
+        const i2 v = refract_dir2(s, r, true, s.c * r.ox, s.c * r.oy, (s.c * r.dz) * tau - 1.f);
+        vm = vsel(valid & v, vm, f2s(-1.f));
+        return;
+    }
+#ifndef AADFF_NORMAL_REEVAL
+    newton2(s, r, alive, t0, tau, valid, nan_flag, &g);
+    r.ox += r.dx * tau; r.oy += r.dy * tau; r.oz = s.d + r.dz * tau;
+#else
+    newton2(s, r, alive, t0, tau, valid, nan_flag);
+    r.ox += r.dx * tau; r.oy += r.dy * tau; r.oz = s.d + r.dz * tau;
+    f2 sag;
+    sag_and_slope2(s, r.ox * r.ox + r.oy * r.oy, sag, g);
+#endif
+    f2 nx = g * 2.f * r.ox, ny = g * 2.f * r.oy;
+    const f2 inv = vrsq(vmax(nx * nx + ny * ny + 1.f, f2s(1e-24f)));
+    nx *= inv; ny *= inv;
+    valid &= refract_dir2(s, r, true, nx, ny, -inv);
+    vm = vsel(valid, vm, f2s(-1.f));
+}
 // surfaces [first, last) forward; r.alive in/out (r.ra not touched)
 __device__ __forceinline__ void trace_part2(const aadff_surface_t* __restrict__ surf, int first, int last, Ray2& r, int& nan_flag) {
+#ifdef AADFF_PSF_SWITCH_LOOP
     for (int i = first; i < last; ++i) react2(surf[i], r, true, nan_flag);
+#else
+    // the table is read through the constant address space: wave-uniform scalar loads (the kernel's own global stores
+    // otherwise make the compiler fall back to per-lane vector loads inside the sphere loop)
+    const csurf_t cs = (csurf_t)surf;
+    f2 vm = vsel(r.alive, f2s(3e38f), f2s(-1.f));
+    int i = first;
+    while (i < last) {
+        if (cs[i].kind == AADFF_SURF_SPHERIC) {
+            do { sphere_step2(cs[i], r, vm); ++i; } while (i < last && cs[i].kind == AADFF_SURF_SPHERIC);
+        } else {
+            other_step2(surf[i], r, vm, nan_flag);
+            ++i;
+        }
+    }
+    r.alive = vm >= 0.f;
+#endif
 }
 // in: r.alive; out: r.alive and r.ra = alive ? 1 : 0
 __device__ __forceinline__ void trace_forward2(const aadff_surface_t* __restrict__ surf, int n_surf, Ray2& r, int& nan_flag) {
-    for (int i = 0; i < n_surf; ++i) react2(surf[i], r, true, nan_flag);   // (unrolling by two: 2 % slower, code size)
+    trace_part2(surf, 0, n_surf, r, nan_flag);
     r.ra = vsel(r.alive, f2s(1.f), f2s(0.f));
 }
 __device__ __forceinline__ void disc_sample2(f2 u_theta, f2 u_r, float R2, f2& x, f2& y) {

@@ -802,7 +802,7 @@ def _staged_vs_copy(repo_root, monkeypatch, steps, lib=None):
         # histogram atomics: sum order; the staged refocus sums its rays in 4 quarters, d_sensor moves by an fp32
         # ulp and now and then one of the 512 rays of a point flips across a validity edge (one ray = 1/400 of a PSF)
         assert rel_l2(ma.cpu().numpy(), mb.cpu().numpy()) <= 5e-4
-        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 4e-5
     assert (outs[True][0][0] - outs[True][1][0]).abs().max().item() > 1e-4   # different seeds do differ
     return bits
 
