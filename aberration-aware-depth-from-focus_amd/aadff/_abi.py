@@ -13,6 +13,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AADFF_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libaadff.so")   # AADFF_LIB: A/B builds (tools/)
 
+ABI_VERSION = 2
 MAX_GRID, MAX_KS, MAX_SURF, MAX_AI = 64, 51, 32, 8
 SURF_STOP, SURF_SPHERIC, SURF_ASPHERIC = 0, 1, 2
 
@@ -56,13 +57,15 @@ PROTOTYPES = {
     "aadff_render_psf_map_stack": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "aadff_render_psf": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "aadff_local_psf_render": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "aadff_thinlens_render": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P],
     "aadff_trace_rays": [_P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P],
     "aadff_trace_points": [_P, _I, _P, _P, _I, _F, _F, _P, _I, _P, _P, _P, _P, _P],
     "aadff_psf_splat": [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P],
     "aadff_psf_points": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _L, _L, _P, _I, _L, _L, _I, _I, _I, _P, _P, _P, _P],
     "aadff_psf_points_staged": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _L, _L, _P, _I, _L, _L, _I, _I, _I, _P, _P, _P,
                                 C.POINTER(Stage), _P],
-    "aadff_psfnet_forward": [_P, _L, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "aadff_psfnet_forward": [_P, _L, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "aadff_psfnet_render_rgbd": [_P, _P, _P, _P, _F, _F, _L, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "aadff_refocus": [_P, _I, _P, _I, _L, _P, LensConst, _P, _P],
     "aadff_refocus_staged": [_P, _I, _P, _P, _L, _I, _L, _P, LensConst, _P, _P, _P],
     "aadff_post_computation": [_I, _P, LensConst, _P, _P],
@@ -93,8 +96,8 @@ def load_library(path=None):
     lib.aadff_last_error.restype = C.c_char_p
     lib.aadff_device_info.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]
     lib.aadff_device_info.restype = C.c_int
-    if lib.aadff_abi_version() != 1:
-        raise RuntimeError(f"aadff: ABI version mismatch: library {lib.aadff_abi_version()} != binding 1")
+    if lib.aadff_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"aadff: ABI version mismatch: library {lib.aadff_abi_version()} != binding {ABI_VERSION}")
     if path is None:
         _lib = lib
     return lib

@@ -1026,6 +1026,69 @@ __global__ __launch_bounds__(64) void local_psf_dma_kernel(const float* __restri
         if (CN > 0 || cc < C) out[((size_t)(b * C + cc) * H + y) * W + x0 + lane] = acc[cc];
 }
 
+// ------------------------------------------------------------------------------------
+// Thin-lens baseline (ThinLens.coc + ThinLens.render, deeplens/psfnet.py:503-570) with the PSF evaluated IN the gather
+// kernel: per pixel  coc -> Gaussian exp(-(x^2+y^2)/(2 rad^2)) cut at x^2+y^2 < rad^2 -> L1 normalise -> 11x11 gather over
+// the replicate-padded image (render_psf.py:76-107, no flip).  24 B/pixel of HBM traffic + 4 B of depth instead of the
+// 508 B/pixel of materialising the [N,H,W,ks,ks] PSF tensor and streaming it through local_psf_render.
+//   coc chain in the reference's fp32 op order with IEEE divisions (the hard cut r^2 < rad^2 is discontinuous: a 1-ulp
+//   difference in rad^2 next to an integer would flip a whole ring of taps), Gaussian as a product of two 1-D factors
+//   (differs from exp of the sum by rounding only), normalisation folded into one division of the gathered sums.
+// ------------------------------------------------------------------------------------
+template <int KS, int CN>
+__global__ __launch_bounds__(64) void thinlens_kernel(const float* __restrict__ img, const float* __restrict__ depth,
+                                                       const float* __restrict__ foc_dist, const int* __restrict__ negate,
+                                                       float* __restrict__ out, int C, int H, int W, float a_coc, float foc_len,
+                                                       float inv_ps, float d_min, float d_max) {
+    constexpr int MC = CN > 0 ? CN : LP_MAXC;
+    constexpr int PAD = KS / 2, TWD = LP_NPX + KS - 1;
+    __shared__ float tl[MC * KS * TWD];
+    const int lane = threadIdx.x;
+    const int x0 = blockIdx.x * LP_NPX, y = blockIdx.y, b = blockIdx.z;
+    const int npx = min(LP_NPX, W - x0);
+    const bool act = lane < npx;
+    float d = depth[((size_t)b * H + y) * W + x0 + (act ? lane : 0)];
+    float fd = foc_dist[b];
+    lp_stage_window<KS, CN>(img, tl, b, C, H, W, y, x0, lane);
+    __syncthreads();
+    if (negate && *negate) { d = -d; fd = -fd; }            // `if (depth < 0).any()` is a whole-tensor test (psfnet.py:505)
+    d = fminf(fmaxf(d, d_min), d_max);
+    float rad2;
+    {
+#pragma clang fp contract(off)
+        float coc = a_coc * fabsf(d - fd);                   // foc_len / fnum * |depth - foc_dist| / depth * foc_len / (foc_dist - foc_len)
+        coc = coc / d;
+        coc = coc * foc_len;
+        coc = coc / (fd - foc_len);
+        coc = fmaxf(coc * inv_ps, 0.1f);                     // tensor / python-scalar = tensor * (1 / scalar) in ATen
+        const float rad = coc * 0.5f;
+        rad2 = rad * rad;
+    }
+    float e[PAD + 1];                                        // exp(-k^2 / 2 / rad^2), k = 0..PAD
+#pragma unroll
+    for (int k = 0; k <= PAD; ++k) e[k] = __expf((float)(-(k * k)) * 0.5f / rad2);
+    float acc[MC] = {};
+    float wsum = 0.f;
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+#pragma unroll
+        for (int v = 0; v < KS; ++v) {
+            const int du = u < PAD ? PAD - u : u - PAD, dv = v < PAD ? PAD - v : v - PAD;
+            const float wv = (float)(du * du + dv * dv) < rad2 ? e[du] * e[dv] : 0.f;
+            wsum += wv;
+#pragma unroll
+            for (int cc = 0; cc < MC; ++cc)
+                if (CN > 0 || cc < C) acc[cc] = fmaf(tl[(cc * KS + u) * TWD + lane + v], wv, acc[cc]);
+        }
+    }
+    if (act) {
+        const float inv = 1.f / wsum;
+#pragma unroll
+        for (int cc = 0; cc < MC; ++cc)
+            if (CN > 0 || cc < C) out[((size_t)(b * C + cc) * H + y) * W + x0 + lane] = acc[cc] * inv;
+    }
+}
+
 // any odd ks / any channel count: PSFs through LDS (the previous design), correctness path
 template <int NPX>
 __global__ __launch_bounds__(64) void local_psf_generic_kernel(const float* __restrict__ img, const float* __restrict__ psf,
@@ -1136,6 +1199,26 @@ int aadff_local_psf_render(const float* img, const float* psf, float* out, int B
             hipLaunchKernelGGL(local_psf_generic_kernel<16>, g, dim3(64), lds, st, img, psf, out, C, H, W, ks);
         }
     }
+    AADFF_CHECK_LAUNCH();
+    return 0;
+}
+
+int aadff_thinlens_render(const float* img, const float* depth, const float* foc_dist, const int* negate_or_null, float* out,
+                          int B, int C, int H, int W, int ks, float foc_len_over_fnum, float foc_len, float inv_pixel_size,
+                          float d_min, float d_max, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(img && depth && foc_dist && out, "thinlens_render: NULL pointer");
+    AADFF_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0, "thinlens_render: empty tensor");
+    AADFF_CHECK_ARG(C <= LP_MAXC, "thinlens_render: at most %d channels", LP_MAXC);
+    AADFF_CHECK_ARG(ks == 3 || ks == 5 || ks == 7 || ks == 9 || ks == 11 || ks == 13, "thinlens_render: ks %d not in {3,5,...,13}", ks);
+    AADFF_CHECK_ARG(H <= 65535 && B <= 65535, "thinlens_render: H or B too large for the launch grid");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g((W + LP_NPX - 1) / LP_NPX, H, B);
+#define AADFF_TLC(K, CN) hipLaunchKernelGGL((thinlens_kernel<K, CN>), g, dim3(64), 0, st, img, depth, foc_dist, negate_or_null, out, C, H, W, \
+                                            foc_len_over_fnum, foc_len, inv_pixel_size, d_min, d_max)
+#define AADFF_TL(K) case K: if (C == 3) AADFF_TLC(K, 3); else AADFF_TLC(K, 0); break;
+    switch (ks) { AADFF_TL(3) AADFF_TL(5) AADFF_TL(7) AADFF_TL(9) AADFF_TL(11) AADFF_TL(13) }
+#undef AADFF_TL
+#undef AADFF_TLC
     AADFF_CHECK_LAUNCH();
     return 0;
 }

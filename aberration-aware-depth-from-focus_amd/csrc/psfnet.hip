@@ -30,6 +30,17 @@ typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
+// In-kernel layer-0 input (PSFNet.render, deeplens/psfnet.py:424-437): row (n, slice, y, x) of the network input is
+// (xs[x], ys[y], clamp((depth[n][y][x] - d_min) * inv_range, 0, 1), foc_z[n][slice]) -- the [N,S,H,W,4] coordinate tensor
+// of the reference (168 MB for a 1024^2 x 10 stack) is never written.  depth == nullptr: rows come from `inp`.
+struct Coord {
+    const float* depth;     // [N][H][W] mm (< 0)
+    const float* xs;        // [W]  torch.linspace(-1, 1, W)
+    const float* ys;        // [H]  torch.linspace(1, -1, H)
+    const float* foc_z;     // [N][S]  depth2z(foc_dist)
+    float d_min, inv_range; // depth2z: (depth - d_min) * (1 / (d_max - d_min)), the form ATen evaluates tensor / scalar in
+};
+
 struct Layers {
     int n;                              // number of Linear layers
     int kpad[MAXL];                     // input features padded to 32
@@ -67,7 +78,8 @@ template <int TP>
 __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(const float* __restrict__ inp, long P, const uint4v* __restrict__ wpack,
                                                            const float* __restrict__ bias, Layers L, int nout, int mode,
                                                            float* __restrict__ psf_out, const float* __restrict__ img,
-                                                           float* __restrict__ out, int C, int H, int W, int ks, int out_slices) {
+                                                           float* __restrict__ out, int C, int H, int W, int ks, int out_slices,
+                                                           Coord coord, int* __restrict__ flags) {
     __shared__ __attribute__((aligned(16))) _Float16 act[2][TP * AP];          // 135 168 B; reused for the fp32 PSFs at the end
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -78,7 +90,19 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
     for (int e = tid; e < TP * 8; e += NTH) {                                   // 8 groups of 4 halves per pixel and plane
         const int px = e >> 3, g4 = e & 7;
         float4v v = {0.f, 0.f, 0.f, 0.f};
-        if (g4 == 0 && p0 + px < P) v = *reinterpret_cast<const float4v*>(inp + (p0 + px) * 4);
+        if (g4 == 0 && p0 + px < P) {
+            if (coord.depth) {
+                const long gp = p0 + px, hw = (long)H * W;
+                const long ns = gp / hw;                                         // (n, slice) = n * S + slice
+                const int rem = (int)(gp - ns * hw);
+                const int yy = rem / W, xx = rem - yy * W;
+                const long n = out_slices > 0 ? ns / out_slices : ns;
+                const float z = fminf(fmaxf((coord.depth[n * hw + rem] - coord.d_min) * coord.inv_range, 0.f), 1.f);
+                v = (float4v){coord.xs[xx], coord.ys[yy], z, coord.foc_z[ns]};
+            } else {
+                v = *reinterpret_cast<const float4v*>(inp + (p0 + px) * 4);
+            }
+        }
         half4v h, l;
         split4(v, h, l);
         *reinterpret_cast<half4v*>(&act[0][swz(px, 4 * g4)]) = h;
@@ -88,6 +112,7 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
 
     constexpr int NPT = TP / 16;                                                // pixel tiles
     float4v acc[2][NPT];
+    float amax = 0.f;                  // largest hidden activation this lane has split: above 65504 its fp16 hi half is inf
 #pragma unroll 1
     for (int l = 0; l < L.n; ++l) {
         const int nks = L.kpad[l] >> 5, ntile = L.npad[l] >> 4;
@@ -154,6 +179,7 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
                         float4v v = acc[j][p];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                        amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));      // two v_max3_f32
                         half4v h, lo;
                         split4(v, h, lo);
                         const int o = swz(16 * p + lo4, f0);
@@ -193,6 +219,10 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
         }
         __syncthreads();
     }
+
+    // A hidden activation beyond the fp16 range was split into (inf, -inf/NaN): the outputs of this workgroup are garbage.
+    // Say so (flag bit 4) instead of returning it silently; !(amax <= max) also catches a NaN that survived the max chain.
+    if (flags && !(amax <= 65504.f)) atomicOr(flags, 16);
 
     // ---- epilogue: 4 threads per pixel; L1 normalisation (F.normalize eps 1e-12), then PSFs or gather ----
     {
@@ -251,11 +281,11 @@ using namespace aadff;
 
 extern "C" {
 
-int aadff_psfnet_forward(const float* inp, long P, const void* wpack, const float* bias, int n_layers,
+static int psfnet_launch(const float* inp, long P, const void* wpack, const float* bias, int n_layers,
                          const int* in_features, const int* out_features, int mode, float* psf_out,
-                         const float* img, float* out, int C, int H, int W, int ks, int out_slices,
-                         aadff_stream_t stream) {
-    AADFF_CHECK_ARG(inp && wpack && bias && in_features && out_features, "psfnet_forward: NULL pointer");
+                         const float* img, float* out, int C, int H, int W, int ks, int out_slices, pn::Coord coord,
+                         int* flags_or_null, aadff_stream_t stream) {
+    AADFF_CHECK_ARG((inp || coord.depth) && wpack && bias && in_features && out_features, "psfnet_forward: NULL pointer");
     AADFF_CHECK_ARG(n_layers >= 1 && n_layers <= AADFF_PSFNET_MAX_LAYERS, "psfnet_forward: %d layers outside [1,%d]", n_layers, AADFF_PSFNET_MAX_LAYERS);
     AADFF_CHECK_ARG(P >= 0 && P < (1L << 40), "psfnet_forward: bad P");
     AADFF_CHECK_ARG(mode == 0 ? psf_out != nullptr : (img && out && C > 0 && H > 0 && W > 0), "psfnet_forward: missing output/image for mode %d", mode);
@@ -287,12 +317,32 @@ int aadff_psfnet_forward(const float* inp, long P, const void* wpack, const floa
     AADFF_CHECK_ARG(nwg < (1L << 31), "psfnet_forward: too many pixels");
     if (tp == 128)
         hipLaunchKernelGGL(pn::psfnet_fused_kernel<128>, dim3((unsigned)nwg), dim3(pn::NTH), 0, (hipStream_t)stream, inp, P,
-                           reinterpret_cast<const pn::uint4v*>(wpack), bias, L, nout, mode, psf_out, img, out, C, H, W, ks, out_slices);
+                           reinterpret_cast<const pn::uint4v*>(wpack), bias, L, nout, mode, psf_out, img, out, C, H, W, ks, out_slices, coord, flags_or_null);
     else
         hipLaunchKernelGGL(pn::psfnet_fused_kernel<64>, dim3((unsigned)nwg), dim3(pn::NTH), 0, (hipStream_t)stream, inp, P,
-                           reinterpret_cast<const pn::uint4v*>(wpack), bias, L, nout, mode, psf_out, img, out, C, H, W, ks, out_slices);
+                           reinterpret_cast<const pn::uint4v*>(wpack), bias, L, nout, mode, psf_out, img, out, C, H, W, ks, out_slices, coord, flags_or_null);
     AADFF_CHECK_LAUNCH();
     return 0;
+}
+
+int aadff_psfnet_forward(const float* inp, long P, const void* wpack, const float* bias, int n_layers,
+                         const int* in_features, const int* out_features, int mode, float* psf_out,
+                         const float* img, float* out, int C, int H, int W, int ks, int out_slices,
+                         int* flags_or_null, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(inp, "psfnet_forward: NULL input rows");
+    return psfnet_launch(inp, P, wpack, bias, n_layers, in_features, out_features, mode, psf_out, img, out, C, H, W, ks,
+                         out_slices, pn::Coord{}, flags_or_null, stream);
+}
+
+int aadff_psfnet_render_rgbd(const float* depth, const float* xs, const float* ys, const float* foc_z, float d_min,
+                             float inv_range, long N, int S, const void* wpack, const float* bias, int n_layers,
+                             const int* in_features, const int* out_features, const float* img, float* out, int C, int H,
+                             int W, int ks, int* flags_or_null, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(depth && xs && ys && foc_z, "psfnet_render_rgbd: NULL pointer");
+    AADFF_CHECK_ARG(N >= 0 && S >= 1 && H > 0 && W > 0, "psfnet_render_rgbd: bad sizes N=%ld S=%d", N, S);
+    const pn::Coord c{depth, xs, ys, foc_z, d_min, inv_range};
+    return psfnet_launch(nullptr, N * S * (long)H * W, wpack, bias, n_layers, in_features, out_features, 1, nullptr, img, out,
+                         C, H, W, ks, S, c, flags_or_null, stream);
 }
 
 }  // extern "C"

@@ -197,7 +197,8 @@ class PSFNet(Lensgroup):
     def render_stack(self, img, depth, foc_dists):
         """[N,C,S,H,W] focal stack of img [N,C,H,W] for depth [N,1,H,W] (mm, < 0) and focus distances [N,S] (mm, < 0):
         the loop `stack([render(img, depth, foc_dists[:, i]) for i], dim=2)` of 2_aber_aware_dff_aif.py:104-114 as
-        ONE fused launch when the fused kernel applies, else that loop."""
+        ONE fused launch when the fused kernel applies (the (x, y, z, foc_z) rows of psfnet.py:424-437 are generated in
+        the kernel from the depth map: no [N,S,H,W,4] tensor), else that loop."""
         dev = next(self.psfnet.parameters()).device
         N, C, H, W = img.shape
         foc_dists = foc_dists.to(dev).reshape(N, -1)
@@ -206,12 +207,17 @@ class PSFNet(Lensgroup):
         if packed is None:
             return torch.stack([self.render(img, depth, foc_dists[:, i]) for i in range(S)], dim=2)
         from aadff import psfnet_pack
-        z = self.depth2z(depth.to(dev)).reshape(N, 1, H, W).expand(N, S, H, W)
-        x, y = self._field_grid(H, W, dev)
-        foc_z = self.depth2z(foc_dists).reshape(N, S, 1, 1).expand(N, S, H, W)
-        o = torch.stack((x.expand(N, S, H, W), y.expand(N, S, H, W), z, foc_z), -1).float()
-        out = psfnet_pack.forward(packed, o.reshape(-1, 4), 1, img=img.to(dev), ks=self.kernel_size, slices=S)
+        xs, ys = self._field_axes(H, W, dev)
+        out = psfnet_pack.render_rgbd(packed, img.to(dev), depth.to(dev).reshape(N, H, W), xs, ys, self.depth2z(foc_dists.float()),
+                                      float(self.d_min), float(self.d_max - self.d_min), self.kernel_size)
         return out.to(img.device)
+
+    def _field_axes(self, H, W, dev):
+        """linspace(-1,1,W) and linspace(1,-1,H) (reference: psfnet.py:427-431) on `dev`, cached per (H, W, device)."""
+        key = (H, W, str(dev))
+        if getattr(self, "_axes_key", None) != key:
+            self._axes, self._axes_key = (torch.linspace(-1, 1, W).to(dev), torch.linspace(1, -1, H).to(dev)), key
+        return self._axes
 
     def _field_grid(self, H, W, dev):
         """x = linspace(-1,1,W) over columns, y = linspace(1,-1,H) over rows (reference: psfnet.py:427-431),
@@ -309,9 +315,31 @@ class ThinLens(DeepObj):
 
     @torch.no_grad()
     def render(self, img, depth, foc_dist):
-        """img [N,C,H,W], depth [N,1,H,W], foc_dist [N] -> [N,C,H,W]."""
+        """img [N,C,H,W], depth [N,1,H,W], foc_dist [N] -> [N,C,H,W] (reference: psfnet.py:549-570).  One HIP kernel:
+        the per-pixel Gaussian PSF is evaluated inside the gather (aadff_thinlens_render), the [N,H,W,ks,ks] PSF tensor
+        of the reference is never built.  `render_psf_tensor` keeps the tensor form (tests, odd shapes)."""
         if len(img.shape) != 4:
             raise ValueError("ThinLens.render needs [N,C,H,W] (the reference's 3-D branch calls methods ThinLens lacks)")
+        N, C, H, W = img.shape
+        ks = self.kernel_size
+        if C > 4 or ks not in (3, 5, 7, 9, 11, 13):
+            return self.render_psf_tensor(img, depth, foc_dist)
+        import ctypes as C_
+        from aadff import _abi
+        _abi.require_gpu()
+        dev = img.device if img.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        x, d, fd = _abi.f32c(img, dev), _abi.f32c(depth, dev).reshape(N, 1, H, W), _abi.f32c(foc_dist, dev).reshape(N)
+        neg = (d < 0).any().to(torch.int32).reshape(1)          # whole-tensor sign test of the reference, stays on the device
+        out = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            _abi.call("aadff_thinlens_render", _abi.ptr(x), _abi.ptr(d), _abi.ptr(fd), _abi.ptr(neg), _abi.ptr(out), N, C, H, W, ks,
+                      C_.c_float(self.foc_len / self.fnum), C_.c_float(self.foc_len), C_.c_float(1.0 / self.ps),
+                      C_.c_float(self.d_min), C_.c_float(self.d_max), _abi.stream_ptr(dev))
+        return out.to(img.device)
+
+    @torch.no_grad()
+    def render_psf_tensor(self, img, depth, foc_dist):
+        """The reference's literal form: build the [N,H,W,ks,ks] Gaussian PSFs with torch ops, then local_psf_render."""
         ks, dev = self.kernel_size, img.device
         N, C, H, W = img.shape
         fd = foc_dist.unsqueeze(-1).unsqueeze(-1).unsqueeze(-1).repeat(1, 1, H, W)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AADFF_ABI_VERSION 1
+#define AADFF_ABI_VERSION 2
 
 #define AADFF_EINVAL      (-1)   /* bad shape / size / NULL pointer                  */
 #define AADFF_EUNSUPPORTED (-2)  /* parameter outside what the kernels were built for */
@@ -121,6 +121,19 @@ int aadff_render_psf(const float* img, const float* psf, float* out,
 int aadff_local_psf_render(const float* img, const float* psf, float* out,
                            int B, int C, int H, int W, int ks, aadff_stream_t stream);
 
+/* Thin-lens baseline renderer with the PSF evaluated in the kernel.  Replaces ThinLens.coc + ThinLens.render (4-D
+ * branch), deeplens/psfnet.py:503-512,549-570: per pixel the circle of confusion of `depth` for focus distance
+ * `foc_dist[b]`, a Gaussian of sigma = coc/2 pixels cut off at radius coc/2, L1-normalised, gathered over the
+ * replicate-padded image (deeplens/render_psf.py:76-107).  No [N,H,W,ks,ks] tensor is materialised.
+ *   img [B,C,H,W] (C <= 4), depth [B,1,H,W] (mm), foc_dist [B] (mm), out [B,C,H,W]; ks in {3,5,...,13}
+ *   negate_or_null: device int, non-zero = negate depth and foc_dist first (the reference's whole-tensor test
+ *                   `(depth < 0).any()`, psfnet.py:505, evaluated by the caller on the device: no host sync)
+ *   foc_len_over_fnum, foc_len, inv_pixel_size = 1/ps, d_min, d_max: the lens constants of psfnet.py:491-500
+ *   (depth is clamped to [d_min, d_max]; coc in pixels is clamped to >= 0.1). */
+int aadff_thinlens_render(const float* img, const float* depth, const float* foc_dist, const int* negate_or_null,
+                          float* out, int B, int C, int H, int W, int ks, float foc_len_over_fnum, float foc_len,
+                          float inv_pixel_size, float d_min, float d_max, aadff_stream_t stream);
+
 /* ------------------------------------------------------------------ ray tracing */
 
 /* Generic trace of n rays through surfaces [first,last) in travel order (reverse when
@@ -214,7 +227,20 @@ int aadff_psf_points_staged(const float* points, int S, int N, int L,
 int aadff_psfnet_forward(const float* inp, long P, const void* wpack, const float* bias, int n_layers,
                          const int* in_features, const int* out_features, int mode, float* psf_out,
                          const float* img, float* out, int C, int H, int W, int ks, int out_slices,
-                         aadff_stream_t stream);
+                         int* flags_or_null, aadff_stream_t stream);
+/* flags_or_null (both psfnet entries): bit 4 is ORed in when a hidden activation exceeded 65504, the largest value the
+ * fp16 hi half of the split operand can carry — the affected outputs are then inf/NaN garbage and the caller must not
+ * use them (the shipped rf50mm checkpoint peaks at 41, tests/golden/g11_ckpt_activation_range.json). */
+
+/* PSFNet.render for a whole RGB-D focal stack with the network input generated in the kernel
+ * (deeplens/psfnet.py:393-441 per slice, 2_aber_aware_dff_aif.py:104-114 for the stack): row (n, s, y, x) =
+ * (xs[x], ys[y], clamp((depth[n][y][x] - d_min) * inv_range, 0, 1), foc_z[n][s]); out [N,C,S,H,W] (S = 1: [N,C,H,W]).
+ * xs = linspace(-1, 1, W), ys = linspace(1, -1, H) (psfnet.py:427-431), foc_z = depth2z(foc_dist) (psfnet.py:447-450),
+ * inv_range = 1 / (d_max - d_min) in fp32. */
+int aadff_psfnet_render_rgbd(const float* depth, const float* xs, const float* ys, const float* foc_z, float d_min,
+                             float inv_range, long N, int S, const void* wpack, const float* bias, int n_layers,
+                             const int* in_features, const int* out_features, const float* img, float* out, int C, int H,
+                             int W, int ks, int* flags_or_null, aadff_stream_t stream);
 
 /* Refocus S lens states in one launch: trace spp rays from (0,0,depth[s]) (green table),
  * least-squares axis crossing -> d_sensor, then hfov/foclen/fnum.  Replaces

@@ -148,6 +148,49 @@ def test_render_psf_map_1024_golden_crops(golden_dir):
     assert out.astype(np.float64).sum((1, 2)) == pytest.approx(g["sums"], rel=1e-6)
 
 
+def test_conv_hdr_dynamic_range_within_a_band():
+    """The MFMA paths carry fp32 pixels as fp16 hi/lo pairs after ONE power-of-two scale per image tile: a tile whose
+    pixels span 1e-4 .. 1e3 (seven decades) must still come out like an fp32 FMA chain, i.e. with an absolute error
+    proportional to the LARGEST pixel under the PSF, not to the local value."""
+    rng = np.random.Generator(np.random.PCG64(404))
+    H = W = 192
+    img = (10.0 ** rng.uniform(-4.0, 3.0, size=(1, 3, H, W))).astype(np.float32)
+    maps = rng.random((10, 3, 33, 33), dtype=np.float32)
+    maps /= maps.reshape(10, 3, 3, 11, 3, 11).sum((3, 5), keepdims=True).reshape(10, 3, 3, 1, 3, 1).repeat(11, 3).repeat(11, 5).reshape(10, 3, 33, 33)
+    want = np.stack([oconv.render_psf_map(tt(img), tt(m), 3).numpy() for m in maps], 2)        # [1,3,10,H,W]
+    got_stack = rp.render_psf_map_stack(tt(img).to(DEV), tt(maps).to(DEV), 3).cpu().numpy()     # slice-batched GEMM
+    got_one = rp.render_psf_map(tt(img).to(DEV), tt(maps[0]).to(DEV), 3).cpu().numpy()          # Toeplitz GEMM
+    bound = 1e-6 * float(img.max())
+    assert np.abs(got_stack - want).max() <= bound
+    assert np.abs(got_one - want[:, :, 0]).max() <= bound
+    # and relative to the result itself the bulk is at fp32 level: the scale is per tile, not per image
+    rel = np.abs(got_stack - want) / np.abs(want)
+    assert np.median(rel) <= 2e-7
+
+
+def test_conv_non_finite_pixel_poisons_a_bounded_neighbourhood():
+    """One inf (or NaN) pixel: F.conv2d in the reference turns the 11x11 support non-finite (inf where the tap is
+    positive, NaN where it is zero).  The GEMM forms multiply the pixel with the zero padding of their K extent and split
+    inf into (inf, NaN), so they return NaN, on a support that is at most one GEMM block wider.  Contract: everything the
+    reference poisons is non-finite here too, and everything farther than 16 pixels from the bad pixel is unaffected."""
+    rng = np.random.Generator(np.random.PCG64(405))
+    H = W = 160
+    base = rng.random((1, 3, H, W), dtype=np.float32)
+    maps = rng.random((4, 3, 22, 22), dtype=np.float32) / 60.5           # taps sum to ~1 per PSF
+    for bad in (np.inf, np.nan):
+        img = base.copy()
+        img[0, 1, 70, 91] = bad
+        want = np.stack([oconv.render_psf_map(tt(img), tt(m), 2).numpy() for m in maps], 2)
+        clean = np.stack([oconv.render_psf_map(tt(base), tt(m), 2).numpy() for m in maps], 2)
+        for got in (rp.render_psf_map_stack(tt(img).to(DEV), tt(maps).to(DEV), 2).cpu().numpy(),
+                    np.stack([rp.render_psf_map(tt(img).to(DEV), tt(m).to(DEV), 2).cpu().numpy() for m in maps], 2)):
+            assert not np.isfinite(got[~np.isfinite(want)]).any()
+            yy, xx = np.mgrid[0:H, 0:W]
+            far = np.maximum(np.abs(yy - 70), np.abs(xx - 91)) > 16
+            assert np.isfinite(got[..., far]).all() and np.abs(got[..., far] - clean[..., far]).max() <= CONV_ATOL
+            assert np.isfinite(got[:, [0, 2]]).all()                  # other channels untouched
+
+
 def test_stack_fused_equals_per_slice():
     """The stack path (slice-batched GEMM, 4 slices per MFMA) and the single-slice path (Toeplitz GEMM) carry the same
     exact fp16 hi/lo operand split; they differ only in fp32 summation order."""
@@ -533,6 +576,52 @@ def test_fused_mlp_pred_golden_and_vs_torch(g67, psfnet64):
         assert psfnet64.pred(x).requires_grad
 
 
+def test_fused_mlp_small_weights(repo_root):
+    """Weights of magnitude ~1e-3 (and down to 1e-7): the lo halves of the fp16 split are all subnormal there (spacing 6e-8
+    absolute, see aadff/psfnet_pack.py).  The fused kernel must still match torch fp32 to 2e-7: in particular the MFMA f16
+    path must not flush subnormal operands (a flush would cost ~1e-5)."""
+    net = PSFNet(lens_path(repo_root), sensor_res=(64, 64), kernel_size=11, device=DEV)
+    rng = np.random.Generator(np.random.PCG64(5))
+    sd = {}
+    for k, v in mlp_state_dict(seed=99).items():
+        if k.endswith("weight"):
+            scale = 10.0 ** rng.uniform(-4.0, -1.0, size=v.shape).astype(np.float32)       # |w| spread over 1e-5 .. 1e-1 of the init
+            v = (v * scale).astype(np.float32)
+        sd[k] = tt(v)
+    net.psfnet.load_state_dict(sd)
+    x = tt(rng.random((777, 4), dtype=np.float32)).to(DEV)
+    x[:, :2] = x[:, :2] * 2 - 1
+    with torch.no_grad():
+        a = net.pred(x).reshape(777, -1)
+        b = net.psfnet(x)
+    assert net._fused(DEV) is not None
+    assert (a - b).abs().max().item() <= 2e-7 and rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 2e-6
+
+
+def test_fused_mlp_activation_overflow_raises(repo_root):
+    """A hidden activation above 65504 does not fit the fp16 hi half of the split operand: the fused kernel raises flag
+    bit 4 and the host raises ActivationOverflow instead of returning inf/NaN PSFs; the torch mode still renders."""
+    from aadff.psfnet_pack import ActivationOverflow
+    net = PSFNet(lens_path(repo_root), sensor_res=(16, 16), kernel_size=11, device=DEV)
+    sd = {k: tt(v) for k, v in mlp_state_dict(seed=4321).items()}
+    sd["net.2.weight"] = sd["net.2.weight"] * 3e4                 # second layer: activations ~1e5
+    net.psfnet.load_state_dict(sd)
+    x = torch.rand(300, 4, device=DEV)
+    with torch.no_grad():
+        assert float(torch.relu(net.psfnet.net[:4](x)).max()) > 65504.0
+        with pytest.raises(ActivationOverflow):
+            net.pred(x)
+        img, depth = torch.rand(1, 3, 16, 16, device=DEV), -torch.rand(1, 1, 16, 16, device=DEV) * 3000 - 300
+        with pytest.raises(ActivationOverflow):
+            net.render_stack(img, depth, torch.tensor([[-500.0, -900.0]], device=DEV))
+        net.mlp_precision = "torch"
+        out = net.render(img, depth, torch.tensor([-500.0], device=DEV))
+        assert torch.isfinite(out).all()
+    # the shipped rf50mm checkpoint stays far inside the range (numbers recorded from the reference's ckpt, no weights)
+    rec = json.load(open(os.path.join(repo_root, "tests", "golden", "g11_ckpt_activation_range.json")))
+    assert max(l["max_abs_preact"] for l in rec["layers"]) < 100.0 and max(l["max_abs_weight"] for l in rec["layers"]) < 2.0
+
+
 def test_fused_render_equals_torch_mlp_plus_gather(psfnet64):
     """mode 1 (MLP + gather fused) == torch MLP + aadff_local_psf_render, incl. a ragged last tile and B = 2."""
     rng = np.random.Generator(np.random.PCG64(78))
@@ -591,6 +680,30 @@ def test_thinlens_golden(g67):
     thin = ThinLens(foc_len=50.0, fnum=1.8, kernel_size=11, sensor_size=[24.0, 24.0], sensor_res=(64, 64))
     out = thin.render(img, depth, torch.tensor([-1500.0], device=DEV))
     assert rel_l2(out.cpu().numpy(), g67["thin_out"]) <= IMG_TOL
+
+
+def test_thinlens_kernel_matches_tensor_form_and_edge_cases(g67):
+    """aadff_thinlens_render (PSF evaluated in the gather kernel) vs the reference's literal tensor form on the same GPU
+    (ThinLens.render_psf_tensor -> local_psf_render): batches with different focus distances, positive depths (no sign
+    flip), ragged widths, one channel, and the coc clamp: a pixel exactly in focus has coc 0 -> clamped to 0.1 px -> only
+    the centre tap survives the cut -> the pixel is copied."""
+    thin = ThinLens(foc_len=50.0, fnum=1.8, kernel_size=11, sensor_size=[24.0, 24.0], sensor_res=(64, 64))
+    assert np.abs(thin.coc(-tt(synth_depth_mm(64, 64, seed=12))[None, None], torch.full((1, 1, 64, 64), -1500.0)).numpy()
+                  - g67["thin_coc"]).max() <= 1e-5 * np.abs(g67["thin_coc"]).max()
+    rng = np.random.Generator(np.random.PCG64(77))
+    for (N, C, H, W, ks, sign) in ((2, 3, 40, 72, 11, -1), (1, 3, 33, 130, 11, 1), (2, 1, 20, 64, 5, -1), (1, 4, 17, 50, 7, 1)):
+        t = ThinLens(foc_len=50.0, fnum=2.8, kernel_size=ks, sensor_size=[24.0, 36.0], sensor_res=(H, W))
+        img = tt(rng.random((N, C, H, W), dtype=np.float32)).to(DEV)
+        depth = sign * tt(np.stack([synth_depth_mm(H, W, seed=50 + i) for i in range(N)]))[:, None].to(DEV)
+        fd = sign * torch.tensor([900.0, 2500.0][:N], device=DEV)
+        got, want = t.render(img, depth, fd), t.render_psf_tensor(img, depth, fd)
+        assert got.shape == want.shape == (N, C, H, W)
+        assert (got - want).abs().max().item() <= 3e-6, (N, C, H, W, ks, sign)
+    t = ThinLens(foc_len=50.0, fnum=1.8, kernel_size=11, sensor_size=[24.0, 24.0], sensor_res=(32, 64))
+    img = tt(rng.random((1, 3, 32, 64), dtype=np.float32)).to(DEV)
+    depth = torch.full((1, 1, 32, 64), -1500.0, device=DEV)
+    out = t.render(img, depth, torch.tensor([-1500.0], device=DEV))
+    assert torch.equal(out, img)                                          # delta PSF
 
 
 def test_get_training_data_shapes_and_normalisation(repo_root):
