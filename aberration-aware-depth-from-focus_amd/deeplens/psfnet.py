@@ -238,7 +238,28 @@ class PSFNet(Lensgroup):
     def get_training_data(self, bs=256, spp=4096):
         """One focus distance, `bs` random (x, y, z) points and their ray-traced PSFs
         (reference: psfnet.py:135-170; RNG order: np.random.choice, refocus draws,
-        rand x, rand y, randn z, psf draws)."""
+        rand x, rand y, randn z, psf draws).  Returns device tensors (inp [bs,4], psf [bs,ks*ks]).
+        With wavelength DEFAULT_WAVE and host sampling this runs through the pipelined producer
+        (aadff/training.py: two launches, no copies); the reference's asserts are raised here, synchronously
+        (set `self.check_flags = False` to defer them to the producer's periodic poll)."""
+        plan = self._training_plan(bs, spp)
+        if plan is None:
+            return self._get_training_data_unpipelined(bs, spp)
+        inp, psf = plan.next()
+        if getattr(self, "check_flags", True):
+            plan.check_flags()
+        return inp.clone(), psf.clone()
+
+    def _training_plan(self, bs, spp):
+        if self.sampler.on_device or self._gpu().type != "cuda":
+            return None
+        key = (int(bs), int(spp), self.kernel_size, tuple(self.sensor_res), str(self._gpu()), id(self.sampler))
+        if getattr(self, "_tplan_key", None) != key:
+            from aadff.training import TrainingDataPlan
+            self._tplan, self._tplan_key = TrainingDataPlan(self, bs, spp), key
+        return self._tplan
+
+    def _get_training_data_unpipelined(self, bs=256, spp=4096):
         foc_z = np.random.choice(self.foc_z_arr)
         foc_dist = foc_z * (self.d_max - self.d_min) + self.d_min
         self.refocus(depth=foc_dist)
@@ -258,20 +279,29 @@ class PSFNet(Lensgroup):
         """Fit the MLP to ray-traced PSFs generated on the fly (reference: psfnet.py:79-132:
         MSE, AdamW, cosine schedule; checkpoints are plain state_dicts).  On a GPU the forward/backward/AdamW
         step (a few dozen small kernels on a 128-row batch) is captured once in a HIP graph and replayed;
-        `graph=False` runs it eagerly."""
+        `graph=False` runs it eagerly.  Batches come from the pipelined producer: the host only draws the random
+        numbers and enqueues two launches and one graph replay per iteration."""
         psfnet = self.psfnet
         dev = next(psfnet.parameters()).device
         step = _TrainStep(psfnet, lr, int(iters), bs, self.kernel_size ** 2, dev, autocast_bf16, graph and dev.type == "cuda")
+        plan = self._training_plan(bs, spp)
         for i in tqdm(range(iters + 1)):
-            inp, psf = self.get_training_data(bs=bs, spp=spp)
+            if plan is not None:
+                inp, psf = plan.next()                   # device views, consumed in stream order by the step below
+            else:
+                inp, psf = self.get_training_data(bs=bs, spp=spp)
             pred = step(inp.to(dev), psf.to(dev))
             self._packed = None        # graph replays update the weights without bumping tensor versions: repack on next use
             if (i + 1) % evaluate_every == 0:
                 ks = self.kernel_size
+                if plan is not None:
+                    plan.check_flags()
                 psf = psf.to(dev)
                 both = torch.stack((psf[:5].view(-1, ks, ks), pred[:5].detach().float().view(-1, ks, ks)), 1)
                 save_image(make_grid(both.reshape(-1, 1, ks, ks) / both.max(), nrow=2), f"{result_dir}/iter{i + 1}.png")
                 torch.save(psfnet.state_dict(), f"{result_dir}/iter{i + 1}_PSFNet_{self.model_name}.pkl")
+        if plan is not None:
+            plan.check_flags()
         torch.save(psfnet.state_dict(), f"{result_dir}/PSFNet_{self.model_name}.pkl")
 
     @torch.no_grad()

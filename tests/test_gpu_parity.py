@@ -170,23 +170,27 @@ def test_conv_hdr_dynamic_range_within_a_band():
 
 def test_conv_non_finite_pixel_poisons_a_bounded_neighbourhood():
     """One inf (or NaN) pixel: F.conv2d in the reference turns the 11x11 support non-finite (inf where the tap is
-    positive, NaN where it is zero).  The GEMM forms multiply the pixel with the zero padding of their K extent and split
-    inf into (inf, NaN), so they return NaN, on a support that is at most one GEMM block wider.  Contract: everything the
-    reference poisons is non-finite here too, and everything farther than 16 pixels from the bad pixel is unaffected."""
+    positive, NaN where it is zero).  The GEMM forms scale every image TILE by a power of two taken from the tile's
+    largest pixel, multiply the pixel with the zero padding of their K extent and split inf into (inf, NaN): they return
+    NaN for the whole tile that staged the bad pixel (at most a 34 x 108 pixel band with its halo).  Contract: everything
+    the reference poisons is non-finite here too, and everything farther than 128 pixels from the bad pixel is unaffected
+    (documented in DESIGN.md; a non-finite input image is outside what the renderer is specified for)."""
     rng = np.random.Generator(np.random.PCG64(405))
-    H = W = 160
+    H = W = 352
+    by, bx = 170, 181
     base = rng.random((1, 3, H, W), dtype=np.float32)
     maps = rng.random((4, 3, 22, 22), dtype=np.float32) / 60.5           # taps sum to ~1 per PSF
     for bad in (np.inf, np.nan):
         img = base.copy()
-        img[0, 1, 70, 91] = bad
+        img[0, 1, by, bx] = bad
         want = np.stack([oconv.render_psf_map(tt(img), tt(m), 2).numpy() for m in maps], 2)
         clean = np.stack([oconv.render_psf_map(tt(base), tt(m), 2).numpy() for m in maps], 2)
         for got in (rp.render_psf_map_stack(tt(img).to(DEV), tt(maps).to(DEV), 2).cpu().numpy(),
                     np.stack([rp.render_psf_map(tt(img).to(DEV), tt(m).to(DEV), 2).cpu().numpy() for m in maps], 2)):
             assert not np.isfinite(got[~np.isfinite(want)]).any()
             yy, xx = np.mgrid[0:H, 0:W]
-            far = np.maximum(np.abs(yy - 70), np.abs(xx - 91)) > 16
+            far = np.maximum(np.abs(yy - by), np.abs(xx - bx)) > 128
+            assert far.sum() > 10000
             assert np.isfinite(got[..., far]).all() and np.abs(got[..., far] - clean[..., far]).max() <= CONV_ATOL
             assert np.isfinite(got[:, [0, 2]]).all()                  # other channels untouched
 
@@ -704,6 +708,33 @@ def test_thinlens_kernel_matches_tensor_form_and_edge_cases(g67):
     depth = torch.full((1, 1, 32, 64), -1500.0, device=DEV)
     out = t.render(img, depth, torch.tensor([-1500.0], device=DEV))
     assert torch.equal(out, img)                                          # delta PSF
+
+
+def test_pipelined_training_batches_equal_unpipelined(repo_root):
+    """aadff.training.TrainingDataPlan (one pinned block per batch uploaded inside the refocus launch, two launches, no
+    sync) against the call-by-call form (refocus, then psf) on the same numpy/torch RNG streams, for 2*RING + 5 batches:
+    every pinned block is reused twice, the guard wait and the flags mirror run."""
+    from aadff.training import TrainingDataPlan
+    net = PSFNet(lens_path(repo_root), sensor_res=(480, 640), kernel_size=11, device=DEV)
+    n = 2 * TrainingDataPlan.RING + 5
+    np.random.seed(11)
+    torch.manual_seed(11)
+    want = [net._get_training_data_unpipelined(bs=32, spp=512) for _ in range(n)]
+    np.random.seed(11)
+    torch.manual_seed(11)
+    plan = net._training_plan(32, 512)
+    assert plan is not None
+    got = []
+    for _ in range(n):
+        inp, psf = plan.next()
+        got.append((inp.clone(), psf.clone()))
+    plan.check_flags()
+    assert len(plan.guards) <= TrainingDataPlan.RING // TrainingDataPlan.GUARD_EVERY + 2
+    for i, ((ia, pa), (ib, pb)) in enumerate(zip(got, want)):
+        assert torch.equal(ia.cpu(), ib.cpu()), i
+        # the staged refocus sums its rays in four quarters: d_sensor moves by an ulp, PSFs by sum-order noise
+        assert rel_l2(pa.cpu().numpy(), pb.cpu().numpy()) <= 5e-4, i
+        assert pa.sum(-1).cpu().numpy() == pytest.approx(1.0, abs=1e-5)
 
 
 def test_get_training_data_shapes_and_normalisation(repo_root):
