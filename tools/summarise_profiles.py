@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of a tools/prof_r02.sh run from gpurun_out/<tag>_* into profiles/ (tracked):
+kernel-stats CSVs as they are, PMC counter CSVs reduced to one averaged row per kernel, plus two small JSON digests
+(profiles/psf_kernel_pmc.json, profiles/conv_traffic.json) that bench.py quotes as static context."""
+import collections, csv, glob, json, os, shutil, sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02_a"
+G, P = os.path.join(REPO, "gpurun_out"), os.path.join(REPO, "profiles")
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(G, pattern), recursive=True)
+    return f[0] if f else None
+
+
+def pmc_rows(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"]
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        meta[k] = (r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size"], r["Grid_Size"])
+    return {k: ({c: sum(v) / len(v) for c, v in cs.items()}, len(next(iter(cs.values()))), meta[k]) for k, cs in acc.items()}
+
+
+def write_pmc(dst, sources, keep):
+    rows = {}
+    for src in sources:
+        if not src:
+            continue
+        for k, (vals, n, meta) in pmc_rows(src).items():
+            if any(s in k for s in keep):
+                rows.setdefault(k, [{}, n, meta])[0].update(vals)
+    with open(dst, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches_averaged", "vgpr", "sgpr", "lds_bytes", "workgroup", "grid", "counter", "mean_value_per_launch"])
+        for k, (vals, n, meta) in rows.items():
+            for c, v in sorted(vals.items()):
+                w.writerow([k[:100], n, *meta, c, f"{v:.3f}"])
+    return rows
+
+
+for name, sub in (("kernel_stats", "stats"), ("fit_kernel_stats", "fit_stats"), ("local_psf_kernel_stats", "lp_stats")):
+    src = one(f"{tag}_{sub}/**/*_kernel_stats.csv")
+    if src:
+        shutil.copy(src, os.path.join(P, f"{tag}_{name}.csv"))
+for name in ("bench", "bench_fit", "bench_m2"):
+    src = os.path.join(G, f"{tag}_{name}.json")
+    if os.path.exists(src) and os.path.getsize(src):
+        shutil.copy(src, os.path.join(P, f"{tag}_{name}.json"))
+
+rows = write_pmc(os.path.join(P, f"{tag}_psf_kernel_pmc.csv"),
+                 [one(f"{tag}_psf_pmc1/**/*counter_collection.csv"), one(f"{tag}_psf_pmc2/**/*counter_collection.csv")], ("psf_points_kernel",))
+for k, (v, n, meta) in rows.items():
+    if "SQ_INSTS_VALU" in v:
+        stats = one(f"{tag}_stats/**/*_kernel_stats.csv")
+        us = None
+        for r in csv.DictReader(open(stats)):
+            if "psf_points_kernel" in r["Name"]:
+                us = float(r["AverageNs"]) / 1e3
+        simd_cycles = us * 1e-6 * 2.4e9 * 1024 if us else None          # 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
+        json.dump({"kernel": "psf_points_kernel (S=10, N=121, L=3, spp 2048 + 2048 chief)", "source": f"profiles/{tag}_psf_kernel_pmc.csv, profiles/{tag}_kernel_stats.csv",
+                   "us_per_launch_rocprof": us, "SQ_INSTS_VALU": v["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU_quadcycles": v.get("SQ_ACTIVE_INST_VALU"),
+                   "valu_wave_instructions_per_surface_per_lane": round(v["SQ_INSTS_VALU"] / (178421760 / 128), 1),
+                   "note": "a lane carries two rays (packed fp32), so one surface step of a lane = 2 ray-surface steps; 178 421 760 ray-surface steps per launch (SURVEY.md 8d); includes sampling, chief-ray reduction, compaction and splat",
+                   "valu_busy": round(min(1.0, v["SQ_ACTIVE_INST_VALU"] * 4 / simd_cycles), 3) if simd_cycles else None,
+                   "valu_busy_definition": "SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (kernel time x 2.4 GHz x 1024 SIMDs); the chip clocks below 2.4 GHz under load, so this is a lower bound",
+                   "cycles_per_valu_instruction": round(simd_cycles / v["SQ_INSTS_VALU"], 2) if simd_cycles else None}, open(os.path.join(P, "psf_kernel_pmc.json"), "w"), indent=1)
+
+f, w = one(f"{tag}_fetch/**/*counter_collection.csv"), one(f"{tag}_write/**/*counter_collection.csv")
+if f and w:
+    rows = write_pmc(os.path.join(P, f"{tag}_conv_traffic_pmc.csv"), [f, w], ("conv_psf_map_sbatch",))
+    for k, (v, n, meta) in rows.items():
+        fetch, write = v["FETCH_SIZE"] * 1024, v["WRITE_SIZE"] * 1024
+        json.dump({"kernel": "conv_psf_map_sbatch_kernel (S=10 stack, 1024x1024x3)",
+                   "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes on bench.py (tools/prof_r02.sh), profiles/{tag}_conv_traffic_pmc.csv",
+                   "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"],
+                   "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read -> doubled; WRITE_SIZE as is. Both include Infinity-Cache hits.",
+                   "hbm_bytes_per_launch": int(2 * fetch + write), "unique_bytes_per_launch": 138412032, "algorithmic_bytes_per_launch": 251658240},
+                  open(os.path.join(P, "conv_traffic.json"), "w"), indent=1)
+lp = one(f"{tag}_lp_fetch/**/*counter_collection.csv")
+if lp:
+    write_pmc(os.path.join(P, f"{tag}_local_psf_fetch_pmc.csv"), [lp], ("local_psf",))
+print(sorted(os.listdir(P)))
