@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import _abi
+from . import ops  # noqa: F401  (registers torch.ops.aadff.*)
 
 MAX_WIDTH, MAX_OUT = 256, 128
 EVENT_HOOK = None      # optional callable(start: bool) recording a torch.cuda.Event around the kernel launch (bench.py)
@@ -91,9 +92,7 @@ def forward(packed, inp, mode, img=None, ks=0, slices=0, check=True):
     st = _abi.stream_ptr(dev)
     with torch.cuda.device(dev):
         if mode == 0:
-            out = torch.empty((P, packed.n_out), dtype=torch.float32, device=dev)
-            _abi.call("aadff_psfnet_forward", _abi.ptr(inp), P, _abi.ptr(packed.wpack), _abi.ptr(packed.bias), packed.n,
-                      packed.ins, packed.outs, 0, _abi.ptr(out), None, None, 0, 0, 0, 0, 0, _abi.ptr(packed.flags), st)
+            out = torch.ops.aadff.psfnet_forward(inp, packed.wpack, packed.bias, list(packed.ins), list(packed.outs), packed.flags)
             _check(packed, check)
             return out
         x = _abi.f32c(img, dev)
@@ -119,15 +118,12 @@ def render_rgbd(packed, img, depth, xs, ys, foc_z, d_min, d_range, ks, check=Tru
     S = fz.shape[1]
     xs, ys = _abi.f32c(xs, dev), _abi.f32c(ys, dev)
     assert d.shape == (N, H, W) and xs.shape == (W,) and ys.shape == (H,)
-    out = torch.empty((N, Cc, S, H, W), dtype=torch.float32, device=dev)
     inv_range = float(np.float32(1.0) / np.float32(d_range))          # tensor / python scalar = tensor * (1 / scalar) in ATen
-    with torch.cuda.device(dev):
-        if EVENT_HOOK is not None:
-            EVENT_HOOK(True)
-        _abi.call("aadff_psfnet_render_rgbd", _abi.ptr(d), _abi.ptr(xs), _abi.ptr(ys), _abi.ptr(fz), C.c_float(d_min), C.c_float(inv_range),
-                  N, S, _abi.ptr(packed.wpack), _abi.ptr(packed.bias), packed.n, packed.ins, packed.outs, _abi.ptr(x), _abi.ptr(out),
-                  Cc, H, W, ks, _abi.ptr(packed.flags), _abi.stream_ptr(dev))
-        if EVENT_HOOK is not None:
-            EVENT_HOOK(False)
+    if EVENT_HOOK is not None:
+        EVENT_HOOK(True)
+    out = torch.ops.aadff.psfnet_render_rgbd(x, d, xs, ys, fz, float(d_min), inv_range, packed.wpack, packed.bias, list(packed.ins),
+                                             list(packed.outs), ks, packed.flags)
+    if EVENT_HOOK is not None:
+        EVENT_HOOK(False)
     _check(packed, check)
     return out

@@ -13,11 +13,21 @@ reference's call order so results are comparable sample f
 import ctypes as C
 import json
 import logging
-
+import random                    # noqa: F401  (the next five names ride the star-import chain the reference scripts rely on:
+from datetime import datetime    # noqa: F401   `from deeplens.psfnet import *` must provide torch, nn, np, plt, tqdm,
+                                 #              save_image, make_grid ... as deeplens/optics.py:5-20 does)
 import numpy as np
 import torch
 import torch.nn.functional as F
 from scipy import stats
+from tqdm import tqdm            # noqa: F401
+
+try:                             # plotting is out of scope, the NAME is part of the star surface
+    import matplotlib
+    matplotlib.use("Agg", force=False)
+    import matplotlib.pyplot as plt   # noqa: F401
+except Exception:                # pragma: no cover - matplotlib is present in the image
+    plt = None
 
 from aadff import _abi
 from aadff.sampling import HostSampler
@@ -29,6 +39,7 @@ from .render_psf import render_psf_map
 from .surfaces import *          # noqa: F401,F403
 from .surfaces import Aspheric, pack_table, trace_ray_object
 from .utils import *             # noqa: F401,F403
+from .utils import make_grid, save_image   # noqa: F401
 
 
 def raise_psf_flags(bits):
@@ -370,15 +381,12 @@ class Lensgroup(DeepObj):
         u_main = torch.stack(mains).to(dev)
         u_chief = torch.stack(chiefs).to(dev) if center else None
         pts = _abi.f32c(points, dev)
-        G = int(round(np.sqrt(N))) * ks
-        out = torch.empty((L, G, G) if map_layout else (N, L, ks, ks), dtype=torch.float32, device=dev)
         flags = torch.zeros(1, dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
-            _abi.call("aadff_psf_points", _abi.ptr(pts), 1, N, L, _abi.ptr(self._table(wvlns)),
-                      _abi.ptr(self._table([DEFAULT_WAVE])), self._lens_const(), _abi.ptr(self._state_device()),
-                      _abi.ptr(u_main), spp, 2 * L * spp, 2 * spp, _abi.ptr(u_chief), GEO_SPP, 2 * L * GEO_SPP, 2 * GEO_SPP,
-                      ks, int(bool(center)), int(map_layout),
-                      _abi.ptr(out), None, _abi.ptr(flags), _abi.stream_ptr(dev))
+        from aadff import ops
+        um = u_main.reshape(1, L, 2, spp)
+        uc = u_chief.reshape(1, L, 2, GEO_SPP) if center else torch.empty((1, L, 2, 0), device=dev)
+        out = torch.ops.aadff.psf_points(pts.unsqueeze(0), self._table(wvlns), self._table([DEFAULT_WAVE]), ops.lens_const_to_list(self._lens_const()),
+                                         self._state_device(), um, uc, ks, bool(center), bool(map_layout), flags)[0]
         if getattr(self, "check_flags", True):
             raise_psf_flags(int(flags.item()))          # the reference asserts inside psf_center (optics.py:901): same sync point
         return out.to(self.device) if self.device.type != "cuda" else out

@@ -354,17 +354,11 @@ class ThinLens(DeepObj):
         ks = self.kernel_size
         if C > 4 or ks not in (3, 5, 7, 9, 11, 13):
             return self.render_psf_tensor(img, depth, foc_dist)
-        import ctypes as C_
-        from aadff import _abi
+        from aadff import _abi, ops  # noqa: F401
         _abi.require_gpu()
         dev = img.device if img.is_cuda else torch.device("cuda", torch.cuda.current_device())
-        x, d, fd = _abi.f32c(img, dev), _abi.f32c(depth, dev).reshape(N, 1, H, W), _abi.f32c(foc_dist, dev).reshape(N)
-        neg = (d < 0).any().to(torch.int32).reshape(1)          # whole-tensor sign test of the reference, stays on the device
-        out = torch.empty_like(x)
-        with torch.cuda.device(dev):
-            _abi.call("aadff_thinlens_render", _abi.ptr(x), _abi.ptr(d), _abi.ptr(fd), _abi.ptr(neg), _abi.ptr(out), N, C, H, W, ks,
-                      C_.c_float(self.foc_len / self.fnum), C_.c_float(self.foc_len), C_.c_float(1.0 / self.ps),
-                      C_.c_float(self.d_min), C_.c_float(self.d_max), _abi.stream_ptr(dev))
+        out = torch.ops.aadff.thinlens_render(_abi.f32c(img, dev), _abi.f32c(depth, dev), _abi.f32c(foc_dist, dev), ks, float(self.foc_len),
+                                              float(self.fnum), float(self.ps), float(self.d_min), float(self.d_max))
         return out.to(img.device)
 
     @torch.no_grad()

@@ -1,6 +1,7 @@
 """Image-space PSF application on MI355X (HIP kernels in csrc/conv.hip).
 
-Same four functions, argument order and assertion messages as the reference's
+Each function validates like the reference, then calls its torch custom op (torch.ops.aadff.*, aadff/ops.py), which
+packs pointers for the C ABI.  Same four functions, argument order and assertion messages as the reference's
 deeplens/render_psf.py (:12 render_psf, :31 render_psf_map, :76 local_psf_render, :110
 local_psf_render_high_res).  Inputs on any device are made contiguous fp32 on the GPU,
 outputs come back on the input's device.  Forward only: the reference never
@@ -10,6 +11,7 @@ import numpy as np
 import torch
 
 from aadff import _abi
+from aadff import ops as _ops      # noqa: F401  (registers torch.ops.aadff.*)
 
 
 def _prep(t, what):
@@ -30,11 +32,7 @@ def render_psf(img, psf):
     assert ks == ks2 and ks % 2 == 1, "PSF kernel size should be odd"
     if img.numel() == 0:
         return torch.empty_like(img, dtype=torch.float32)
-    x, p = _abi.f32c(img, dev), _abi.f32c(psf, dev)
-    out = torch.empty_like(x)
-    with torch.cuda.device(dev):
-        _abi.call("aadff_render_psf", _abi.ptr(x), _abi.ptr(p), _abi.ptr(out), B, C, H, W, ks, _abi.stream_ptr(dev))
-    return out.to(img.device)
+    return torch.ops.aadff.render_psf(_abi.f32c(img, dev), _abi.f32c(psf, dev)).to(img.device)
 
 
 def render_psf_map(img, psf_map, grid):
@@ -52,12 +50,7 @@ def render_psf_map(img, psf_map, grid):
     if img.numel() == 0:                      # empty batch: the reference's conv2d loop returns an empty tensor too
         return torch.empty_like(img, dtype=torch.float32)
     dev = _prep(img, "render_psf_map")
-    x, p = _abi.f32c(img, dev), _abi.f32c(psf_map, dev)
-    out = torch.empty_like(x)
-    with torch.cuda.device(dev):
-        _abi.call("aadff_render_psf_map", _abi.ptr(x), _abi.ptr(p), _abi.ptr(out), B, C, H, W, grid, ks,
-                  _abi.stream_ptr(dev))
-    return out.to(img.device)
+    return torch.ops.aadff.render_psf_map(_abi.f32c(img, dev), _abi.f32c(psf_map, dev), grid).to(img.device)
 
 
 def render_psf_map_stack(img, psf_maps, grid):
@@ -74,12 +67,7 @@ def render_psf_map_stack(img, psf_maps, grid):
     if img.numel() == 0 or S == 0:
         return torch.empty((B, C, S, H, W), dtype=torch.float32, device=img.device)
     dev = _prep(img, "render_psf_map_stack")
-    x, p = _abi.f32c(img, dev), _abi.f32c(psf_maps, dev)
-    out = torch.empty((B, C, S, H, W), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(p), _abi.ptr(out), B, C, S, H, W, grid, ks,
-                  _abi.stream_ptr(dev))
-    return out.to(img.device)
+    return torch.ops.aadff.render_psf_map_stack(_abi.f32c(img, dev), _abi.f32c(psf_maps, dev), grid).to(img.device)
 
 
 def local_psf_render(input, psf, kernel_size=11):
@@ -93,11 +81,7 @@ def local_psf_render(input, psf, kernel_size=11):
     x = _abi.f32c(input, dev)
     p = _abi.f32c(psf, dev).reshape(-1, h, w, kernel_size, kernel_size)
     assert p.shape[0] == b, "psf should be [B, H, W, ks, ks]"
-    out = torch.empty_like(x)
-    with torch.cuda.device(dev):
-        _abi.call("aadff_local_psf_render", _abi.ptr(x), _abi.ptr(p), _abi.ptr(out), b, c, h, w, kernel_size,
-                  _abi.stream_ptr(dev))
-    return out.to(input.device)
+    return torch.ops.aadff.local_psf_render(x, p, kernel_size).to(input.device)
 
 
 def local_psf_render_high_res(input, psf, patch_size=[320, 480], kernel_size=11):

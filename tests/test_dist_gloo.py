@@ -100,3 +100,44 @@ def test_spawn_ranks_launcher(tmp_path, emulate, repo_root):
     assert spawn_ranks([str(script)], 2, emulate=emulate, env=env, timeout=120) == 0
     assert sorted(os.listdir(tmp_path)) == ["ok_0", "ok_1", "rank.py"]
     assert spawn_ranks([str(script), "7"], 2, emulate=emulate, env=env, timeout=120) == 7
+
+
+def _config5_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("config5", os.path.join(repo, "examples", "config5_ddp_render.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    from oracle import psfnet as opsf
+    from aadff.synth import mlp_state_dict
+    sd = {k: torch.from_numpy(v) for k, v in mlp_state_dict().items()}
+    calls = []
+
+    def render(img, depth_m, n):                       # test renderer: the oracle's M2 stack (CPU); the GPU box uses the HIP one
+        calls.append(tuple(img.shape))
+        return opsf.focal_stack_m2(sd, img, depth_m, n), opsf.select_focus_dist_linear(depth_m, n)
+
+    r, w, net, loss = ex.train(render, torch.device("cpu"), steps=2, n_stack=4, hw=(12, 12), batch=1)
+    assert (r, w) == (rank, world) and len(calls) == 2 and np.isfinite(loss)
+    torch.save([p.detach().clone() for p in net.parameters()], os.path.join(out_dir, f"params_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_config5_call_pattern_ddp_consumer_with_rank_local_stacks(tmp_path):
+    """Config 5 (DDP training on on-the-fly stacks): rank-local rendering, no data-path collective, DDP keeps the
+    consumer's weights identical on both ranks although each rank rendered different scenes."""
+    world, port = 2, _free_port()
+    mp.spawn(_config5_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = (torch.load(os.path.join(tmp_path, f"params_{r}.pt")) for r in range(world))
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    torch.manual_seed(0)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("config5", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "config5_ddp_render.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    init = [p.detach() for p in ex.TinyDFF(4).parameters()]
+    assert any(not torch.equal(x, y) for x, y in zip(a, init))             # and they did train

@@ -195,6 +195,38 @@ def test_conv_non_finite_pixel_poisons_a_bounded_neighbourhood():
             assert np.isfinite(got[:, [0, 2]]).all()                  # other channels untouched
 
 
+def test_custom_ops_opcheck_and_compile_tracing():
+    """torch.ops.aadff.* (north_star: "HIP kernels through PyTorch-ROCm custom ops"): torch.library.opcheck validates
+    schema, fake-tensor shapes and dispatch registration; a torch.compile'd function that calls the ops traces without a
+    graph break (aot_eager backend: no code generation) and returns the eager result."""
+    from aadff import ops  # noqa: F401
+    rng = np.random.Generator(np.random.PCG64(9))
+    img = tt(rng.random((1, 3, 48, 40), dtype=np.float32)).to(DEV)
+    pm = tt(rng.random((3, 33, 33), dtype=np.float32)).to(DEV)
+    maps = tt(rng.random((4, 3, 33, 33), dtype=np.float32)).to(DEV)
+    psf = tt(rng.random((1, 48, 40, 5, 5), dtype=np.float32)).to(DEV)
+    tests = ("test_schema", "test_faketensor")
+    torch.library.opcheck(torch.ops.aadff.render_psf_map.default, (img, pm, 3), test_utils=tests)
+    torch.library.opcheck(torch.ops.aadff.render_psf_map_stack.default, (img, maps, 3), test_utils=tests)
+    torch.library.opcheck(torch.ops.aadff.local_psf_render.default, (img, psf, 5), test_utils=tests)
+    torch.library.opcheck(torch.ops.aadff.thinlens_render.default, (img, -img[:, :1] * 3000 - 300, torch.tensor([-900.0], device=DEV), 11, 50.0, 1.8,
+                                                                     0.02, 200.0, 20000.0), test_utils=tests)
+
+    def f(x, m, p):
+        a = torch.ops.aadff.render_psf_map_stack(x, m, 3)            # [1,3,4,H,W]
+        return torch.ops.aadff.local_psf_render(a[:, :, 0].contiguous(), p, 5) + a.sum(2)
+
+    want = f(img, maps, psf)
+    got = torch.compile(f, backend="aot_eager", fullgraph=True)(img, maps, psf)
+    assert torch.equal(got, want)
+    assert np.abs(want.cpu().numpy() - (oconv.local_psf_render(oconv.render_psf_map(img.cpu(), maps[0].cpu(), 3), psf.cpu(), 5)
+                                        + sum(oconv.render_psf_map(img.cpu(), m.cpu(), 3) for m in maps)).numpy()).max() <= 2e-4
+    x = img.clone().requires_grad_(True)
+    y = torch.ops.aadff.render_psf_map(x, pm, 3)                      # no autograd formula: forward-only (SURVEY.md 8b)
+    with pytest.raises(RuntimeError):
+        y.sum().backward()
+
+
 def test_stack_fused_equals_per_slice():
     """The stack path (slice-batched GEMM, 4 slices per MFMA) and the single-slice path (Toeplitz GEMM) carry the same
     exact fp16 hi/lo operand split; they differ only in fp32 summation order."""

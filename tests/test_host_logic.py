@@ -177,3 +177,38 @@ def test_preset_sampler_replays_selected_slices():
     assert torch.equal(out.reshape(2, per), block[[1, 3]])
     with pytest.raises(AssertionError):
         ps.rand(1)
+
+
+def test_star_import_surface_of_the_reference_scripts():
+    """`from deeplens.psfnet import *` is how 1_fit_psfnet.py / 2_aber_aware_dff_*.py get torch, nn, np, plt, tqdm,
+    save_image ... (reference chain psfnet -> optics -> surfaces -> basics, deeplens/optics.py:5-20, basics.py:7-12)."""
+    ns = {}
+    exec("from deeplens.psfnet import *", ns)
+    for name in ("torch", "nn", "np", "plt", "tqdm", "save_image", "make_grid", "random", "datetime", "json", "F", "nnF", "stats",
+                 "PSFNet", "ThinLens", "Lensgroup", "Ray", "Material", "render_psf_map", "local_psf_render", "forward_integral",
+                 "GEO_SPP", "DEPTH", "WAVE_RGB", "DEFAULT_WAVE", "EPSILON", "set_seed", "set_logger", "MLP"):
+        assert name in ns, name
+    assert ns["nn"].DataParallel is torch.nn.DataParallel          # 2_aber_aware_dff_aif.py:67 resolves it this way
+
+
+def test_custom_ops_are_registered_with_shape_functions():
+    """torch.ops.aadff.* (aadff/ops.py): schemas exist, the fake/meta implementations infer the output shapes, and a CPU
+    call fails loudly (no CPU fallback)."""
+    from aadff import ops  # noqa: F401
+    m = lambda *s: torch.empty(*s, device="meta")
+    assert torch.ops.aadff.render_psf_map(m(2, 3, 20, 24), m(3, 33, 33), 3).shape == (2, 3, 20, 24)
+    assert torch.ops.aadff.render_psf_map_stack(m(2, 3, 20, 24), m(5, 3, 33, 33), 3).shape == (2, 3, 5, 20, 24)
+    assert torch.ops.aadff.render_psf(m(1, 3, 8, 8), m(3, 5, 5)).shape == (1, 3, 8, 8)
+    assert torch.ops.aadff.local_psf_render(m(1, 3, 8, 8), m(1, 8, 8, 5, 5), 5).shape == (1, 3, 8, 8)
+    assert torch.ops.aadff.thinlens_render(m(2, 3, 8, 8), m(2, 1, 8, 8), m(2), 11, 50.0, 1.8, 0.02, 200.0, 20000.0).shape == (2, 3, 8, 8)
+    fl = torch.empty(1, dtype=torch.int32, device="meta")
+    assert torch.ops.aadff.psfnet_forward(m(10, 4), m(4), m(4), [4, 64], [64, 121], fl).shape == (10, 121)
+    assert torch.ops.aadff.psfnet_render_rgbd(m(2, 3, 8, 9), m(2, 8, 9), m(9), m(8), m(2, 5), -200.0, -1e-4, m(4), m(4), [4, 64], [64, 121],
+                                              11, fl).shape == (2, 3, 5, 8, 9)
+    lc = [12.0] + [1.0] * 12
+    assert torch.ops.aadff.psf_points(m(2, 121, 3), m(4), m(4), lc, m(64), m(2, 3, 2, 256), m(2, 3, 2, 2048), 11, True, True, fl).shape == (2, 3, 121, 121)
+    assert torch.ops.aadff.psf_points(m(1, 7, 3), m(4), m(4), lc, m(32), m(1, 1, 2, 64), m(1, 1, 2, 0), 5, False, False, fl).shape == (1, 7, 1, 5, 5)
+    with pytest.raises(NotImplementedError):
+        torch.ops.aadff.render_psf_map(torch.zeros(1, 3, 8, 8), torch.zeros(3, 9, 9), 3)
+    schema = str(torch.ops.aadff.psfnet_forward.default._schema)
+    assert "Tensor(a" in schema and "flags" in schema                      # flags is declared as mutated
