@@ -507,7 +507,12 @@ __device__ __forceinline__ f2 vmin3(f2 a, f2 b, f2 c) {
 // (beta = c (p0.d) - dz from the root), and  d' = eta d + g n  with  g = -(sqrt(1 - eta^2 (1 - (d.n)^2)) + eta d.n)
 // is  (eta dx + (g c) x,  eta dy + (g c) y,  eta dz + (g c)(dz tau) - g)   (surfaces.py:589-679 restated).
 typedef const __attribute__((address_space(4))) aadff_surface_t* csurf_t;
-__device__ __forceinline__ void sphere_step2(const __attribute__((address_space(4))) aadff_surface_t& s, Ray2& r, f2& vm) {
+struct SphereP {                          // the scalars one sphere step needs
+    float d, c, r2, eta, eta2, thr;
+};
+// (Measured and rejected: issuing the next entry's scalar loads by hand ahead of the arithmetic, with the ray registers
+// tied to the asm statements to pin the order: 376 us against 332 us for the compiler's own s_load / s_waitcnt placement.)
+__device__ __forceinline__ void sphere_step2(const SphereP& s, Ray2& r, f2& vm) {
     const f2 t0 = (s.d - r.oz) * vrcp(r.dz);
     r.ox += r.dx * t0; r.oy += r.dy * t0;                               // vertex plane
     const f2 rho2 = r.ox * r.ox + r.oy * r.oy;
@@ -522,14 +527,13 @@ __device__ __forceinline__ void sphere_step2(const __attribute__((address_space(
     vm = vmin3(vm, disc, t0 + tau);                                     // hit the sphere, t >= 0 (surfaces.py:466-470)
     const f2 dn = beta + s.c * tau;
     const f2 cos2 = dn * dn;
-    const float thr = __builtin_bit_cast(float, __builtin_bit_cast(int, s.cos2_min_fwd) + 1);    // cos2 > min <=> cos2 >= nextup(min)
-    vm = vmin3(vm, s.r2 - (r.ox * r.ox + r.oy * r.oy), cos2 - thr);   // inside the aperture; refraction valid (surfaces.py:660-666)
-    const f2 sq = vsqrt(vmax0(s.eta_fwd2 * cos2 + (1.f - s.eta_fwd2)));
-    const f2 g = -(sq + s.eta_fwd * dn);
+    vm = vmin3(vm, s.r2 - (r.ox * r.ox + r.oy * r.oy), cos2 - s.thr);   // inside the aperture; refraction valid (surfaces.py:660-666)
+    const f2 sq = vsqrt(vmax0(s.eta2 * cos2 + (1.f - s.eta2)));
+    const f2 g = -(sq + s.eta * dn);
     const f2 gc = g * s.c;
-    r.dx = s.eta_fwd * r.dx + gc * r.ox;
-    r.dy = s.eta_fwd * r.dy + gc * r.oy;
-    r.dz = s.eta_fwd * r.dz + (gc * dzt - g);
+    r.dx = s.eta * r.dx + gc * r.ox;
+    r.dy = s.eta * r.dy + gc * r.oy;
+    r.dz = s.eta * r.dz + (gc * dzt - g);
 }
 // stop / asphere, forward (the general code of react2 with the margin form of validity)
 __device__ __forceinline__ void other_step2(const aadff_surface_t& s, Ray2& r, f2& vm, int& nan_flag) {
@@ -583,7 +587,13 @@ __device__ __forceinline__ void trace_part2(const aadff_surface_t* __restrict__ 
     int i = first;
     while (i < last) {
         if (cs[i].kind == AADFF_SURF_SPHERIC) {
-            do { sphere_step2(cs[i], r, vm); ++i; } while (i < last && cs[i].kind == AADFF_SURF_SPHERIC);
+            do {
+                SphereP cur;
+                cur.d = cs[i].d; cur.c = cs[i].c; cur.r2 = cs[i].r2; cur.eta = cs[i].eta_fwd; cur.eta2 = cs[i].eta_fwd2;
+                cur.thr = __builtin_bit_cast(float, __builtin_bit_cast(int, cs[i].cos2_min_fwd) + 1);
+                sphere_step2(cur, r, vm);
+                ++i;
+            } while (i < last && cs[i].kind == AADFF_SURF_SPHERIC);
         } else {
             other_step2(surf[i], r, vm, nan_flag);
             ++i;
