@@ -100,7 +100,7 @@ class StackPlan:
         self.stage_counters = torch.zeros(S, dtype=torch.int32, device=dev)
         self.refocus_scratch = torch.zeros(S * 16, dtype=torch.int32, device=dev)     # 64 B per focus state
         self.stage_generation = 0
-        self._geo_key, self._dep, self._pts = None, None, None
+        self._geo = {}
 
     def uniforms(self, sampler):
         """Device block of this step's uniforms, drawn in the reference's order."""
@@ -174,14 +174,18 @@ class StackPlan:
         raise_psf_flags(bits)
 
     def geometry(self, focus, depth_plane_mm):
+        """Device copies of the focus distances [S] and of the field points [S,N,3] at this depth plane, cached per
+        (focus list, plane): a sharded run alternates between scenes and must not re-upload them every time."""
         key = (tuple(focus), float(depth_plane_mm))
-        if key != self._geo_key:
+        hit = self._geo.get(key)
+        if hit is None:
+            if len(self._geo) >= 64:
+                self._geo.clear()
             pts = self.pts_xy.clone()
             pts[:, 2] = float(depth_plane_mm)
-            self._pts = pts.unsqueeze(0).repeat(self.S, 1, 1).contiguous().to(self.dev)
-            self._dep = torch.tensor(focus, dtype=torch.float32).to(self.dev)
-            self._geo_key = key
-        return self._dep, self._pts
+            hit = (torch.tensor(focus, dtype=torch.float32).to(self.dev), pts.unsqueeze(0).repeat(self.S, 1, 1).contiguous().to(self.dev))
+            self._geo[key] = hit
+        return hit
 
 
 @torch.no_grad()
@@ -334,12 +338,22 @@ def shard_units(n_units, rank, world):
 
 
 class PresetSampler:
-    """Replays a block of uniforms drawn earlier (host or device) in place of the lens's sampler."""
+    """Replays uniforms drawn earlier (host or device) in place of the lens's sampler.  `rows` selects rows of a 2-D host
+    block without materialising the selection (plain memcpy per row: torch's parallel CPU copies and gathers stall for
+    milliseconds on a box that exposes more logical CPUs than its cgroup quota lets run)."""
 
-    def __init__(self, block):
-        self.block, self.pos, self.on_device = block.reshape(-1), 0, block.is_cuda
+    def __init__(self, block, rows=None):
+        self.on_device = block.is_cuda
+        if rows is not None and not block.is_cuda and block.dim() == 2 and block.is_contiguous():
+            self.block2d, self.rows, self.block = block, list(rows), None
+        else:
+            self.block2d, self.rows = None, None
+            self.block = (block if rows is None else block[list(rows)]).reshape(-1)
+        self.pos = 0
 
     def _take(self, n):
+        if self.block is None:                      # lazily flatten (device consumers / odd sizes)
+            self.block = self.block2d[self.rows].reshape(-1)
         out = self.block[self.pos:self.pos + n]
         assert out.numel() == n, "preset uniforms exhausted"
         self.pos += n
@@ -352,7 +366,18 @@ class PresetSampler:
         return self._take(int(sum(sizes)))
 
     def rand_into(self, out):
-        out.copy_(self._take(out.numel()))
+        n, es = out.numel(), out.element_size()
+        if self.block is None and self.pos == 0 and out.is_contiguous() and n == len(self.rows) * self.block2d.shape[1]:
+            per = self.block2d.shape[1]
+            for i, r in enumerate(self.rows):
+                C.memmove(out.data_ptr() + i * per * es, self.block2d.data_ptr() + r * per * es, per * es)
+            self.pos = n
+            return out
+        src = self._take(n)
+        if src.is_cuda or not src.is_contiguous() or not out.is_contiguous():
+            out.copy_(src)
+        else:
+            C.memmove(out.data_ptr(), src.data_ptr(), n * es)
         return out
 
 
@@ -394,7 +419,7 @@ class SceneUnitRenderer:
                 sl = [k for k, _ in items]
                 self.seed_scene(scene)
                 block = saved.rand_block([S * self.per]).reshape(S, self.per)        # the whole stack's draws
-                lens.sampler = PresetSampler(block[sl].contiguous())
+                lens.sampler = PresetSampler(block, rows=sl)
                 n = len(sl)
                 plan = self.plans.get(n)
                 if plan is None:

@@ -105,6 +105,8 @@ def main():
         # Self-launch: one child per rank, started BEFORE this process has made any GPU call (it never makes one).
         from aadff.dist import spawn_ranks
         raise SystemExit(spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus, emulate=args.emulate_ranks))
+    # the GPU box exposes 256 logical CPUs under a 16-CPU cgroup quota: unbounded OpenMP pools stall small torch CPU ops
+    torch.set_num_threads(max(1, usable_cpus() // max(1, int(os.environ.get("WORLD_SIZE", "1")))))
     if args.mode == "m2":
         return main_m2(args)
     if args.mode == "fit":

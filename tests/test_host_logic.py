@@ -171,12 +171,14 @@ def test_preset_sampler_replays_selected_slices():
     per = stack_uniform_layout(64)[0]
     torch.manual_seed(5)
     block = HostSampler().rand_block([4 * per]).reshape(4, per)
-    ps = PresetSampler(block[[1, 3]].contiguous())
-    out = torch.empty(2 * per)
-    ps.rand_into(out)
-    assert torch.equal(out.reshape(2, per), block[[1, 3]])
-    with pytest.raises(AssertionError):
-        ps.rand(1)
+    for ps in (PresetSampler(block[[1, 3]].contiguous()), PresetSampler(block, rows=[1, 3])):
+        out = torch.empty(2 * per)
+        ps.rand_into(out)
+        assert torch.equal(out.reshape(2, per), block[[1, 3]])
+        with pytest.raises(AssertionError):
+            ps.rand(1)
+    ps = PresetSampler(block, rows=[2, 0])                     # piecewise consumers fall back to the flattened selection
+    assert torch.equal(torch.cat((ps.rand(5), ps.rand_block([per - 5, per]))), block[[2, 0]].reshape(-1))
 
 
 def test_star_import_surface_of_the_reference_scripts():
