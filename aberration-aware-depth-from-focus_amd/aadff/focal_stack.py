@@ -65,7 +65,10 @@ def draw_stack_uniforms(sampler, S, spp, L=3, spp_chief=GEO_SPP, spp_focus=GEO_S
 
 
 STAGED_UPLOAD = os.environ.get("AADFF_STAGED_UPLOAD", "1") != "0"
-STAGE_FIRST = int(os.environ.get("AADFF_STAGE_FIRST", "3"))   # focus states uploaded by the refocus launch
+try:                                                          # focus states uploaded by the refocus launch (tuning override, clamped)
+    STAGE_FIRST = max(0, min(64, int(os.environ.get("AADFF_STAGE_FIRST", "3"))))
+except ValueError:
+    STAGE_FIRST = 3
 
 
 class StackPlan:

@@ -459,8 +459,16 @@ __device__ __forceinline__ void lds_read16(uint2v& a, uint2v& b, unsigned byte_a
 template <int RB, int NC>
 __global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
     const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, int C, int S, int H, int W,
-    int grid, int ntx, int nty, int npass, PatchBounds pb) {
+    int grid, int ntx, int nty, int npass, PatchBounds pb, int stagger) {
     using namespace sb;
+    if (stagger) {
+        // Workgroups that share a CU are dispatched ~256 linear ids apart and would all run the same phase at the same
+        // time (stage -> build T -> matrix phase -> stores).  A start delay by residency slot spreads the phases so that
+        // one workgroup's HBM reads overlap another's MFMAs.
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int slot = (int)((lin >> 8) % 5u);
+        for (int i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     constexpr int NW = NC, THP = RB + KS - 1, NSL = 4 * NC;
     static_assert(RB % 2 == 0 && THP % 2 == 0, "bands are whole row pairs");
     static_assert(WDW <= 64, "one lane per dword column");
@@ -739,8 +747,11 @@ static int launch_fast(const float* img, const float* psf, float* out, int B, in
         const int waste = (S + n - 1) / n * n - S;
         if (waste < best) { best = waste; nw = n; }
     }
-    const char* env = getenv("AADFF_CONV_NW");
-    if (env && KS == 11) nw = atoi(env);
+    const char* env = getenv("AADFF_CONV_NW");                 // tuning override, validated: garbage / out-of-range values are ignored
+    if (env && KS == 11) {
+        const int v = atoi(env);
+        if (v >= 1 && v <= maxnw) nw = v;
+    }
     const int nchunk = (S + nw - 1) / nw;
     AADFF_CHECK_ARG((size_t)B * C * nchunk <= 65535, "render_psf_map: B*C*chunks too large");
     PatchBounds pbm = pb;
@@ -766,7 +777,8 @@ static int launch_fast(const float* img, const float* psf, float* out, int B, in
             PatchBounds pbs = pb;
             pbs.m_ntx = magic_of(sntx); pbs.m_nty = magic_of(snty); pbs.m_nchunk = magic_of(npass); pbs.m_c = magic_of(C);
             dim3 gs(sntx * grid, snty * grid, B * C * npass);
-#define AADFF_LAUNCH_S(NCV) hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV>), gs, dim3(64 * NCV), 0, st, img, psf, out, C, S, H, W, grid, sntx, snty, npass, pbs)
+            static const int stagger = [] { const char* e = getenv("AADFF_CONV_STAGGER"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 64 ? 64 : v); }();   // default 1: -1 % in bench, -7 % back to back
+#define AADFF_LAUNCH_S(NCV) hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV>), gs, dim3(64 * NCV), 0, st, img, psf, out, C, S, H, W, grid, sntx, snty, npass, pbs, stagger)
             switch (nc) {
                 case 1: AADFF_LAUNCH_S(1); break;
                 case 2: AADFF_LAUNCH_S(2); break;

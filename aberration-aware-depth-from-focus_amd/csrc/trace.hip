@@ -20,7 +20,7 @@ constexpr int kNewtonMaxIter = 10;       // deeplens/surfaces.py:26
 constexpr float kTolTight = 10e-6f;      // deeplens/surfaces.py:27
 constexpr float kTolLoose = 50e-6f;      // deeplens/surfaces.py:28
 constexpr float kStepBound = 5.f;        // deeplens/surfaces.py:29
-constexpr float kStepConverged = 1e-3f;  // fused kernels: a Newton update below 1 um ends the loop (see newton2)
+constexpr float kStepConverged = 1e-2f;  // fused kernels: a Newton update below 10 um ends the loop (see newton2)
 [[maybe_unused]] constexpr float kTwoPiHi = 3.14159274101257324f;   // (float)np.pi (libm sin/cos builds)
 
 struct Ray {
@@ -302,6 +302,18 @@ __device__ __forceinline__ f2 vabs(f2 a) { return __builtin_elementwise_abs(a); 
 __device__ __forceinline__ f2 vsel(i2 m, f2 a, f2 b) { return (f2){m.x ? a.x : b.x, m.y ? a.y : b.y}; }
 __device__ __forceinline__ bool any2(i2 m) { return (m.x | m.y) != 0; }
 
+// sum a_j r2^j (to be multiplied by r2) and its r2-derivative, by Horner
+__device__ __forceinline__ void poly2(const aadff_surface_t& s, f2 r2, f2& ps, f2& pd) {
+    if (s.n_ai <= 6) {
+        ps = f2s(s.ai[5]); pd = f2s(s.dai[5]);
+#pragma unroll
+        for (int j = 4; j >= 0; --j) { ps = ps * r2 + s.ai[j]; pd = pd * r2 + s.dai[j]; }
+    } else {
+        ps = f2s(s.ai[AADFF_MAX_AI - 1]); pd = f2s(s.dai[AADFF_MAX_AI - 1]);
+#pragma unroll
+        for (int j = AADFF_MAX_AI - 2; j >= 0; --j) { ps = ps * r2 + s.ai[j]; pd = pd * r2 + s.dai[j]; }
+    }
+}
 __device__ __forceinline__ void sag_and_slope2(const aadff_surface_t& s, f2 r2, f2& sag, f2& slope) {
     const f2 a = (1.f + s.k) * r2 * (s.c * s.c);
 #ifndef AADFF_NO_RSQ_SLOPE
@@ -319,15 +331,7 @@ __device__ __forceinline__ void sag_and_slope2(const aadff_surface_t& s, f2 r2, 
 #endif
     if (s.n_ai > 0) {
         f2 ps, pd;
-        if (s.n_ai <= 6) {
-            ps = f2s(s.ai[5]); pd = f2s(s.dai[5]);
-#pragma unroll
-            for (int j = 4; j >= 0; --j) { ps = ps * r2 + s.ai[j]; pd = pd * r2 + s.dai[j]; }
-        } else {
-            ps = f2s(s.ai[AADFF_MAX_AI - 1]); pd = f2s(s.dai[AADFF_MAX_AI - 1]);
-#pragma unroll
-            for (int j = AADFF_MAX_AI - 2; j >= 0; --j) { ps = ps * r2 + s.ai[j]; pd = pd * r2 + s.dai[j]; }
-        }
+        poly2(s, r2, ps, pd);
         sag += ps * r2;
         slope += pd;
     }
@@ -391,16 +395,19 @@ __device__ __forceinline__ void newton2(const aadff_surface_t& s, const Ray2& r,
     const f2 od = r.dx * r.ox + r.dy * r.oy;
     f2 tau = f2s(0.f);
 #ifndef AADFF_NEWTON_PLANE_START
+    i2 hit0;
     {
         f2 tc;
-        const i2 hit = conic_root2(s, r, tc);
-        tau = vsel(hit, tc, f2s(0.f));
+        hit0 = conic_root2(s, r, tc);
+        tau = vsel(hit0, tc, f2s(0.f));
     }
 #endif
     // The reference leaves its loop when the residual BEFORE the last update is below 5e-5 mm, i.e. it spends one
     // whole evaluation confirming a converged point, then takes its extra (strict) step.  A Newton update shorter than
-    // kStepConverged leaves a residual of order (curvature) x step^2 << 5e-5 mm, so the confirming evaluation is
-    // skipped (hit points move by < 1e-9 mm); the strict step's own |residual| < 1e-5 test still guards every ray.
+    // kStepConverged = 1e-2 mm leaves an error of f''/(2 f') x step^2 <= 0.03 x 1e-4 = 3e-6 mm (f'' is the surface
+    // curvature seen along the ray, f' ~ -dz), i.e. a residual 3x under the strict step's |residual| < 1e-5 test, and the
+    // strict step — a full Newton update like any other — then takes the point to ~1e-12 mm: the confirming evaluation is
+    // skipped without moving the hit (with 1e-3 the rim rays of nearly every wave forced one more whole evaluation).
     f2 ft = f2s(kMaxT), step = f2s(kMaxT);
 #if !defined(AADFF_NEWTON_LITERAL_EXIT) && !defined(AADFF_NEWTON_CHECK_EVERY_STEP)
     // The first evaluation always runs (the reference enters its loop with ft = MAXT) and the second does whenever any
@@ -408,6 +415,25 @@ __device__ __forceinline__ void newton2(const aadff_surface_t& s, const Ray2& r,
     // batch: run both without the wave-wide exit test, then continue under it.  (Steps on converged rays are no-ops
     // at the 1e-9 level, which is also what the reference's batch-wide loop does to them.)  A NaN residual survives
     // every later update, so it is tested once, on the strict step's residual.
+#if !defined(AADFF_NEWTON_PLANE_START) && !defined(AADFF_NEWTON_GENERIC_FIRST)
+    if (s.n_ai > 0 && !__any(any2(alive & ~hit0))) {
+        // Every live ray of the wave starts ON the conic (tau = its conic root), where the residual is the polynomial
+        // part alone, sag_conic = dz tau, and sf = sqrt(1 - (1+k) c^2 r^2) = 1 - (1+k) c dz tau: the first Newton step
+        // needs no square root and no conic sag (30 instead of 74 instructions per lane); same update as the generic
+        // evaluation up to rounding.
+        const f2 px = r.ox + r.dx * tau, py = r.oy + r.dy * tau;
+        const f2 r2 = px * px + py * py;
+        f2 ps, pd;
+        poly2(s, r2, ps, pd);
+        ft = ps * r2;
+        const f2 sf = 1.f - ((1.f + s.k) * s.c) * (r.dz * tau);
+        const f2 slope = (0.5f * s.c) * vrcp(sf) + pd;
+        const f2 dfdt = slope * (2.f * (dxy2 * tau + od)) - r.dz;
+        step = ft * vrcp(dfdt + kEps);
+        step = vmin(vmax(step, f2s(-kStepBound)), f2s(kStepBound));
+        tau -= step;
+    } else
+#endif
     ft = newton_step2<false>(s, r, dxy2, od, tau, nullptr, &step);
     ft = newton_step2<false>(s, r, dxy2, od, tau, nullptr, &step);
     for (int it = 2; it < kNewtonMaxIter; ++it) {
@@ -767,7 +793,7 @@ struct StageArgs {
 #endif
 constexpr int kPsfThreads = AADFF_PSF_THREADS, kPsfWaves = kPsfThreads / 64;
 constexpr int kCompactMax = 2048;         // rays per compaction chunk of the main pass (48 KB of LDS)
-__global__ __launch_bounds__(kPsfThreads) void psf_points_kernel(const float* __restrict__ points, int N, int L,
+__global__ __launch_bounds__(kPsfThreads, 6) void psf_points_kernel(const float* __restrict__ points, int N, int L,
                                                           const aadff_surface_t* __restrict__ surf_main,
                                                           const aadff_surface_t* __restrict__ surf_chief,
                                                           aadff_lens_const_t lc,
