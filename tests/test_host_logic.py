@@ -214,3 +214,22 @@ def test_custom_ops_are_registered_with_shape_functions():
         torch.ops.aadff.render_psf_map(torch.zeros(1, 3, 8, 8), torch.zeros(3, 9, 9), 3)
     schema = str(torch.ops.aadff.psfnet_forward.default._schema)
     assert "Tensor(a" in schema and "flags" in schema                      # flags is declared as mutated
+
+
+def test_dff_factory_shims(repo_root):
+    """dff.factory.get_lens / get_dataset and dff.utils.select_focus_dist resolve like in 2_aber_aware_dff_aif.py:27-60."""
+    from dff.factory import get_dataset, get_lens
+    from dff.utils import select_focus_dist as sfd
+    from deeplens.psfnet import ThinLens
+    assert sfd is select_focus_dist
+    thin = {"lens": "thinlens", "foc_len": 50.0, "fnum": 1.8, "sensor_size": ["24", "36"], "dataset": "Synthetic", "n": 3}
+    args = {"ks": 11, "res": (32, 48), "device": torch.device("cpu"), "train": thin, "test": dict(thin, dataset="Middlebury2014")}
+    a, b = get_lens(args)
+    assert isinstance(a, ThinLens) and isinstance(b, ThinLens) and a.ps == 24.0 / 32 and a.kernel_size == 11
+    with pytest.raises(NotImplementedError, match="Middlebury2014"):
+        get_dataset(args)
+    args["test"]["dataset"] = "Synthetic"
+    tr, te = get_dataset(args)
+    img, depth = tr[1]
+    assert len(tr) == 3 and img.shape == (3, 32, 48) and depth.shape == (1, 32, 48) and 0.4 < float(depth.min()) and float(depth.max()) <= 5.0
+    assert not torch.equal(tr[0][0], te[0][0])
