@@ -30,68 +30,126 @@ _MLP_CHUNK = 1 << 19
 
 class _TrainStep:
     """One optimisation step of train_psfnet: MSE(MLP(inp), psf) -> backward -> AdamW, learning rate on the cosine
-    schedule of torch.optim.lr_scheduler.CosineAnnealingLR(T_max=iters, eta_min=0) (closed form).  With `graph` the
-    step is captured in a HIP graph after three eager warm-up steps (static input/target buffers, capturable AdamW
-    with the learning rate in a device tensor) and replayed: same arithmetic, ~60 kernel launches less per step."""
+    schedule of torch.optim.lr_scheduler.CosineAnnealingLR(T_max=iters, eta_min=0).
+
+    graph=False: the plain torch loop (torch.optim.AdamW, closed-form schedule set on the host).
+    graph=True (GPU): the parameters are re-homed as views of ONE flat fp32 buffer and the optimiser is the fused HIP
+    kernel `aadff_adamw_step` (csrc/optim.hip: AdamW + the cosine schedule from a device step counter, one launch instead
+    of the ~60 of torch's capturable AdamW); zero-grad, forward, backward and that launch are captured once in a HIP graph
+    after three eager warm-up steps and replayed.  With bf16 the forward/backward run on a bf16 COPY of the parameters that
+    the optimiser kernel refreshes (same arithmetic as autocast, which casts the weights to bf16 every step and the
+    gradients back, without its ~47 cast kernels per step); sigmoid output, L1 normalisation and the loss stay fp32."""
+
+    BETAS, EPS, WD = (0.9, 0.999), 1e-8, 0.01            # torch.optim.AdamW defaults (the reference passes only lr)
 
     def __init__(self, psfnet, lr, iters, bs, nout, dev, bf16, graph):
         self.net, self.cri, self.dev, self.bf16 = psfnet, nn.MSELoss(), dev, bf16 and dev.type == "cuda"
         self.use_graph, self.graph, self.pred = graph, None, None
         self.lr0, self.T, self.t = float(lr), max(1, int(iters)), 0
-        if graph:
-            self.inp = torch.zeros(bs, 4, device=dev)
-            self.psf = torch.zeros(bs, nout, device=dev)
-            self.optim = torch.optim.AdamW(psfnet.parameters(), lr=torch.tensor(float(lr), device=dev), capturable=True)
-        else:
+        if not graph:
             self.optim = torch.optim.AdamW(psfnet.parameters(), lr)
+            return
+        self.inp = torch.zeros(bs, 4, device=dev)
+        self.psf = torch.zeros(bs, nout, device=dev)
+        params = list(psfnet.parameters())
+        n = sum(p.numel() for p in params)
+        self.n = n
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in params:                                  # the module's tensors become views of the flat buffer
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.detach().reshape(-1).float())
+                p.data = self.flat[off:off + k].view_as(p)
+                off += k
+        if self.bf16:
+            self.flat16 = self.flat.to(torch.bfloat16)
+            self.gbuf = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+            self.shadow, off = {}, 0
+            for p in params:
+                k = p.numel()
+                w = self.flat16[off:off + k].view_as(p).requires_grad_(True)     # leaf: a view of a tensor without grad
+                w.grad = self.gbuf[off:off + k].view_as(p)
+                self.shadow[id(p)] = w
+                off += k
+        else:
+            self.flat16 = None
+            self.gbuf = torch.zeros(n, dtype=torch.float32, device=dev)
+            off = 0
+            for p in params:
+                k = p.numel()
+                p.grad = self.gbuf[off:off + k].view_as(p)
+                off += k
+
+    def _forward(self, inp):
+        if not (self.use_graph and self.bf16):
+            if self.use_graph:
+                return self.net(inp)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):
+                return self.net(inp)
+        h = inp.to(torch.bfloat16)                            # the bf16 copy, no autocast
+        for mod in self.net.net:
+            if isinstance(mod, nn.Linear):
+                h = nn.functional.linear(h, self.shadow[id(mod.weight)], self.shadow[id(mod.bias)] if mod.bias is not None else None)
+            elif isinstance(mod, nn.ReLU):
+                h = torch.relu(h)
+            elif isinstance(mod, nn.Sigmoid):
+                h = torch.sigmoid(h)
+            else:
+                h = mod(h)
+        return nn.functional.normalize(h.float(), p=1, dim=-1)
 
     def _body(self, inp, psf):
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):
-            pred = self.net(inp)
-        loss = self.cri(pred.float(), psf)
-        loss.backward()
-        self.optim.step()
+        if not self.use_graph:
+            pred = self._forward(inp)
+            self.cri(pred.float(), psf).backward()
+            self.optim.step()
+            return pred
+        import ctypes as C_
+        from aadff import _abi
+        self.gbuf.zero_()
+        pred = self._forward(inp)
+        self.cri(pred.float(), psf).backward()                # accumulates in place into the views of gbuf
+        with torch.cuda.device(self.dev):
+            _abi.call("aadff_adamw_step", _abi.ptr(self.flat), _abi.ptr(self.gbuf), int(self.bf16), _abi.ptr(self.m), _abi.ptr(self.v),
+                      _abi.ptr(self.flat16), self.n, _abi.ptr(self.step_dev), C_.c_float(self.lr0), self.T, C_.c_float(self.BETAS[0]),
+                      C_.c_float(self.BETAS[1]), C_.c_float(self.EPS), C_.c_float(self.WD), _abi.stream_ptr(self.dev))
         return pred
 
     def __call__(self, inp, psf):
         if not self.use_graph:
             self.optim.zero_grad()
             pred = self._body(inp, psf)
-        else:
-            self.inp.copy_(inp)
-            self.psf.copy_(psf)
-            if self.t < 3:                                   # eager warm-up on the capture stream (torch's capture recipe)
-                self.side = getattr(self, "side", None) or torch.cuda.Stream(self.dev)
-                self.side.wait_stream(torch.cuda.current_stream(self.dev))
-                with torch.cuda.stream(self.side):
-                    self.optim.zero_grad(set_to_none=True)
-                    pred = self._body(self.inp, self.psf)
-                torch.cuda.current_stream(self.dev).wait_stream(self.side)
-            else:
-                if self.graph is None:                       # capture records only: the replay below runs this step
-                    graph = torch.cuda.CUDAGraph()
-                    self.optim.zero_grad(set_to_none=True)
-                    try:
-                        with torch.cuda.graph(graph, stream=self.side):
-                            self.pred = self._body(self.inp, self.psf)
-                        self.graph = graph
-                    except RuntimeError as e:                 # capture refused: run this and all later steps eagerly
-                        import logging
-                        logging.getLogger(__name__).warning("train step not graph-capturable (%s): running eagerly", e)
-                        self.use_graph, self.graph = "eager-static", None
-                if self.graph is not None:
-                    self.graph.replay()
-                    pred = self.pred
-                else:
-                    self.optim.zero_grad(set_to_none=True)
-                    pred = self._body(self.inp, self.psf)
-        self.t += 1
-        new_lr = 0.5 * self.lr0 * (1.0 + math.cos(math.pi * min(self.t, self.T) / self.T))
-        for g in self.optim.param_groups:
-            if torch.is_tensor(g["lr"]):
-                g["lr"].fill_(new_lr)
-            else:
+            self.t += 1
+            new_lr = 0.5 * self.lr0 * (1.0 + math.cos(math.pi * min(self.t, self.T) / self.T))
+            for g in self.optim.param_groups:
                 g["lr"] = new_lr
+            return pred
+        self.inp.copy_(inp)
+        self.psf.copy_(psf)
+        if self.t < 3 or self.use_graph == "eager-static":    # eager warm-up on the capture stream (torch's capture recipe)
+            self.side = getattr(self, "side", None) or torch.cuda.Stream(self.dev)
+            self.side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(self.side):
+                pred = self._body(self.inp, self.psf)
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
+        else:
+            if self.graph is None:                            # capture records only: the replay below runs this step
+                graph = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(graph, stream=self.side):
+                        self.pred = self._body(self.inp, self.psf)
+                    self.graph = graph
+                except RuntimeError as e:                      # capture refused: run this and all later steps eagerly
+                    import logging
+                    logging.getLogger(__name__).warning("train step not graph-capturable (%s): running eagerly", e)
+                    self.use_graph, self.graph = "eager-static", None
+                    return self.__call__(inp, psf)
+            self.graph.replay()
+            pred = self.pred
+        self.t += 1
         return pred
 
 

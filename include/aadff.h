@@ -278,6 +278,16 @@ int aadff_post_computation(int S, const aadff_surface_t* surf_green, aadff_lens_
  * (it reads the mirror after an event it waits on anyway).  One 64-thread launch. */
 int aadff_publish_flags(const int* flags_dev, int* mirror_host, aadff_stream_t stream);
 
+/* One optimisation step of the PSF-network fit on a FLAT fp32 parameter buffer: torch.optim.AdamW (betas, eps, decoupled
+ * weight decay) with the learning rate of CosineAnnealingLR(T_max = t_max, eta_min = 0) evaluated in the kernel from the
+ * device step counter (`*step_dev` = completed steps; incremented by this call), so the launch pair is HIP-graph
+ * capturable with no host-side scalar.  Replaces the optimiser half of deeplens/psfnet.py:85-108 (AdamW + scheduler.step()).
+ *   grad: fp32 [n], or bf16 [n] with grad_is_bf16 != 0 (gradients of the bf16 parameter copy)
+ *   param_bf16_or_null: bf16 [n] copy of the updated parameters (round to nearest even) for the bf16 leg */
+int aadff_adamw_step(float* param, const void* grad, int grad_is_bf16, float* exp_avg, float* exp_avg_sq,
+                     void* param_bf16_or_null, long n, int* step_dev, float lr0, int t_max, float beta1, float beta2,
+                     float eps, float weight_decay, aadff_stream_t stream);
+
 /* ------------------------------------------------------------------ host helper */
 
 /* HOST routine (no GPU work): the next n float32 uniforms of torch's CPU generator, bit-identical
