@@ -70,7 +70,9 @@ PROTOTYPES = {
     "aadff_refocus_staged": [_P, _I, _P, _P, _L, _I, _L, _P, LensConst, _P, _P, _P],
     "aadff_post_computation": [_I, _P, LensConst, _P, _P],
     "aadff_publish_flags": [_P, _P, _P],
-    "aadff_adamw_step": [_P, _P, _I, _P, _P, _P, _L, _P, _F, _I, _F, _F, _F, _F, _P],
+    "aadff_relu_bwd_bias": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "aadff_psfnet_head_loss_grad": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "aadff_adamw_step": [_P, _P, _I, _P, _P, _P, _L, _P, _P, _F, _I, _F, _F, _F, _F, _P],
     "aadff_host_mt19937_uniform_f32": [_P, _L, _L, _P],
 }
 OTHER_SYMBOLS = ["aadff_abi_version", "aadff_last_error", "aadff_device_info"]

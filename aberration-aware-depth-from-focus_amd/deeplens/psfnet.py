@@ -28,6 +28,72 @@ DMAX = 20000   # [mm]
 _MLP_CHUNK = 1 << 19
 
 
+class _LinearInto(torch.autograd.Function):
+    """y = x W^T + b whose backward writes dW and db straight into caller-provided buffers (views of a flat gradient
+    buffer) and returns only dx: the parameters are not autograd leaves, nothing is accumulated or zeroed."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gw, gb):
+        ctx.save_for_backward(x, w)
+        ctx.gw, ctx.gb = gw, gb
+        return nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        torch.mm(dy.t(), x, out=ctx.gw)
+        torch.sum(dy, 0, out=ctx.gb)
+        return (dy @ w if ctx.needs_input_grad[0] else None), None, None, None, None
+
+
+class _LinearReluInto(torch.autograd.Function):
+    """relu(x W^T + b) as ONE GEMM with a ReLU epilogue (torch._addmm_activation -> hipBLASLt), backward as _LinearInto
+    after masking dy with the saved output."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gw, gb):
+        y = torch._addmm_activation(b, x, w.t(), use_gelu=False)
+        ctx.save_for_backward(x, w, y)
+        ctx.gw, ctx.gb = gw, gb
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        from aadff import _abi
+        dy = dy.contiguous()
+        dz = torch.empty_like(dy)
+        with torch.cuda.device(dy.device):               # ReLU backward + bias gradient in one launch (csrc/optim.hip)
+            _abi.call("aadff_relu_bwd_bias", _abi.ptr(dy), _abi.ptr(y), _abi.ptr(dz), _abi.ptr(ctx.gb), dy.shape[0], dy.shape[1],
+                      int(dy.dtype == torch.bfloat16), _abi.stream_ptr(dy.device))
+        torch.mm(dz.t(), x, out=ctx.gw)
+        return (dz @ w if ctx.needs_input_grad[0] else None), None, None, None, None
+
+
+class _HeadLoss(torch.autograd.Function):
+    """(pred, loss-gradient) of the network head in one launch: pred = F.normalize(sigmoid(z).float(), p=1), and the
+    gradient of nn.MSELoss()(pred, target) w.r.t. z, computed in the forward and handed out in the backward (the scalar
+    loss itself is not needed by the fit loop; `backward` scales by the incoming gradient of the dummy loss)."""
+
+    @staticmethod
+    def forward(ctx, z, target):
+        from aadff import _abi
+        z = z.contiguous()
+        pred = torch.empty(z.shape, dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z)
+        with torch.cuda.device(z.device):
+            _abi.call("aadff_psfnet_head_loss_grad", _abi.ptr(z), _abi.ptr(target), _abi.ptr(pred), _abi.ptr(dz), z.shape[0], z.shape[1],
+                      int(z.dtype == torch.bfloat16), _abi.stream_ptr(z.device))
+        ctx.save_for_backward(dz)
+        ctx.mark_non_differentiable(pred)
+        return pred, z.new_zeros(())                     # the second output stands for the loss in the autograd graph
+
+    @staticmethod
+    def backward(ctx, _gpred, gloss):
+        (dz,) = ctx.saved_tensors
+        return dz, None                                   # gloss == 1 (loss.backward()); kept out of the kernel chain
+
+
 class _TrainStep:
     """One optimisation step of train_psfnet: MSE(MLP(inp), psf) -> backward -> AdamW, learning rate on the cosine
     schedule of torch.optim.lr_scheduler.CosineAnnealingLR(T_max=iters, eta_min=0).
@@ -57,6 +123,7 @@ class _TrainStep:
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
         self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.scal = torch.zeros(4, dtype=torch.float32, device=dev)
         off = 0
         with torch.no_grad():
             for p in params:                                  # the module's tensors become views of the flat buffer
@@ -64,42 +131,39 @@ class _TrainStep:
                 self.flat[off:off + k].copy_(p.detach().reshape(-1).float())
                 p.data = self.flat[off:off + k].view_as(p)
                 off += k
-        if self.bf16:
-            self.flat16 = self.flat.to(torch.bfloat16)
-            self.gbuf = torch.zeros(n, dtype=torch.bfloat16, device=dev)
-            self.shadow, off = {}, 0
-            for p in params:
-                k = p.numel()
-                w = self.flat16[off:off + k].view_as(p).requires_grad_(True)     # leaf: a view of a tensor without grad
-                w.grad = self.gbuf[off:off + k].view_as(p)
-                self.shadow[id(p)] = w
-                off += k
-        else:
-            self.flat16 = None
-            self.gbuf = torch.zeros(n, dtype=torch.float32, device=dev)
-            off = 0
-            for p in params:
-                k = p.numel()
-                p.grad = self.gbuf[off:off + k].view_as(p)
-                off += k
+        self.flat16 = self.flat.to(torch.bfloat16) if self.bf16 else None
+        src = self.flat16 if self.bf16 else self.flat
+        self.gbuf = torch.zeros(n, dtype=src.dtype, device=dev)
+        self.wb, off = {}, 0                                   # id(module parameter) -> (tensor the layers use, its gradient view)
+        for p in params:
+            k = p.numel()
+            # requires_grad only so that the layer outputs join the autograd graph; _LinearInto returns no gradient for them
+            self.wb[id(p)] = (src[off:off + k].view_as(p).requires_grad_(True), self.gbuf[off:off + k].view_as(p))
+            off += k
 
-    def _forward(self, inp):
-        if not (self.use_graph and self.bf16):
-            if self.use_graph:
-                return self.net(inp)
+    def _forward(self, inp, target=None):
+        if not self.use_graph:
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):
                 return self.net(inp)
-        h = inp.to(torch.bfloat16)                            # the bf16 copy, no autocast
-        for mod in self.net.net:
+        # graph mode: the layers run through _LinearInto, whose backward WRITES dW / db into the views of the flat gradient
+        # buffer (autograd's own accumulation would add 22 `grad += new` kernels and need the buffer zeroed every step)
+        h = inp.to(torch.bfloat16) if self.bf16 else inp
+        mods = list(self.net.net)
+        for i, mod in enumerate(mods):
             if isinstance(mod, nn.Linear):
-                h = nn.functional.linear(h, self.shadow[id(mod.weight)], self.shadow[id(mod.bias)] if mod.bias is not None else None)
+                w, b = self.wb[id(mod.weight)], self.wb[id(mod.bias)]
+                fused = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU) and mod.bias is not None
+                h = (_LinearReluInto if fused else _LinearInto).apply(h, w[0], b[0], w[1], b[1])
             elif isinstance(mod, nn.ReLU):
-                h = torch.relu(h)
+                if not (i > 0 and isinstance(mods[i - 1], nn.Linear) and mods[i - 1].bias is not None):
+                    h = torch.relu(h)
             elif isinstance(mod, nn.Sigmoid):
+                if i == len(mods) - 1 and target is not None and h.shape[-1] <= 128:
+                    return _HeadLoss.apply(h, target)     # (pred, loss stand-in): sigmoid + L1 normalise + MSE gradient fused
                 h = torch.sigmoid(h)
             else:
                 h = mod(h)
-        return nn.functional.normalize(h.float(), p=1, dim=-1)
+        return nn.functional.normalize(h.float(), p=1, dim=-1), None
 
     def _body(self, inp, psf):
         if not self.use_graph:
@@ -109,12 +173,13 @@ class _TrainStep:
             return pred
         import ctypes as C_
         from aadff import _abi
-        self.gbuf.zero_()
-        pred = self._forward(inp)
-        self.cri(pred.float(), psf).backward()                # accumulates in place into the views of gbuf
+        pred, loss = self._forward(inp, psf)
+        if loss is None:
+            loss = self.cri(pred.float(), psf)
+        loss.backward()                                       # _LinearInto / _LinearReluInto write every dW / db into gbuf
         with torch.cuda.device(self.dev):
             _abi.call("aadff_adamw_step", _abi.ptr(self.flat), _abi.ptr(self.gbuf), int(self.bf16), _abi.ptr(self.m), _abi.ptr(self.v),
-                      _abi.ptr(self.flat16), self.n, _abi.ptr(self.step_dev), C_.c_float(self.lr0), self.T, C_.c_float(self.BETAS[0]),
+                      _abi.ptr(self.flat16), self.n, _abi.ptr(self.step_dev), _abi.ptr(self.scal), C_.c_float(self.lr0), self.T, C_.c_float(self.BETAS[0]),
                       C_.c_float(self.BETAS[1]), C_.c_float(self.EPS), C_.c_float(self.WD), _abi.stream_ptr(self.dev))
         return pred
 

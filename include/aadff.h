@@ -283,10 +283,20 @@ int aadff_publish_flags(const int* flags_dev, int* mirror_host, aadff_stream_t s
  * device step counter (`*step_dev` = completed steps; incremented by this call), so the launch pair is HIP-graph
  * capturable with no host-side scalar.  Replaces the optimiser half of deeplens/psfnet.py:85-108 (AdamW + scheduler.step()).
  *   grad: fp32 [n], or bf16 [n] with grad_is_bf16 != 0 (gradients of the bf16 parameter copy)
- *   param_bf16_or_null: bf16 [n] copy of the updated parameters (round to nearest even) for the bf16 leg */
+ *   param_bf16_or_null: bf16 [n] copy of the updated parameters (round to nearest even) for the bf16 leg
+ *   scratch4: 4 device floats (the step's scalars, written by a one-thread launch in front of the update) */
 int aadff_adamw_step(float* param, const void* grad, int grad_is_bf16, float* exp_avg, float* exp_avg_sq,
-                     void* param_bf16_or_null, long n, int* step_dev, float lr0, int t_max, float beta1, float beta2,
-                     float eps, float weight_decay, aadff_stream_t stream);
+                     void* param_bf16_or_null, long n, int* step_dev, float* scratch4, float lr0, int t_max, float beta1,
+                     float beta2, float eps, float weight_decay, aadff_stream_t stream);
+
+/* Two fused pieces of the fit step's backward (HIP-graph capturable, fp32 or bf16 tensors):
+ * aadff_relu_bwd_bias: dz = dy * (y > 0) and db = column sums of dz for one hidden layer ([M,N] row-major) — the
+ *   ReLU backward + bias gradient of deeplens/psfnet_arch.py:24-41 under autograd;
+ * aadff_psfnet_head_loss_grad: pred = L1-normalised sigmoid(z) (psfnet_arch.py:41-47), and dz = d/dz of
+ *   nn.MSELoss()(pred, target) (deeplens/psfnet.py:94-106) for z [B,N], N <= 128; pred and target are fp32. */
+int aadff_relu_bwd_bias(const void* dy, const void* y, void* dz, void* db, int M, int N, int is_bf16, aadff_stream_t stream);
+int aadff_psfnet_head_loss_grad(const void* z, const float* target, float* pred, void* dz, int B, int N, int is_bf16,
+                                aadff_stream_t stream);
 
 /* ------------------------------------------------------------------ host helper */
 
