@@ -883,8 +883,9 @@ constexpr int LP_NPX = 64, LP_MAXC = 4;
 // load of 64 floats plus a KS-1 float tail, and ALL of them are issued before the first is written to LDS: as a loop of
 // dependent load -> store iterations this staging was a chain of ~38 memory latencies per run and, not the PSF stream,
 // set the speed of the gather kernels (measured: 196 -> see DESIGN.md).
-template <int KS, int CN>      // CN > 0: compile-time channel count (no per-channel branches); CN == 0: runtime C <= LP_MAXC
-__device__ __forceinline__ void lp_stage_window(const float* __restrict__ img, float* tl, int b, int C, int H, int W, int y, int x0, int lane) {
+template <int KS, int CN, int NWV = 1>      // CN > 0: compile-time channel count (no per-channel branches); CN == 0: runtime C <= LP_MAXC
+__device__ __forceinline__ void lp_stage_window(const float* __restrict__ img, float* tl, int b, int C, int H, int W, int y, int x0, int lane,
+                                                int wave = 0) {                         // NWV waves share the rows: row index % NWV == wave
     constexpr int PAD = KS / 2, TWD = LP_NPX + KS - 1;
     constexpr int MC = CN > 0 ? CN : LP_MAXC;
     float v0[MC * KS], v1[MC * KS];
@@ -895,6 +896,7 @@ __device__ __forceinline__ void lp_stage_window(const float* __restrict__ img, f
         if (CN > 0 || cc < C) {
 #pragma unroll
             for (int u = 0; u < KS; ++u) {
+                if (NWV > 1 && (cc * KS + u) % NWV != wave) continue;
                 const int yy = min(max(y - PAD + u, 0), H - 1);
                 const float* row = img + ((size_t)(b * C + cc) * H + yy) * W;
                 v0[cc * KS + u] = row[xa];
@@ -907,6 +909,7 @@ __device__ __forceinline__ void lp_stage_window(const float* __restrict__ img, f
         if (CN > 0 || cc < C) {
 #pragma unroll
             for (int u = 0; u < KS; ++u) {
+                if (NWV > 1 && (cc * KS + u) % NWV != wave) continue;
                 tl[(cc * KS + u) * TWD + lane] = v0[cc * KS + u];
                 if (lane < KS - 1) tl[(cc * KS + u) * TWD + LP_NPX + lane] = v1[cc * KS + u];
             }
@@ -975,39 +978,43 @@ __global__ __launch_bounds__(64) void local_psf_kernel(const float* __restrict__
 // flight at once, and each lane then reads ITS pixel's taps from LDS at a pitch of ks*ks dwords (odd: the 32 lanes of a
 // ds_read_b32 group hit 32 different banks).  The old form let every lane walk its own 484-byte row with 16-byte loads:
 // one wave-instruction touched 64 different rows.  One wave per workgroup, 40 KB of LDS -> 4 runs (120 KB) in flight
-// per CU while other workgroups of the CU compute.
+// per CU while other workgroups of the CU compute.  A workgroup is 2 or 4 waves that split the pieces, the window rows and the
+// tap rows of the run (partial sums meet through the freed tap buffer): the shorter a workgroup computes, the larger the
+// share of its life it spends with loads in flight.
 typedef const __attribute__((address_space(1))) void* lp_gptr_t;
 typedef __attribute__((address_space(3))) void* lp_lptr_t;
 #ifndef AADFF_LP_DMA_AUX
 #define AADFF_LP_DMA_AUX 0          // 2 = nt (streamed-once hint)
 #endif
-template <int KS, int CN>
-__global__ __launch_bounds__(64) void local_psf_dma_kernel(const float* __restrict__ img, const float* __restrict__ psf,
-                                                            float* __restrict__ out, int C, int H, int W) {
+template <int KS, int CN, int NWV>
+__global__ __launch_bounds__(64 * NWV) void local_psf_dma_kernel(const float* __restrict__ img, const float* __restrict__ psf,
+                                                                  float* __restrict__ out, int C, int H, int W) {
     constexpr int KK = KS * KS, TWD = LP_NPX + KS - 1;
     constexpr int RUN_BYTES = LP_NPX * KK * 4, PIECES = (RUN_BYTES + 1023) / 1024;
     extern __shared__ __attribute__((aligned(16))) float lp_smem[];      // (64*KK + C*KS*TWD) floats: 40 744 B at ks 11, C 3 -> 4 per CU
     float* wl = lp_smem;
     float* tl = lp_smem + LP_NPX * KK;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = NWV > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     const int x0 = blockIdx.x * LP_NPX, y = blockIdx.y, b = blockIdx.z;
     const int npx = min(LP_NPX, W - x0);
     const int bytes = npx * KK * 4;                          // multiple of 16 (W % 4 == 0)
     const char* src = reinterpret_cast<const char*>(psf + ((size_t)(b * H + y) * W + x0) * KK);
 #pragma unroll
     for (int p = 0; p < PIECES; ++p) {
+        if (NWV > 1 && p % NWV != wave) continue;           // the waves of a workgroup share the run's pieces
         const int off = p * 1024 + lane * 16;
         if (off < bytes)
             __builtin_amdgcn_global_load_lds((lp_gptr_t)(src + off), (lp_lptr_t)(reinterpret_cast<char*>(wl) + p * 1024), 16, 0, AADFF_LP_DMA_AUX);
     }
-    lp_stage_window<KS, CN>(img, tl, b, C, H, W, y, x0, lane);
+    lp_stage_window<KS, CN, NWV>(img, tl, b, C, H, W, y, x0, lane, wave);
     __syncthreads();                                         // also waits for the DMA pieces (vmcnt(0))
-    if (lane >= npx) return;
     constexpr int MC = CN > 0 ? CN : LP_MAXC;
     const float* wr = wl + lane * KK;
     float acc[MC] = {};
     // One wave per SIMD cannot hide LDS latency by occupancy: read a whole tap row (KS taps + MC*KS window values)
-    // into registers in one burst, one row ahead of the FMAs that consume it.
+    // into registers in one burst, one row ahead of the FMAs that consume it.  With NWV = 2 the tap rows alternate
+    // between the two waves (half the compute latency per run: the workgroup spends more of its life with loads in flight).
     auto load_row = [&](int u, float (&w)[KS], float (&x)[MC][KS]) {
 #pragma unroll
         for (int v = 0; v < KS; ++v) w[v] = wr[u * KS + v];
@@ -1019,20 +1026,37 @@ __global__ __launch_bounds__(64) void local_psf_dma_kernel(const float* __restri
             }
     };
     float w0[KS], x0r[MC][KS], w1[KS], x1r[MC][KS];
-    load_row(0, w0, x0r);
+    const int ustart = wave;                                 // rows ustart, ustart + NWV, ...
+    if (ustart < KS) load_row(ustart, w0, x0r);
 #pragma unroll
-    for (int u = 0; u < KS; ++u) {
-        if (u + 1 < KS) {
-            if (u & 1) load_row(u + 1, w0, x0r); else load_row(u + 1, w1, x1r);
+    for (int k = 0; k < (KS + NWV - 1) / NWV; ++k) {
+        const int u = ustart + k * NWV;
+        if (u >= KS) break;
+        if (u + NWV < KS) {
+            if (k & 1) load_row(u + NWV, w0, x0r); else load_row(u + NWV, w1, x1r);
         }
         asm volatile("" ::: "memory");                       // keep the next row's reads ahead of this row's FMAs
 #pragma unroll
         for (int v = 0; v < KS; ++v) {
 #pragma unroll
             for (int cc = 0; cc < MC; ++cc)
-                if (CN > 0 || cc < C) acc[cc] = fmaf((u & 1) ? x1r[cc][v] : x0r[cc][v], (u & 1) ? w1[v] : w0[v], acc[cc]);
+                if (CN > 0 || cc < C) acc[cc] = fmaf((k & 1) ? x1r[cc][v] : x0r[cc][v], (k & 1) ? w1[v] : w0[v], acc[cc]);
         }
     }
+    if (NWV > 1) {                                           // wave 1 hands its partial sums over through the (now free) tap buffer
+        __syncthreads();
+        if (wave != 0) {
+#pragma unroll
+            for (int cc = 0; cc < MC; ++cc) wl[((wave - 1) * MC + cc) * 64 + lane] = acc[cc];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 1; w < NWV; ++w)
+#pragma unroll
+            for (int cc = 0; cc < MC; ++cc) acc[cc] += wl[((w - 1) * MC + cc) * 64 + lane];
+    }
+    if (lane >= npx) return;
 #pragma unroll
     for (int cc = 0; cc < MC; ++cc)
         if (CN > 0 || cc < C) out[((size_t)(b * C + cc) * H + y) * W + x0 + lane] = acc[cc];
@@ -1188,7 +1212,10 @@ int aadff_local_psf_render(const float* img, const float* psf, float* out, int B
         static const bool force_direct = [] { const char* e = std::getenv("AADFF_LOCAL_PSF"); return e && e[0] == 'd'; }();
         const bool dma = !force_direct && W % 4 == 0 && (reinterpret_cast<uintptr_t>(psf) & 15) == 0;
         const size_t dlds = (size_t)(64 * ks * ks + C * ks * (64 + ks - 1)) * sizeof(float);
-#define AADFF_LPC(K, CN) do { if (dma) hipLaunchKernelGGL((local_psf_dma_kernel<K, CN>), g, dim3(64), dlds, st, img, psf, out, C, H, W); \
+        // waves per workgroup (they split the run's DMA pieces, window rows and tap rows; ks 11 at 1024^2: 1 -> 145 us,
+        // 2 -> 122, 4 -> 101, 8 -> 111; ks 5: 2 -> 25, 4 -> 27): 4 for ks >= 9, 2 below
+#define AADFF_LPC(K, CN) do { constexpr int NWV_ = K >= 9 ? 4 : 2; \
+                              if (dma) hipLaunchKernelGGL((local_psf_dma_kernel<K, CN, NWV_>), g, dim3(64 * NWV_), dlds, st, img, psf, out, C, H, W); \
                               else hipLaunchKernelGGL((local_psf_kernel<K, CN>), g, dim3(64), 0, st, img, psf, out, C, H, W); } while (0)
 #define AADFF_LP(K) case K: if (C == 3) AADFF_LPC(K, 3); else if (C == 1) AADFF_LPC(K, 1); else AADFF_LPC(K, 0); break;
         switch (ks) {
