@@ -64,8 +64,8 @@ PROTOTYPES = {
     "aadff_psf_points": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _L, _L, _P, _I, _L, _L, _I, _I, _I, _P, _P, _P, _P],
     "aadff_psf_points_staged": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _L, _L, _P, _I, _L, _L, _I, _I, _I, _P, _P, _P,
                                 C.POINTER(Stage), _P],
-    "aadff_psfnet_forward": [_P, _L, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
-    "aadff_psfnet_render_rgbd": [_P, _P, _P, _P, _F, _F, _L, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "aadff_psfnet_forward": [_P, _L, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "aadff_psfnet_render_rgbd": [_P, _P, _P, _P, _F, _F, _L, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "aadff_refocus": [_P, _I, _P, _I, _L, _P, LensConst, _P, _P],
     "aadff_refocus_staged": [_P, _I, _P, _P, _L, _I, _L, _P, LensConst, _P, _P, _P],
     "aadff_post_computation": [_I, _P, LensConst, _P, _P],

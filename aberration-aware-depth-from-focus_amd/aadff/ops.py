@@ -111,24 +111,24 @@ def _ints(v):
 
 @custom_op("aadff::psfnet_forward", mutates_args=("flags",), device_types="cuda")
 def psfnet_forward(inp: torch.Tensor, wpack: torch.Tensor, bias: torch.Tensor, in_features: List[int], out_features: List[int],
-                   flags: torch.Tensor) -> torch.Tensor:
+                   flags: torch.Tensor, precision: int = 0) -> torch.Tensor:
     x = inp.contiguous().float().reshape(-1, 4)
     out = torch.empty((x.shape[0], out_features[-1]), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _abi.call("aadff_psfnet_forward", _abi.ptr(x), x.shape[0], _abi.ptr(wpack), _abi.ptr(bias), len(in_features), _ints(in_features),
-                  _ints(out_features), 0, _abi.ptr(out), None, None, 0, 0, 0, 0, 0, _abi.ptr(flags), _st(x))
+                  _ints(out_features), 0, _abi.ptr(out), None, None, 0, 0, 0, 0, 0, int(precision), _abi.ptr(flags), _st(x))
     return out
 
 
 @psfnet_forward.register_fake
-def _(inp, wpack, bias, in_features, out_features, flags):
+def _(inp, wpack, bias, in_features, out_features, flags, precision=0):
     return inp.new_empty((inp.numel() // 4, out_features[-1]), dtype=torch.float32)
 
 
 @custom_op("aadff::psfnet_render_rgbd", mutates_args=("flags",), device_types="cuda")
 def psfnet_render_rgbd(img: torch.Tensor, depth: torch.Tensor, xs: torch.Tensor, ys: torch.Tensor, foc_z: torch.Tensor, d_min: float,
                        inv_range: float, wpack: torch.Tensor, bias: torch.Tensor, in_features: List[int], out_features: List[int],
-                       ks: int, flags: torch.Tensor) -> torch.Tensor:
+                       ks: int, flags: torch.Tensor, precision: int = 0) -> torch.Tensor:
     N, Cn, H, W = img.shape
     S = foc_z.numel() // N
     x, d, fz = img.contiguous().float(), depth.contiguous().float(), foc_z.contiguous().float()
@@ -136,12 +136,12 @@ def psfnet_render_rgbd(img: torch.Tensor, depth: torch.Tensor, xs: torch.Tensor,
     with torch.cuda.device(x.device):
         _abi.call("aadff_psfnet_render_rgbd", _abi.ptr(d), _abi.ptr(xs.contiguous().float()), _abi.ptr(ys.contiguous().float()), _abi.ptr(fz),
                   C.c_float(d_min), C.c_float(inv_range), N, S, _abi.ptr(wpack), _abi.ptr(bias), len(in_features), _ints(in_features),
-                  _ints(out_features), _abi.ptr(x), _abi.ptr(out), Cn, H, W, ks, _abi.ptr(flags), _st(x))
+                  _ints(out_features), _abi.ptr(x), _abi.ptr(out), Cn, H, W, ks, int(precision), _abi.ptr(flags), _st(x))
     return out
 
 
 @psfnet_render_rgbd.register_fake
-def _(img, depth, xs, ys, foc_z, d_min, inv_range, wpack, bias, in_features, out_features, ks, flags):
+def _(img, depth, xs, ys, foc_z, d_min, inv_range, wpack, bias, in_features, out_features, ks, flags, precision=0):
     N, Cn, H, W = img.shape
     return img.new_empty((N, Cn, foc_z.numel() // N, H, W), dtype=torch.float32)
 

@@ -82,7 +82,7 @@ def _check(packed, check):
                                  "operand split of the fused kernel; use mlp_precision='torch' for this network")
 
 
-def forward(packed, inp, mode, img=None, ks=0, slices=0, check=True):
+def forward(packed, inp, mode, img=None, ks=0, slices=0, check=True, precision=0):
     """mode 0: [P,4] -> [P,n_out] normalised PSFs; mode 1: img [N,C,H,W] + inp [N*H*W,4] -> [N,C,H,W], or with
     slices = S: inp [N*S*H*W,4] (rows ordered [n][slice][y][x]) -> [N,C,S,H,W] in one launch.
     check: read back the saturation flag after the launch (a hidden activation above 65504 raises ActivationOverflow)."""
@@ -92,7 +92,7 @@ def forward(packed, inp, mode, img=None, ks=0, slices=0, check=True):
     st = _abi.stream_ptr(dev)
     with torch.cuda.device(dev):
         if mode == 0:
-            out = torch.ops.aadff.psfnet_forward(inp, packed.wpack, packed.bias, list(packed.ins), list(packed.outs), packed.flags)
+            out = torch.ops.aadff.psfnet_forward(inp, packed.wpack, packed.bias, list(packed.ins), list(packed.outs), packed.flags, int(precision))
             _check(packed, check)
             return out
         x = _abi.f32c(img, dev)
@@ -101,14 +101,14 @@ def forward(packed, inp, mode, img=None, ks=0, slices=0, check=True):
         if EVENT_HOOK is not None:
             EVENT_HOOK(True)
         _abi.call("aadff_psfnet_forward", _abi.ptr(inp), P, _abi.ptr(packed.wpack), _abi.ptr(packed.bias), packed.n,
-                  packed.ins, packed.outs, 1, None, _abi.ptr(x), _abi.ptr(out), Cc, H, W, ks, int(slices), _abi.ptr(packed.flags), st)
+                  packed.ins, packed.outs, 1, None, _abi.ptr(x), _abi.ptr(out), Cc, H, W, ks, int(slices), int(precision), _abi.ptr(packed.flags), st)
         if EVENT_HOOK is not None:
             EVENT_HOOK(False)
         _check(packed, check)
         return out
 
 
-def render_rgbd(packed, img, depth, xs, ys, foc_z, d_min, d_range, ks, check=True):
+def render_rgbd(packed, img, depth, xs, ys, foc_z, d_min, d_range, ks, check=True, precision=0):
     """PSFNet.render / render_stack with the network input generated in the kernel (aadff_psfnet_render_rgbd):
     img [N,C,H,W], depth [N,H,W] mm, xs [W], ys [H], foc_z [N,S] -> [N,C,S,H,W]."""
     dev = img.device
@@ -122,7 +122,7 @@ def render_rgbd(packed, img, depth, xs, ys, foc_z, d_min, d_range, ks, check=Tru
     if EVENT_HOOK is not None:
         EVENT_HOOK(True)
     out = torch.ops.aadff.psfnet_render_rgbd(x, d, xs, ys, fz, float(d_min), inv_range, packed.wpack, packed.bias, list(packed.ins),
-                                             list(packed.outs), ks, packed.flags)
+                                             list(packed.outs), ks, packed.flags, int(precision))
     if EVENT_HOOK is not None:
         EVENT_HOOK(False)
     _check(packed, check)

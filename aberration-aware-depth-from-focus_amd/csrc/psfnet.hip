@@ -74,13 +74,19 @@ __device__ __forceinline__ void split4(float4v v, half4v& h, half4v& l) {
 // mode 0: psf_out[P][nout] (normalised PSFs); mode 1: out[N][C][H][W] = per-pixel PSF gather over img
 // TP = pixels per workgroup (128: one workgroup per CU; 64: two, which overlap each other's write-back phases at
 // twice the weight traffic from L2)
-template <int TP>
+// SINGLE: fp16 single-pass mode (opt-in, `mlp_precision="fp16"`): operands are the fp16 roundings themselves, one MFMA per
+// product instead of three, one activation plane (34 KB of LDS instead of 64 KB).  PSFs then carry ~5e-4 relative error —
+// the level of torch's bf16 autocast and far below the surrogate's own fit error — at about a third of the matrix work.
+template <int TP, bool SINGLE>
 __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(const float* __restrict__ inp, long P, const uint4v* __restrict__ wpack,
                                                            const float* __restrict__ bias, Layers L, int nout, int mode,
                                                            float* __restrict__ psf_out, const float* __restrict__ img,
                                                            float* __restrict__ out, int C, int H, int W, int ks, int out_slices,
                                                            Coord coord, int* __restrict__ flags) {
-    __shared__ __attribute__((aligned(16))) _Float16 act[2][TP * AP];          // 135 168 B; reused for the fp32 PSFs at the end
+    constexpr int PLANE = TP * AP;                                              // halves per activation plane
+    constexpr int ACT_HALVES = (SINGLE ? 1 : 2) * PLANE > TP * 132 * 2 ? (SINGLE ? 1 : 2) * PLANE : TP * 132 * 2;
+    __shared__ __attribute__((aligned(16))) _Float16 act_raw[ACT_HALVES];      // [hi | lo] planes; reused for the fp32 PSFs [TP][132] at the end
+    _Float16* const act[2] = {act_raw, act_raw + (SINGLE ? 0 : PLANE)};
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = lane >> 4, lo4 = lane & 15;
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
         half4v h, l;
         split4(v, h, l);
         *reinterpret_cast<half4v*>(&act[0][swz(px, 4 * g4)]) = h;
-        *reinterpret_cast<half4v*>(&act[1][swz(px, 4 * g4)]) = l;
+        if (!SINGLE) *reinterpret_cast<half4v*>(&act[1][swz(px, 4 * g4)]) = l;
     }
     __syncthreads();
 
@@ -133,33 +139,44 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
 #pragma unroll
             for (int j = 0; j < NTL; ++j) {
                 wq[j] = wpack + L.woff[l] + ((size_t)(wave + NWV * j) * nks * 2) * 64 + lane;
-                ah[j] = wq[j][0]; al[j] = wq[j][64];
+                ah[j] = wq[j][0];
+                if (!SINGLE) al[j] = wq[j][64];
                 const int s1 = nks > 1 ? 1 : 0;
-                nh[j] = wq[j][s1 * 128]; nl[j] = wq[j][s1 * 128 + 64];
+                nh[j] = wq[j][s1 * 128];
+                if (!SINGLE) nl[j] = wq[j][s1 * 128 + 64];
             }
 #pragma unroll 1
             for (int s = 0; s < nks; ++s) {
                 half8v th[2], tl[2];
 #pragma unroll
                 for (int j = 0; j < NTL; ++j) {
-                    th[j] = __builtin_bit_cast(half8v, ah[j]); tl[j] = __builtin_bit_cast(half8v, al[j]);
-                    ah[j] = nh[j]; al[j] = nl[j];
+                    th[j] = __builtin_bit_cast(half8v, ah[j]);
+                    ah[j] = nh[j];
+                    if (!SINGLE) { tl[j] = __builtin_bit_cast(half8v, al[j]); al[j] = nl[j]; }
                 }
                 {
                     const int s2 = s + 2 < nks ? s + 2 : nks - 1;              // clamped: the tail re-reads the last step
 #pragma unroll
-                    for (int j = 0; j < NTL; ++j) { nh[j] = wq[j][s2 * 128]; nl[j] = wq[j][s2 * 128 + 64]; }
+                    for (int j = 0; j < NTL; ++j) {
+                        nh[j] = wq[j][s2 * 128];
+                        if (!SINGLE) nl[j] = wq[j][s2 * 128 + 64];
+                    }
                 }
                 const int boffs = swz(lo4, 32 * s + 8 * kg);                    // (16 p + lo4) & 15 == lo4
 #pragma unroll
                 for (int p = 0; p < NPT; ++p) {
                     const half8v bh = *reinterpret_cast<const half8v*>(&act[0][16 * p * AP + boffs]);
-                    const half8v bl = *reinterpret_cast<const half8v*>(&act[1][16 * p * AP + boffs]);
+                    if constexpr (SINGLE) {
 #pragma unroll
-                    for (int j = 0; j < NTL; ++j) {
-                        acc[j][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th[j], bh, acc[j][p], 0, 0, 0);
-                        acc[j][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th[j], bl, acc[j][p], 0, 0, 0);
-                        acc[j][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl[j], bh, acc[j][p], 0, 0, 0);
+                        for (int j = 0; j < NTL; ++j) acc[j][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th[j], bh, acc[j][p], 0, 0, 0);
+                    } else {
+                        const half8v bl = *reinterpret_cast<const half8v*>(&act[1][16 * p * AP + boffs]);
+#pragma unroll
+                        for (int j = 0; j < NTL; ++j) {
+                            acc[j][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th[j], bh, acc[j][p], 0, 0, 0);
+                            acc[j][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th[j], bl, acc[j][p], 0, 0, 0);
+                            acc[j][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl[j], bh, acc[j][p], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -180,11 +197,15 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
                         amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));      // two v_max3_f32
-                        half4v h, lo;
-                        split4(v, h, lo);
                         const int o = swz(16 * p + lo4, f0);
-                        *reinterpret_cast<half4v*>(&act[0][o]) = h;
-                        *reinterpret_cast<half4v*>(&act[1][o]) = lo;
+                        if constexpr (SINGLE) {
+                            *reinterpret_cast<half4v*>(&act[0][o]) = (half4v){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                        } else {
+                            half4v h, lo;
+                            split4(v, h, lo);
+                            *reinterpret_cast<half4v*>(&act[0][o]) = h;
+                            *reinterpret_cast<half4v*>(&act[1][o]) = lo;
+                        }
                     }
                 }
             }
@@ -195,7 +216,7 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
                 for (int e = tid; e < TP * gw; e += NTH) {
                     const int px = e / gw, g4 = e - px * gw;
                     *reinterpret_cast<half4v*>(&act[0][swz(px, nn + 4 * g4)]) = (half4v){0, 0, 0, 0};
-                    *reinterpret_cast<half4v*>(&act[1][swz(px, nn + 4 * g4)]) = (half4v){0, 0, 0, 0};
+                    if (!SINGLE) *reinterpret_cast<half4v*>(&act[1][swz(px, nn + 4 * g4)]) = (half4v){0, 0, 0, 0};
                 }
             }
         } else {
@@ -284,7 +305,8 @@ extern "C" {
 static int psfnet_launch(const float* inp, long P, const void* wpack, const float* bias, int n_layers,
                          const int* in_features, const int* out_features, int mode, float* psf_out,
                          const float* img, float* out, int C, int H, int W, int ks, int out_slices, pn::Coord coord,
-                         int* flags_or_null, aadff_stream_t stream) {
+                         int precision, int* flags_or_null, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(precision == 0 || precision == 1, "psfnet_forward: precision %d (0 = fp32-equivalent split, 1 = fp16 single pass)", precision);
     AADFF_CHECK_ARG((inp || coord.depth) && wpack && bias && in_features && out_features, "psfnet_forward: NULL pointer");
     AADFF_CHECK_ARG(n_layers >= 1 && n_layers <= AADFF_PSFNET_MAX_LAYERS, "psfnet_forward: %d layers outside [1,%d]", n_layers, AADFF_PSFNET_MAX_LAYERS);
     AADFF_CHECK_ARG(P >= 0 && P < (1L << 40), "psfnet_forward: bad P");
@@ -315,34 +337,33 @@ static int psfnet_launch(const float* inp, long P, const void* wpack, const floa
     if (const char* e = getenv("AADFF_PSFNET_TP")) tp = atoi(e) == 128 ? 128 : 64;
     const long nwg = (P + tp - 1) / tp;
     AADFF_CHECK_ARG(nwg < (1L << 31), "psfnet_forward: too many pixels");
-    if (tp == 128)
-        hipLaunchKernelGGL(pn::psfnet_fused_kernel<128>, dim3((unsigned)nwg), dim3(pn::NTH), 0, (hipStream_t)stream, inp, P,
-                           reinterpret_cast<const pn::uint4v*>(wpack), bias, L, nout, mode, psf_out, img, out, C, H, W, ks, out_slices, coord, flags_or_null);
-    else
-        hipLaunchKernelGGL(pn::psfnet_fused_kernel<64>, dim3((unsigned)nwg), dim3(pn::NTH), 0, (hipStream_t)stream, inp, P,
-                           reinterpret_cast<const pn::uint4v*>(wpack), bias, L, nout, mode, psf_out, img, out, C, H, W, ks, out_slices, coord, flags_or_null);
+#define AADFF_PN_LAUNCH(TPV, SV) hipLaunchKernelGGL((pn::psfnet_fused_kernel<TPV, SV>), dim3((unsigned)nwg), dim3(pn::NTH), 0, (hipStream_t)stream, inp, P, \
+        reinterpret_cast<const pn::uint4v*>(wpack), bias, L, nout, mode, psf_out, img, out, C, H, W, ks, out_slices, coord, flags_or_null)
+    if (tp == 128) { if (precision) AADFF_PN_LAUNCH(128, true); else AADFF_PN_LAUNCH(128, false); }
+    else { if (precision) AADFF_PN_LAUNCH(64, true); else AADFF_PN_LAUNCH(64, false); }
+#undef AADFF_PN_LAUNCH
     AADFF_CHECK_LAUNCH();
     return 0;
 }
 
 int aadff_psfnet_forward(const float* inp, long P, const void* wpack, const float* bias, int n_layers,
                          const int* in_features, const int* out_features, int mode, float* psf_out,
-                         const float* img, float* out, int C, int H, int W, int ks, int out_slices,
+                         const float* img, float* out, int C, int H, int W, int ks, int out_slices, int precision,
                          int* flags_or_null, aadff_stream_t stream) {
     AADFF_CHECK_ARG(inp, "psfnet_forward: NULL input rows");
     return psfnet_launch(inp, P, wpack, bias, n_layers, in_features, out_features, mode, psf_out, img, out, C, H, W, ks,
-                         out_slices, pn::Coord{}, flags_or_null, stream);
+                         out_slices, pn::Coord{}, precision, flags_or_null, stream);
 }
 
 int aadff_psfnet_render_rgbd(const float* depth, const float* xs, const float* ys, const float* foc_z, float d_min,
                              float inv_range, long N, int S, const void* wpack, const float* bias, int n_layers,
                              const int* in_features, const int* out_features, const float* img, float* out, int C, int H,
-                             int W, int ks, int* flags_or_null, aadff_stream_t stream) {
+                             int W, int ks, int precision, int* flags_or_null, aadff_stream_t stream) {
     AADFF_CHECK_ARG(depth && xs && ys && foc_z, "psfnet_render_rgbd: NULL pointer");
     AADFF_CHECK_ARG(N >= 0 && S >= 1 && H > 0 && W > 0, "psfnet_render_rgbd: bad sizes N=%ld S=%d", N, S);
     const pn::Coord c{depth, xs, ys, foc_z, d_min, inv_range};
     return psfnet_launch(nullptr, N * S * (long)H * W, wpack, bias, n_layers, in_features, out_features, 1, nullptr, img, out,
-                         C, H, W, ks, S, c, flags_or_null, stream);
+                         C, H, W, ks, S, c, precision, flags_or_null, stream);
 }
 
 }  // extern "C"

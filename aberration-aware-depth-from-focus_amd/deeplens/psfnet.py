@@ -236,6 +236,8 @@ class PSFNet(Lensgroup):
         #   L1-normalise + per-pixel gather in one launch, fp32 operands carried as exact fp16 hi/lo pairs on
         #   MFMA with fp32 accumulation); rendered image within 1e-4 rel-L2 of the reference.
         # "torch": the same in stock torch fp32 ops + the HIP gather (what training always uses).
+        # "fp16": the fused kernel in single-pass fp16 (one MFMA per product instead of three, half the LDS): PSFs within
+        #   ~5e-4 relative of fp32, ~2.5x faster - opt-in, for producing training stacks on the fly.
         # "bf16": MLP GEMMs on bf16 MFMA under autocast (sigmoid / L1-normalise / gather stay fp32); the
         #   surrogate PSFs then differ by ~1e-3, far below the MLP's own fit error - opt-in.
         self.mlp_precision = "fp32"
@@ -258,7 +260,7 @@ class PSFNet(Lensgroup):
     def _fused(self, dev):
         """PackedMLP for the fused kernel, or None when it does not apply (CPU, autograd, other modes/shapes)."""
         from aadff import psfnet_pack
-        if self.mlp_precision != "fp32" or torch.device(dev).type != "cuda" or not psfnet_pack.supported(self.psfnet):
+        if self.mlp_precision not in ("fp32", "fp16") or torch.device(dev).type != "cuda" or not psfnet_pack.supported(self.psfnet):
             return None
         if self._packed is None or self._packed.key != psfnet_pack.PackedMLP.key_of(self.psfnet) or self._packed.wpack.device != torch.device(dev):
             self._packed = psfnet_pack.PackedMLP(self.psfnet, torch.device(dev))
@@ -269,7 +271,7 @@ class PSFNet(Lensgroup):
             packed = self._fused(inp.device)
             if packed is not None:
                 from aadff import psfnet_pack
-                psf = psfnet_pack.forward(packed, inp.reshape(-1, inp.shape[-1]), 0)
+                psf = psfnet_pack.forward(packed, inp.reshape(-1, inp.shape[-1]), 0, precision=int(self.mlp_precision == "fp16"))
                 return psf.reshape(*inp.shape[:-1], self.kernel_size, self.kernel_size)
         psf = self.psfnet(inp)
         return psf.reshape(*psf.shape[:-1], self.kernel_size, self.kernel_size)
@@ -310,7 +312,7 @@ class PSFNet(Lensgroup):
         if packed is not None:
             from aadff import psfnet_pack
             x = img if len(img.shape) == 4 else img.unsqueeze(0)
-            out = psfnet_pack.forward(packed, o.reshape(-1, 4), 1, img=x.to(dev), ks=self.kernel_size)
+            out = psfnet_pack.forward(packed, o.reshape(-1, 4), 1, img=x.to(dev), ks=self.kernel_size, precision=int(self.mlp_precision == "fp16"))
             out = out if len(img.shape) == 4 else out.squeeze(0)
             return out.to(img.device)
         psf = self._pred_chunked(o)
@@ -332,7 +334,8 @@ class PSFNet(Lensgroup):
         from aadff import psfnet_pack
         xs, ys = self._field_axes(H, W, dev)
         out = psfnet_pack.render_rgbd(packed, img.to(dev), depth.to(dev).reshape(N, H, W), xs, ys, self.depth2z(foc_dists.float()),
-                                      float(self.d_min), float(self.d_max - self.d_min), self.kernel_size)
+                                      float(self.d_min), float(self.d_max - self.d_min), self.kernel_size,
+                                      precision=int(self.mlp_precision == "fp16"))
         return out.to(img.device)
 
     def _field_axes(self, H, W, dev):

@@ -226,9 +226,11 @@ int aadff_psf_points_staged(const float* points, int S, int N, int L,
 #define AADFF_PSFNET_MAX_LAYERS 16
 int aadff_psfnet_forward(const float* inp, long P, const void* wpack, const float* bias, int n_layers,
                          const int* in_features, const int* out_features, int mode, float* psf_out,
-                         const float* img, float* out, int C, int H, int W, int ks, int out_slices,
+                         const float* img, float* out, int C, int H, int W, int ks, int out_slices, int precision,
                          int* flags_or_null, aadff_stream_t stream);
-/* flags_or_null (both psfnet entries): bit 4 is ORed in when a hidden activation exceeded 65504, the largest value the
+/* precision (both psfnet entries): 0 = fp32-equivalent (fp16 hi/lo operand split, three MFMAs per product: <= 2e-7 from
+ * torch fp32); 1 = fp16 single pass (opt-in: operands rounded to fp16, one MFMA per product, PSFs ~5e-4 relative).
+ * flags_or_null (both psfnet entries): bit 4 is ORed in when a hidden activation exceeded 65504, the largest value the
  * fp16 hi half of the split operand can carry — the affected outputs are then inf/NaN garbage and the caller must not
  * use them (the shipped rf50mm checkpoint peaks at 41, tests/golden/g11_ckpt_activation_range.json). */
 
@@ -240,7 +242,7 @@ int aadff_psfnet_forward(const float* inp, long P, const void* wpack, const floa
 int aadff_psfnet_render_rgbd(const float* depth, const float* xs, const float* ys, const float* foc_z, float d_min,
                              float inv_range, long N, int S, const void* wpack, const float* bias, int n_layers,
                              const int* in_features, const int* out_features, const float* img, float* out, int C, int H,
-                             int W, int ks, int* flags_or_null, aadff_stream_t stream);
+                             int W, int ks, int precision, int* flags_or_null, aadff_stream_t stream);
 
 /* Refocus S lens states in one launch: trace spp rays from (0,0,depth[s]) (green table),
  * least-squares axis crossing -> d_sensor, then hfov/foclen/fnum.  Replaces

@@ -612,6 +612,32 @@ def test_fused_mlp_pred_golden_and_vs_torch(g67, psfnet64):
         assert psfnet64.pred(x).requires_grad
 
 
+def test_fused_mlp_fp16_single_pass_mode(g67, psfnet64):
+    """mlp_precision="fp16" (opt-in): the fused kernel with one fp16 MFMA per product.  PSFs within 2e-3 rel-L2 of torch
+    fp32 (measured ~3e-4), rendered images within 5e-4; the default mode is untouched."""
+    rng = np.random.Generator(np.random.PCG64(31))
+    x = tt(rng.random((1000, 4), dtype=np.float32)).to(DEV)
+    x[:, :2] = x[:, :2] * 2 - 1
+    img = tt(synth_rgb(64, 64, seed=11))[None].to(DEV)
+    depth = -tt(synth_depth_mm(64, 64, seed=12))[None, None].to(DEV)
+    fds = torch.tensor([[-500.0, -1500.0, -5000.0]], device=DEV)
+    net = PSFNet.__new__(PSFNet)
+    net.__dict__.update(psfnet64.__dict__)
+    net._packed = None
+    with torch.no_grad():
+        ref_psf = net.psfnet(x)
+        ref_stack = net.render_stack(img, depth, fds)
+        net.mlp_precision = "fp16"
+        got_psf = net.pred(x).reshape(1000, -1)
+        got_stack = net.render_stack(img, depth, fds)
+        got_one = net.render(img, depth, fds[:, 1])
+    e_psf, e_img = rel_l2(got_psf.cpu().numpy(), ref_psf.cpu().numpy()), rel_l2(got_stack.cpu().numpy(), ref_stack.cpu().numpy())
+    assert 1e-6 < e_psf <= 2e-3 and e_img <= 5e-4, (e_psf, e_img)            # really the reduced-precision path, and close
+    assert (got_one - got_stack[:, :, 1]).abs().max().item() <= 1e-6
+    assert got_psf.sum(-1).cpu().numpy() == pytest.approx(1.0, abs=1e-5)
+    assert psfnet64.mlp_precision == "fp32"
+
+
 def test_fused_mlp_small_weights(repo_root):
     """Weights of magnitude ~1e-3 (and down to 1e-7): the lo halves of the fp16 split are all subnormal there (spacing 6e-8
     absolute, see aadff/psfnet_pack.py).  The fused kernel must still match torch fp32 to 2e-7: in particular the MFMA f16

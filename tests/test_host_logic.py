@@ -205,6 +205,7 @@ def test_custom_ops_are_registered_with_shape_functions():
     assert torch.ops.aadff.thinlens_render(m(2, 3, 8, 8), m(2, 1, 8, 8), m(2), 11, 50.0, 1.8, 0.02, 200.0, 20000.0).shape == (2, 3, 8, 8)
     fl = torch.empty(1, dtype=torch.int32, device="meta")
     assert torch.ops.aadff.psfnet_forward(m(10, 4), m(4), m(4), [4, 64], [64, 121], fl).shape == (10, 121)
+    assert torch.ops.aadff.psfnet_forward(m(10, 4), m(4), m(4), [4, 64], [64, 121], fl, 1).shape == (10, 121)
     assert torch.ops.aadff.psfnet_render_rgbd(m(2, 3, 8, 9), m(2, 8, 9), m(9), m(8), m(2, 5), -200.0, -1e-4, m(4), m(4), [4, 64], [64, 121],
                                               11, fl).shape == (2, 3, 5, 8, 9)
     lc = [12.0] + [1.0] * 12
