@@ -72,6 +72,11 @@ PROTOTYPES = {
     "aadff_publish_flags": [_P, _P, _P],
     "aadff_relu_bwd_bias": [_P, _P, _P, _P, _I, _I, _I, _P],
     "aadff_psfnet_head_loss_grad": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "aadff_fit_gemm_nt": [_P, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P],
+    "aadff_fit_layer_bwd": [_P, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P],
+    "aadff_fit_input": [_P, _P, _I, _P, _I, _I, _I, _P],
+    "aadff_fit_head": [_P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _F, _I, _F, _F, _F, _P],
+    "aadff_fit_adamw": [_P, _P, _P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _P],
     "aadff_adamw_step": [_P, _P, _I, _P, _P, _P, _L, _P, _P, _F, _I, _F, _F, _F, _F, _P],
     "aadff_host_mt19937_uniform_f32": [_P, _L, _L, _P],
 }

@@ -1,0 +1,161 @@
+"""The PSF-network fit step (deeplens/psfnet.py:85-108: MSE(MLP(inp), psf) -> backward -> AdamW + cosine schedule) as a
+chain of hand-written bf16 MFMA kernels (csrc/mlp_train.hip) instead of torch autograd over hipBLASLt.
+
+For a batch of 128 rows every GEMM of the step is at most 256 x 256 x 256: launch latency, not arithmetic, sets the time
+(33 hipBLASLt launches of 8-10 us each).  One NT GEMM kernel form covers forward, dX and dW once every activation,
+gradient and weight also exists transposed; its epilogues absorb bias + ReLU, the ReLU mask of the backward pass and the
+bias gradient.  25 launches per step (input cast, 11 forward, head + optimiser scalars, 11 layer backwards [dW and dX together],
+optimiser),
+captured in one HIP graph.  Master parameters, Adam moments and gradients stay fp32; the GEMM operands are bf16 (what
+autocast computes in), refreshed by the optimiser kernel through per-element destination maps.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _abi
+
+EPI_FWD, EPI_FWD_RELU, EPI_DX, EPI_DW = 0, 1, 2, 3
+
+
+def _up(x, m):
+    return (x + m - 1) // m * m
+
+
+def supported(mlp, bs):
+    """Linear + ReLU chain ending in Linear + Sigmoid, widths <= 256 and multiples of 4 (except the last), batch <= 256."""
+    mods = list(mlp.net)
+    lin = [m for m in mods if isinstance(m, nn.Linear)]
+    ok = len(mods) == 2 * len(lin) and all(isinstance(mods[2 * i + 1], nn.ReLU) for i in range(len(lin) - 1)) and isinstance(mods[-1], nn.Sigmoid)
+    ok = ok and all(l.bias is not None and l.in_features <= 256 and l.out_features <= 256 for l in lin)
+    ok = ok and all(l.in_features % 4 == 0 for l in lin) and all(l.out_features % 4 == 0 for l in lin[:-1]) and lin[-1].out_features <= 128
+    return ok and 1 <= bs <= 256
+
+
+class FusedFit:
+    BETAS, EPS, WD = (0.9, 0.999), 1e-8, 0.01              # torch.optim.AdamW defaults (the reference passes only lr)
+
+    def __init__(self, mlp, lr, iters, bs, dev):
+        self.dev, self.bs, self.lr0, self.T = dev, int(bs), float(lr), max(1, int(iters))
+        lin = [m for m in mlp.net if isinstance(m, nn.Linear)]
+        self.L = len(lin)
+        self.K = [l.in_features for l in lin]
+        self.N = [l.out_features for l in lin]
+        self.N4 = [_up(n, 4) for n in self.N]
+        self.ldk = [_up(k, 8) for k in self.K]              # leading dimension of W [N][K]
+        self.ldn = [_up(n, 8) for n in self.N]              # leading dimension of W^T [K][N] and of activations [B][N]
+        self.ldb = _up(self.bs, 8)                          # leading dimension of everything transposed [..][B]
+        params = [p for l in lin for p in (l.weight, l.bias)]
+        n = sum(p.numel() for p in params)
+        self.n = n
+        # ---- flat fp32 master parameters (the module's tensors become views), gradients, moments
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.scal = torch.zeros(4, dtype=torch.float32, device=dev)
+        off, self.w_off, self.b_off = 0, [], []
+        with torch.no_grad():
+            for l in lin:
+                for p, lst in ((l.weight, self.w_off), (l.bias, self.b_off)):
+                    k = p.numel()
+                    self.flat[off:off + k].copy_(p.detach().reshape(-1).float())
+                    p.data = self.flat[off:off + k].view_as(p)
+                    lst.append(off)
+                    off += k
+        # ---- bf16 operand copies [W | W^T | bias] per layer with padded leading dimensions, and the maps flat index -> slot
+        size16, self.o_w, self.o_wt, self.o_b = 0, [], [], []
+        for l in range(self.L):
+            self.o_w.append(size16); size16 += self.N4[l] * self.ldk[l]
+            self.o_wt.append(size16); size16 += self.K[l] * self.ldn[l]
+            self.o_b.append(size16); size16 += _up(self.N4[l], 8)
+        dst, dst_t = np.empty(n, dtype=np.int32), np.full(n, -1, dtype=np.int32)
+        for l in range(self.L):
+            nn_, kk = self.N[l], self.K[l]
+            r, c = np.divmod(np.arange(nn_ * kk), kk)
+            dst[self.w_off[l]:self.w_off[l] + nn_ * kk] = self.o_w[l] + r * self.ldk[l] + c
+            dst_t[self.w_off[l]:self.w_off[l] + nn_ * kk] = self.o_wt[l] + c * self.ldn[l] + r
+            dst[self.b_off[l]:self.b_off[l] + nn_] = self.o_b[l] + np.arange(nn_)
+        self.p16 = torch.zeros(size16, dtype=torch.bfloat16, device=dev)
+        self.dst, self.dst_t = torch.from_numpy(dst).to(dev), torch.from_numpy(dst_t).to(dev)
+        self.refresh_operands()
+        # ---- activations X_l [B][ld], X_l^T [n][ldb]; gradients dZ_l, dZ_l^T (l = 0 is the network input)
+        z16 = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=dev)
+        widths = [self.K[0]] + self.N
+        self.X = [z16(self.bs, _up(w, 8)) for w in widths]
+        self.XT = [z16(_up(w, 4), self.ldb) for w in widths]
+        self.dZ = [None] + [z16(self.bs, self.ldn[l]) for l in range(self.L)]
+        self.dZT = [None] + [z16(self.N4[l], self.ldb) for l in range(self.L)]
+        self.inp = torch.zeros(self.bs, self.K[0], dtype=torch.float32, device=dev)
+        self.psf = torch.zeros(self.bs, self.N[-1], dtype=torch.float32, device=dev)
+        self.pred = torch.zeros(self.bs, self.N[-1], dtype=torch.float32, device=dev)
+        self.graph, self.side, self.t = None, torch.cuda.Stream(dev), 0
+
+    def refresh_operands(self):
+        """bf16 operand copies from the fp32 master parameters (after construction or an external load_state_dict)."""
+        h = self.flat.to(torch.bfloat16)
+        self.p16[self.dst.long()] = h
+        keep = self.dst_t >= 0
+        self.p16[self.dst_t[keep].long()] = h[keep]
+
+    def _p16(self, off):
+        return C.c_void_p(self.p16.data_ptr() + 2 * off)
+
+    def _g(self, off):
+        return C.c_void_p(self.grad.data_ptr() + 4 * off)
+
+    def _body(self, optimise=True):
+        B, st, L = self.bs, _abi.stream_ptr(self.dev), self.L
+        _abi.call("aadff_fit_input", _abi.ptr(self.inp), _abi.ptr(self.X[0]), self.X[0].shape[1], _abi.ptr(self.XT[0]), self.ldb, B, self.K[0], st)
+        for l in range(L):                                                         # ---- forward: X_{l+1} = relu(X_l W_l^T + b_l)
+            last = l == L - 1
+            _abi.call("aadff_fit_gemm_nt", self._p16(self.o_w[l]), self.ldk[l], self.N4[l], _abi.ptr(self.X[l]), self.X[l].shape[1], B, self.K[l],
+                      EPI_FWD if last else EPI_FWD_RELU, _abi.ptr(self.X[l + 1]), self.X[l + 1].shape[1],
+                      None if last else _abi.ptr(self.XT[l + 1]), self.ldb, self._p16(self.o_b[l]), None, 0, None, st)
+        _abi.call("aadff_fit_head", _abi.ptr(self.X[L]), self.X[L].shape[1], _abi.ptr(self.psf), _abi.ptr(self.pred), _abi.ptr(self.dZ[L]),
+                  self.ldn[L - 1], _abi.ptr(self.dZT[L]), self.ldb, self._g(self.b_off[L - 1]), B, self.N[-1],
+                  _abi.ptr(self.step_dev) if optimise else None, _abi.ptr(self.scal), C.c_float(self.lr0), self.T, C.c_float(self.BETAS[0]),
+                  C.c_float(self.BETAS[1]), C.c_float(self.WD), st)
+        for l in range(L, 0, -1):                                                  # ---- backward of layer i = l - 1: dW_i, then dZ_{i}
+            i = l - 1
+            dx = i > 0
+            _abi.call("aadff_fit_layer_bwd", _abi.ptr(self.XT[i]), self.ldb, self.K[i], _abi.ptr(self.dZT[l]), self.ldb, self.N[i], B,
+                      self._g(self.w_off[i]), self._p16(self.o_wt[i]) if dx else None, self.ldn[i], _abi.ptr(self.dZ[l]), self.ldn[i],
+                      _abi.ptr(self.X[i]) if dx else None, self.X[i].shape[1], _abi.ptr(self.dZ[i]) if dx else None, self.ldn[i - 1] if dx else 0,
+                      _abi.ptr(self.dZT[i]) if dx else None, self.ldb, self._g(self.b_off[i - 1]) if dx else None, st)
+        if optimise:
+            _abi.call("aadff_fit_adamw", _abi.ptr(self.flat), _abi.ptr(self.grad), _abi.ptr(self.m), _abi.ptr(self.v), _abi.ptr(self.p16),
+                      _abi.ptr(self.dst), _abi.ptr(self.dst_t), self.n, _abi.ptr(self.scal), C.c_float(self.BETAS[0]), C.c_float(self.BETAS[1]),
+                      C.c_float(self.EPS), st)
+
+    def gradients(self, inp, psf):
+        """Forward + backward WITHOUT the optimiser: the flat fp32 gradient (a copy; the buffer is cleared) and the prediction.  For tests."""
+        self.inp.copy_(inp)
+        self.psf.copy_(psf)
+        self.grad.zero_()
+        self._body(optimise=False)
+        g = self.grad.clone()
+        self.grad.zero_()
+        return g, self.pred.clone()
+
+    def __call__(self, inp, psf):
+        """One optimisation step on (inp [B,4], psf [B,ks*ks]); returns the network's prediction for the batch."""
+        self.inp.copy_(inp)
+        self.psf.copy_(psf)
+        with torch.cuda.device(self.dev):
+            if self.t < 2:                                    # two plain runs, then capture (torch's capture recipe)
+                self.side.wait_stream(torch.cuda.current_stream(self.dev))
+                with torch.cuda.stream(self.side):
+                    self._body()
+                torch.cuda.current_stream(self.dev).wait_stream(self.side)
+            else:
+                if self.graph is None:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.side):
+                        self._body()
+                    self.graph = g
+                self.graph.replay()
+        self.t += 1
+        return self.pred

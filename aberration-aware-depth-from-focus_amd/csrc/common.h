@@ -36,4 +36,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// AdamW step scalars under the cosine schedule (torch.optim.AdamW + CosineAnnealingLR(T_max, eta_min 0) of
+// deeplens/psfnet.py:85-90), computed ONCE per step by one thread (float64 pow / cos), then the step counter advances:
+// scal = {lr / bias_correction1, sqrt(bias_correction2), 1 - lr * weight_decay, lr}.
+struct AdamwSchedule { int* step; float* scal; float lr0; int T; float b1, b2, wd; };
+
+__device__ inline void adamw_prepare(const AdamwSchedule& s) {
+    const int t = *s.step;
+    const double frac = (double)(t < s.T ? t : s.T) / (double)s.T;
+    const float lr = (float)(0.5 * (double)s.lr0 * (1.0 + cos(3.14159265358979323846 * frac)));
+    const double s1 = (double)(t + 1);
+    const float bc1 = (float)(1.0 - pow((double)s.b1, s1));
+    s.scal[0] = lr / bc1;
+    s.scal[1] = (float)sqrt(1.0 - pow((double)s.b2, s1));
+    s.scal[2] = 1.f - lr * s.wd;
+    s.scal[3] = lr;
+    *s.step = t + 1;
+}
+
 }  // namespace aadff

@@ -24,19 +24,8 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {        // round to ne
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-// One thread: the scalars of step t = *step (float64 pow / cos once instead of once per thread), then t += 1.
-__global__ void adamw_prep_kernel(int* step, float* scal, float lr0, int T, float b1, float b2, float wd) {
-    if (threadIdx.x != 0) return;
-    const int t = *step;
-    const double frac = (double)(t < T ? t : T) / (double)T;
-    const float lr = (float)(0.5 * (double)lr0 * (1.0 + cos(M_PI * frac)));
-    const double s1 = (double)(t + 1);
-    const float bc1 = (float)(1.0 - pow((double)b1, s1));
-    scal[0] = lr / bc1;                                           // step_size
-    scal[1] = (float)sqrt(1.0 - pow((double)b2, s1));             // sqrt(bias_correction2)
-    scal[2] = 1.f - lr * wd;                                      // decoupled weight decay factor
-    scal[3] = lr;
-    *step = t + 1;
+__global__ void adamw_prep_kernel(AdamwSchedule s) {
+    if (threadIdx.x == 0) adamw_prepare(s);
 }
 
 template <bool GRAD_BF16>
@@ -142,7 +131,7 @@ extern "C" int aadff_adamw_step(float* param, const void* grad, int grad_is_bf16
                                 float beta2, float eps, float weight_decay, aadff_stream_t stream) {
     AADFF_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_dev && scratch4, "adamw_step: NULL pointer");
     AADFF_CHECK_ARG(n > 0 && t_max > 0, "adamw_step: bad sizes n=%ld T=%d", n, t_max);
-    hipLaunchKernelGGL(adamw_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, scratch4, lr0, t_max, beta1, beta2, weight_decay);
+    hipLaunchKernelGGL(adamw_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, AdamwSchedule{step_dev, scratch4, lr0, t_max, beta1, beta2, weight_decay});
     AADFF_CHECK_LAUNCH();
     const int blocks = (int)std::min<long>((n + 255) / 256, 4096);
     if (grad_is_bf16)

@@ -6,6 +6,7 @@ The per-pixel PSF application runs in csrc/conv.hip (local_psf_render); ray-trac
 training targets come from the fused PSF kernel of csrc/trace.hip.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -104,7 +105,10 @@ class _TrainStep:
     of the ~60 of torch's capturable AdamW); zero-grad, forward, backward and that launch are captured once in a HIP graph
     after three eager warm-up steps and replayed.  With bf16 the forward/backward run on a bf16 COPY of the parameters that
     the optimiser kernel refreshes (same arithmetic as autocast, which casts the weights to bf16 every step and the
-    gradients back, without its ~47 cast kernels per step); sigmoid output, L1 normalisation and the loss stay fp32."""
+    gradients back, without its ~47 cast kernels per step); sigmoid output, L1 normalisation and the loss stay fp32.
+    graph=True with bf16 on a Linear+ReLU chain of widths <= 256 (the reference's MLP): the whole step runs as the
+    hand-written MFMA kernels of aadff/mlp_fit.py (25 launches in one HIP graph, no torch autograd); set
+    AADFF_FIT_KERNELS=torch to keep the torch-GEMM path."""
 
     BETAS, EPS, WD = (0.9, 0.999), 1e-8, 0.01            # torch.optim.AdamW defaults (the reference passes only lr)
 
@@ -115,6 +119,13 @@ class _TrainStep:
         if not graph:
             self.optim = torch.optim.AdamW(psfnet.parameters(), lr)
             return
+        self.fused = None
+        if self.bf16 and os.environ.get("AADFF_FIT_KERNELS", "hip") != "torch":
+            from aadff import mlp_fit
+            if hasattr(psfnet, "net") and mlp_fit.supported(psfnet, bs) and len(list(psfnet.parameters())) == 2 * sum(
+                    isinstance(m, nn.Linear) for m in psfnet.net):
+                self.fused = mlp_fit.FusedFit(psfnet, lr, iters, bs, dev)
+                return
         self.inp = torch.zeros(bs, 4, device=dev)
         self.psf = torch.zeros(bs, nout, device=dev)
         params = list(psfnet.parameters())
@@ -192,6 +203,9 @@ class _TrainStep:
             for g in self.optim.param_groups:
                 g["lr"] = new_lr
             return pred
+        if self.fused is not None:
+            self.t += 1
+            return self.fused(inp, psf)
         self.inp.copy_(inp)
         self.psf.copy_(psf)
         if self.t < 3 or self.use_graph == "eager-static":    # eager warm-up on the capture stream (torch's capture recipe)

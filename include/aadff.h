@@ -300,6 +300,36 @@ int aadff_relu_bwd_bias(const void* dy, const void* y, void* dz, void* db, int M
 int aadff_psfnet_head_loss_grad(const void* z, const float* target, float* pred, void* dz, int B, int N, int is_bf16,
                                 aadff_stream_t stream);
 
+/* The fit step of the PSF network as hand-written bf16 MFMA kernels (csrc/mlp_train.hip; used by aadff/mlp_fit.py), i.e. the
+ * autograd graph of deeplens/psfnet.py:94-106 over deeplens/psfnet_arch.py:24-47 without torch autograd:
+ * aadff_fit_gemm_nt: out[b][a] = sum_c A[a][c] B[b][c] for bf16 A [na][lda], B [nb][ldb], contraction nc <= 256, with
+ *   epilogue 0 forward (+ bias[a], bf16 out [nb][ld_out] and optional transposed copy outT [na][ld_outT]),
+ *            1 forward + ReLU,
+ *            2 dX (multiply by mask[b][a] > 0 — the forward output —, bf16 out / outT, dbias[a] += column sums, fp32 atomics),
+ *            3 dW (fp32 out [nb][ld_out]);
+ *   leading dimensions multiples of 8 (operands) / 4 (outputs), padding zero, na a multiple of 4;
+ * aadff_fit_layer_bwd: the backward of one layer in ONE launch: dW [n][k] fp32 = dzT [n][:batch] . xT_prev [k][:batch], and,
+ *   when wT != NULL, the dX epilogue for the layer below: dz_prev [batch][k] = (dz [batch][:n] . wT [k][:n]) masked by
+ *   x_prev > 0, its transposed copy dzT_prev and dbias_prev[k] += column sums;
+ * aadff_fit_input: fp32 batch [B][K] -> bf16 x [B][ld_x] and xT [K][ld_xT];
+ * aadff_fit_head: sigmoid + L1 normalise + MSE gradient for logits z [B][ld_z] bf16 -> pred fp32 [B][N], dz / dzT bf16,
+ *   dbias += column sums; when step_dev != NULL it also prepares the optimiser step (scalars into scratch4 as in
+ *   aadff_adamw_step, step counter += 1) for the aadff_fit_adamw that follows in the same stream;
+ * aadff_fit_adamw: AdamW on flat fp32 parameters with fp32 gradients (zeroed after use), refreshing the bf16 operand
+ *   copies param_bf16[dst[i]] and, where dst_t[i] >= 0, param_bf16[dst_t[i]] (the transposed weights). */
+int aadff_fit_gemm_nt(const void* A, int lda, int na, const void* B, int ldb, int nb, int nc, int epilogue, void* out,
+                      int ld_out, void* outT, int ld_outT, const void* bias, const void* mask, int ld_mask, float* dbias,
+                      aadff_stream_t stream);
+int aadff_fit_layer_bwd(const void* xT_prev, int ld_xT, int k, const void* dzT, int ld_dzT, int n, int batch, float* dW,
+                        const void* wT, int ld_wT, const void* dz, int ld_dz, const void* x_prev, int ld_x, void* dz_prev,
+                        int ld_dzp, void* dzT_prev, int ld_dzTp, float* dbias_prev, aadff_stream_t stream);
+int aadff_fit_input(const float* inp, void* x, int ld_x, void* xT, int ld_xT, int B, int K, aadff_stream_t stream);
+int aadff_fit_head(const void* z, int ld_z, const float* target, float* pred, void* dz, int ld_dz, void* dzT, int ld_dzT,
+                   float* dbias, int B, int N, int* step_dev, float* scratch4, float lr0, int t_max, float beta1, float beta2,
+                   float weight_decay, aadff_stream_t stream);
+int aadff_fit_adamw(float* param, float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16, const int* dst,
+                    const int* dst_t, long n, const float* scal4, float beta1, float beta2, float eps, aadff_stream_t stream);
+
 /* ------------------------------------------------------------------ host helper */
 
 /* HOST routine (no GPU work): the next n float32 uniforms of torch's CPU generator, bit-identical

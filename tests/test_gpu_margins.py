@@ -167,7 +167,7 @@ def test_bf16_train_step_runs_and_tracks_fp32(repo_root, margin):
             pred = step(inp, psf)
             ls.append(float(((pred.detach().float() - psf) ** 2).mean()))
         torch.cuda.synchronize()
-        assert step.graph is not None or step.use_graph == "eager-static"
+        assert step.fused is not None or step.graph is not None or step.use_graph == "eager-static"
         assert np.isfinite(ls).all() and all(ls[9 + b] < ls[b] for b in range(3)), ls      # batch b: its 4th visit vs its 1st
         losses[bf16] = np.array(ls)
     margin("bf16 train step: |loss_bf16/loss_fp32 - 1| after 12 steps", abs(losses[True][-1] / losses[False][-1] - 1), 0.05)

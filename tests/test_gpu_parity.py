@@ -927,6 +927,94 @@ def test_graph_captured_training_step_matches_eager(repo_root):
         assert rel_l2(nets[1][k], nets[2][k]) <= 1e-4 or np.abs(nets[1][k] - nets[2][k]).max() <= 1e-6, k
 
 
+@pytest.mark.parametrize("bs,ks,hidden,layers", [(128, 11, 256, 8), (50, 9, 128, 3), (256, 7, 64, 1), (8, 11, 256, 2)])
+def test_fit_kernels_gradients_match_torch(bs, ks, hidden, layers):
+    """The hand-written fit step (csrc/mlp_train.hip via aadff/mlp_fit.py): prediction and every dW / db of one
+    forward + backward against torch autograd on the same network (deeplens/psfnet.py:94-106).  bf16 operands: tolerance
+    1e-2 against torch's bf16 autocast, 2e-2 against fp32 autograd.  Ragged batches / widths exercise the zero padding."""
+    import copy
+    from aadff.mlp_fit import FusedFit, supported
+    from deeplens.psfnet_arch import MLP
+    torch.manual_seed(bs + ks)
+    net = MLP(4, ks * ks, hidden, layers).to(DEV)
+    ref = copy.deepcopy(net)
+    rng = np.random.Generator(np.random.PCG64(bs))
+    inp = tt(rng.random((bs, 4), dtype=np.float32) * 2 - 1).to(DEV)
+    psf = tt(rng.random((bs, ks * ks), dtype=np.float32)).to(DEV)
+    psf /= psf.sum(-1, keepdim=True)
+    assert supported(net, bs)
+    fit = FusedFit(net, 1e-3, 100, bs, torch.device(DEV))
+    grad, pred = fit.gradients(inp, psf)
+    torch.cuda.synchronize()
+    lin = [m for m in ref.net if isinstance(m, torch.nn.Linear)]
+    want = {}
+    for autocast in (True, False):
+        ref.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            out = ref(inp)
+        torch.nn.functional.mse_loss(out.float(), psf).backward()
+        want[autocast] = (out.detach().float().cpu().numpy(), [(m.weight.grad.cpu().numpy().copy(), m.bias.grad.cpu().numpy().copy()) for m in lin])
+    assert rel_l2(pred.cpu().numpy(), want[True][0]) <= 1e-6 and rel_l2(pred.cpu().numpy(), want[False][0]) <= 5e-3
+    for l, m in enumerate(lin):
+        gw = grad[fit.w_off[l]:fit.w_off[l] + m.weight.numel()].view_as(m.weight).cpu().numpy()
+        gb = grad[fit.b_off[l]:fit.b_off[l] + m.bias.numel()].cpu().numpy()
+        for got, k in ((gw, 0), (gb, 1)):
+            assert rel_l2(got, want[True][1][l][k]) <= 1e-2, (l, k)
+            # against fp32 autograd: no further from it than torch's own bf16 autocast is (the error grows with depth)
+            assert rel_l2(got, want[False][1][l][k]) <= max(1.5 * rel_l2(want[True][1][l][k], want[False][1][l][k]), 5e-3), (l, k)
+
+
+def test_fit_kernels_follow_torch_adamw_and_cosine_schedule():
+    """20 fused steps (one HIP graph after two plain runs) against torch.optim.AdamW + CosineAnnealingLR in fp32 on the same
+    batches: parameters agree to bf16-gradient noise, the module's own tensors hold the result (state_dict works)."""
+    import copy
+    from deeplens.psfnet import _TrainStep
+    from deeplens.psfnet_arch import MLP
+    net = MLP(4, 121, 256, 8).to(DEV)
+    net.load_state_dict({k: tt(v) for k, v in mlp_state_dict(seed=4321).items()})
+    ref = copy.deepcopy(net)
+    rng = np.random.Generator(np.random.PCG64(3))
+    data = []
+    for _ in range(4):
+        inp = tt(rng.random((128, 4), dtype=np.float32) * 2 - 1).to(DEV)
+        psf = tt(rng.random((128, 121), dtype=np.float32)).to(DEV) ** 4
+        data.append((inp, psf / psf.sum(-1, keepdim=True)))
+    step = _TrainStep(net, 1e-3, 20, 128, 121, torch.device(DEV), True, True)
+    assert step.fused is not None
+    opt = torch.optim.AdamW(ref.parameters(), 1e-3)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=20, eta_min=0)
+    first = last = None
+    for it in range(20):
+        inp, psf = data[it % 4]
+        pred = step(inp, psf)
+        loss = float(((pred - psf) ** 2).mean())
+        first, last = (loss if first is None else first), loss
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(ref(inp), psf).backward()
+        opt.step()
+        sch.step()
+    torch.cuda.synchronize()
+    assert step.fused.graph is not None and int(step.fused.step_dev.item()) == 20 and last < first
+    for (k, a), b in zip(net.state_dict().items(), ref.state_dict().values()):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 2e-2, k
+    with torch.no_grad():                                       # the bf16 operand copies follow the fp32 master parameters
+        h = step.fused.flat.to(torch.bfloat16)
+        assert torch.equal(step.fused.p16[step.fused.dst.long()], h)
+
+
+def test_fit_kernels_can_be_switched_off(monkeypatch):
+    from deeplens.psfnet import _TrainStep
+    from deeplens.psfnet_arch import MLP
+    monkeypatch.setenv("AADFF_FIT_KERNELS", "torch")
+    step = _TrainStep(MLP(4, 121, 64, 2).to(DEV), 1e-3, 20, 16, 121, torch.device(DEV), True, True)
+    assert step.fused is None
+    monkeypatch.delenv("AADFF_FIT_KERNELS")
+    wide = torch.nn.Module()
+    wide.net = torch.nn.Sequential(torch.nn.Linear(4, 512), torch.nn.ReLU(), torch.nn.Linear(512, 121), torch.nn.Sigmoid()).to(DEV)
+    wide.forward = lambda x: torch.nn.functional.normalize(wide.net(x), p=1, dim=-1)
+    assert _TrainStep(wide, 1e-3, 20, 16, 121, torch.device(DEV), True, True).fused is None      # width 512: torch-GEMM path
+
+
 def test_fused_inference_sees_weights_after_graph_training(repo_root, tmp_path):
     """The packed weights of the fused kernel are rebuilt after train_psfnet (graph replays do not bump tensor versions)."""
     net = PSFNet(lens_path(repo_root), sensor_res=(64, 64), kernel_size=11, device=DEV)
