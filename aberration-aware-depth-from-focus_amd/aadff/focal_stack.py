@@ -65,6 +65,7 @@ def draw_stack_uniforms(sampler, S, spp, L=3, spp_chief=GEO_SPP, spp_focus=GEO_S
 
 
 STAGED_UPLOAD = os.environ.get("AADFF_STAGED_UPLOAD", "1") != "0"
+REFOCUS_OVERLAP = os.environ.get("AADFF_REFOCUS_OVERLAP", "1") != "0"    # staged path: focus traces on a side stream
 try:                                                          # focus states uploaded by the refocus launch (tuning override, clamped)
     STAGE_FIRST = max(0, min(64, int(os.environ.get("AADFF_STAGE_FIRST", "3"))))
 except ValueError:
@@ -78,10 +79,16 @@ class StackPlan:
     RING = 8           # pinned/device uniform blocks in flight
     GUARD_EVERY = 4    # staged path: one guard event per 4 steps protects the reuse of a pinned block RING steps later
 
-    def __init__(self, lens, S, H, W, B=1, C_=3, grid=11, ks=11, spp=GEO_SPP):
+    def __init__(self, lens, S, H, W, B=1, C_=3, grid=11, ks=11, spp=GEO_SPP, overlap_refocus=None):
         dev = lens._gpu()
         self.lens, self.S, self.grid, self.ks, self.spp, self.dev = lens, S, grid, ks, spp, dev
-        self.states = torch.zeros(S * C.sizeof(_abi.LensState), dtype=torch.uint8, device=dev)
+        # focus states, one block per ring slot: the focus traces of stack i+1 run on a side stream WHILE the PSF-grid and
+        # convolution kernels of stack i (which read block i) are still running; `states` is the block of the last stack
+        self.states_ring = [torch.zeros(S * C.sizeof(_abi.LensState), dtype=torch.uint8, device=dev) for _ in range(self.RING)]
+        self.states = self.states_ring[0]
+        self.side = torch.cuda.Stream(dev) if (REFOCUS_OVERLAP if overlap_refocus is None else overlap_refocus) else None
+        self.side_events = [torch.cuda.Event() for _ in range(self.RING)]
+        self.side_primed = False
         self.psf_maps = torch.empty((S, 3, grid * ks, grid * ks), dtype=torch.float32, device=dev)
         self.out = torch.empty((B, C_, S, H, W), dtype=torch.float32, device=dev)
         self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -217,11 +224,25 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
             _abi.call("aadff_refocus", _abi.ptr(dep), S, C.c_void_p(ub), GEO_SPP, plan.per, _abi.ptr(plan.tab_green),
                       plan.lc, _abi.ptr(plan.states), st)
         else:       # host draws: the upload rides on the refocus launch
-            u_pin, u = plan.uniforms_host(lens.sampler)
+            slot = plan.turn % plan.RING
+            u_pin, u = plan.uniforms_host(lens.sampler)          # waits (host) until the stack that last used this slot is done
             ub = u.data_ptr()
             first = min(S, STAGE_FIRST)
+            plan.states = plan.states_ring[slot]
+            rst = st
+            if plan.side is not None:
+                # The focus traces depend on nothing the previous stack produces: launched on the plan's side stream they
+                # run beside the previous stack's PSF-grid / convolution kernels (a handful of workgroups, latency-bound).
+                if not plan.side_primed:
+                    plan.side.wait_stream(torch.cuda.current_stream(dev))     # plan buffers were filled on the caller's stream
+                    plan.side_primed = True
+                rst = C.c_void_p(plan.side.cuda_stream)
             _abi.call("aadff_refocus_staged", _abi.ptr(dep), S, C.c_void_p(u_pin.data_ptr()), C.c_void_p(ub), first * plan.per,
-                      GEO_SPP, plan.per, _abi.ptr(plan.tab_green), plan.lc, _abi.ptr(plan.states), _abi.ptr(plan.refocus_scratch), st)
+                      GEO_SPP, plan.per, _abi.ptr(plan.tab_green), plan.lc, _abi.ptr(plan.states), _abi.ptr(plan.refocus_scratch), rst)
+            if plan.side is not None:
+                ev = plan.side_events[slot]
+                ev.record(plan.side)
+                torch.cuda.current_stream(dev).wait_event(ev)
             plan.stage_generation += 1
             stage = _abi.Stage(u_pin.data_ptr(), ub, plan.per, first, plan.stage_generation & 0xFFFFFFFF,
                                plan.stage_counters.data_ptr())
@@ -255,6 +276,57 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
     if own_plan:
         plan.check_flags()                               # one-shot calls: same sync point as the reference's asserts
     return (plan.out, plan.psf_maps) if return_maps else plan.out
+
+
+class StackPipeline:
+    """`depth` M1 stacks in flight on `depth` HIP streams (one StackPlan each, used in turn).  Within one stream a stack is
+    three dependent launches (focus traces -> PSF grid -> convolution) with ~6-12 us of queue gap between them and a
+    half-empty machine at the tail of every kernel; a second stack on another stream fills both (the PSF-grid kernel of
+    stack i+1 is VALU-bound, the convolution of stack i is LDS/MFMA/HBM-bound).  The samples are still drawn on the host
+    in call order (the reference's RNG stream), so every stack is the same as with a single plan.
+
+    render() returns (out, done): `out` [B,C,S,H,W] belongs to the slot's plan and is complete when `done` (an event on
+    the slot's stream) has fired: `torch.cuda.current_stream().wait_event(done)` or `wait()` before consuming it.  The
+    slot is reused `depth` calls later.  By default the slot's stream first waits for the caller's current stream (inputs
+    written there are complete; the previous consumer of the slot's output has finished); `inputs_ready=True` skips that
+    barrier when the caller guarantees both (same resident image, outputs consumed)."""
+
+    def __init__(self, lens, S, H, W, B=1, C_=3, grid=11, ks=11, spp=GEO_SPP, depth=2, overlap_refocus=None):
+        self.dev, self.depth = lens._gpu(), int(depth)
+        if overlap_refocus is None:
+            overlap_refocus = REFOCUS_OVERLAP and self.depth == 1      # with >= 2 streams the other stack already fills the gap
+        self.plans = [StackPlan(lens, S, H, W, B, C_, grid, ks, spp, overlap_refocus=overlap_refocus) for _ in range(self.depth)]
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.depth)] if self.depth > 1 else [None]
+        self.done = [None] * self.depth
+        self.turn = 0
+        self.args = (grid, ks, spp)
+
+    def render(self, lens, img, depth_plane_mm, focus_mm, inputs_ready=False, update_lens=False):
+        k = self.turn % self.depth
+        self.turn += 1
+        plan, st = self.plans[k], self.streams[k]
+        if st is None:
+            out = render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, *self.args, plan=plan, update_lens=update_lens)
+            return out, None
+        if not inputs_ready:
+            st.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(st):
+            out = render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, *self.args, plan=plan, update_lens=update_lens)
+            if self.done[k] is None:
+                self.done[k] = torch.cuda.Event()
+            self.done[k].record(st)
+        return out, self.done[k]
+
+    def wait(self):
+        """The caller's current stream waits for every stack rendered so far."""
+        cur = torch.cuda.current_stream(self.dev)
+        for e in self.done:
+            if e is not None:
+                cur.wait_event(e)
+
+    def check_flags(self):
+        for p in self.plans:
+            p.check_flags()
 
 
 def depth_layers(depth_mm, layers):

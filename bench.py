@@ -94,6 +94,10 @@ def main():
     ap.add_argument("--spinup-s", type=float, default=0.3, help="untimed device spin-up before the warm-up steps [s]")
     ap.add_argument("--conv-events-every", type=int, default=8,
                     help="bracket the conv launch with HIP events on every n-th timed step (an event pair costs ~6 us of queue gap)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("AADFF_BENCH_STREAMS", "1")),
+                    help="M1: stacks in flight on this many HIP streams of the one GPU (aadff.focal_stack.StackPipeline).  Default 1: "
+                         "every kernel runs alone, so the HIP-event duration of the convolution is the kernel's own (the roofline "
+                         "block); the line also carries the 2-stream throughput measured in an untimed extra leg")
     ap.add_argument("--mode", choices=("m1", "m2", "fit", "c3"), default="m1",
                     help="m1 (default, BASELINE.json metric): ray-traced PSF grid + patch convolution; "
                          "m2: RGB-D stack through the PSF surrogate network (PSFNet.render, SURVEY.md 8f-1); "
@@ -125,7 +129,7 @@ def main():
     dev = torch.device("cuda", local)
     adist.init_from_env(backend="nccl", device=dev)       # RCCL (gloo when ranks are emulated on one GPU); no-op for one process
 
-    from aadff.focal_stack import StackPlan, render_focal_stack_m1
+    from aadff.focal_stack import StackPipeline
     from aadff.sampling import DeviceSampler
     from aadff.synth import synth_depth_mm, synth_rgb
     from deeplens.optics import Lensgroup
@@ -139,7 +143,9 @@ def main():
     if args.device_rng:
         lens.sampler = DeviceSampler(dev, seed=rank)
     img = img_h.to(dev)
-    plan = StackPlan(lens, S, H, W, 1, 3, GRID, KS, SPP)
+    n_streams = 1 if (world > 1 and args.gather) else max(1, args.streams)
+    pipe = StackPipeline(lens, S, H, W, 1, 3, GRID, KS, SPP, depth=n_streams)
+    plan = pipe.plans[0]
     # HIP events bracket the conv launch on every `--conv-events-every`-th timed step
     ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for i in range(0, args.steps, max(1, args.conv_events_every))}
@@ -151,12 +157,13 @@ def main():
 
     def step(i, timed=False):
         torch.manual_seed(i)
+        cur = pipe.plans[pipe.turn % pipe.depth]
         if timed and i in ev:
-            plan.conv_events = ev[i]
+            cur.conv_events = ev[i]
         if ring is not None:
-            k, plan.out = ring.acquire()
-        out = render_focal_stack_m1(lens, img, dbar, fds, GRID, KS, SPP, plan=plan, update_lens=False)
-        plan.conv_events = None
+            k, cur.out = ring.acquire()
+        out, _ = pipe.render(lens, img, dbar, fds, inputs_ready=True)      # the image is resident; outputs are not consumed here
+        cur.conv_events = None
         if ring is not None:
             ring.submit(k)
         return out
@@ -186,8 +193,11 @@ def main():
     dt = adist.all_reduce_max(time.perf_counter() - t0)
 
     # ---- untimed: kernel error flags of every step so far (NaN residual / no valid chief ray -> the number is void)
-    bits = int(plan.flags.item())
-    plan.flags.zero_()
+    torch.cuda.synchronize(dev)
+    bits = 0
+    for p_ in pipe.plans:
+        bits |= int(p_.flags.item())
+        p_.flags.zero_()
     if bits & 3:
         print(f"bench: kernel flags 0x{bits:x} raised during the timed loop (bit0 NaN in Newton residual, bit1 no valid chief ray)",
               file=sys.stderr, flush=True)
@@ -206,18 +216,44 @@ def main():
     # ---- untimed: the fused trace/PSF kernel bracketed by HIP events on its own launch stream
     pev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
     for i, e in enumerate(pev):
-        plan.psf_events = e
+        torch.cuda.synchronize(dev)                                   # alone on the device: the kernel's own duration
+        cur = pipe.plans[pipe.turn % pipe.depth]
+        cur.psf_events = e
         step(i)
-    plan.psf_events = None
+        cur.psf_events = None
     torch.cuda.synchronize(dev)
     psf_ms = float(np.median([a.elapsed_time(b) for a, b in pev]))
     # ---- untimed: the pixels of a seed-0 step for the parity block
-    step(0)
     torch.cuda.synchronize(dev)
-    got = plan.out[0].cpu().numpy() if rank == 0 else None          # [3,S,H,W]
+    out0 = step(0)
+    torch.cuda.synchronize(dev)
+    got = out0[0].cpu().numpy() if rank == 0 else None              # [3,S,H,W]
 
     conv_ms = float(np.mean([a.elapsed_time(b) for a, b in ev.values()]))
     achieved = ALG_BYTES_PER_SLICE * S / (conv_ms * 1e-3)
+    # ---- untimed extra: the same stacks with two in flight on two streams (StackPipeline).  Kernels of different stacks
+    # then share the device, so per-kernel durations stop meaning anything (the convolution reads 2.6x longer while the PSF
+    # kernel of the next stack runs beside it) - which is why the contract line above is measured on one stream.
+    two = None
+    if n_streams == 1 and ring is None and args.steps >= 20:
+        pipe2 = StackPipeline(lens, S, H, W, 1, 3, GRID, KS, SPP, depth=2)
+        n2 = min(args.steps, 200)
+        for i in range(20):
+            torch.manual_seed(i)
+            pipe2.render(lens, img, dbar, fds, inputs_ready=True)
+        barrier()
+        t2 = time.perf_counter()
+        for i in range(n2):
+            torch.manual_seed(i)
+            pipe2.render(lens, img, dbar, fds, inputs_ready=True)
+        barrier()
+        dt2 = adist.all_reduce_max(time.perf_counter() - t2)
+        for p_ in pipe2.plans:
+            bits |= int(p_.flags.item())
+        two = {"value": round(world * S * H * W / 1e6 * n2 / dt2, 2), "unit": "MP/s", "ms_per_step": round(dt2 / n2 * 1e3, 4), "steps": n2,
+               "what": "same stacks, two in flight on two HIP streams of the one GPU (aadff.focal_stack.StackPipeline, bench.py --streams 2); "
+                       "untimed extra leg, not `value`"}
+        del pipe2
     traffic = unique = None
     tpath = os.path.join(REPO, "profiles", "conv_traffic.json")
     if os.path.exists(tpath):
@@ -237,6 +273,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "latency_ms_p50": round(float(np.median(lat)) * 1e3, 4),
+            "streams": n_streams, "throughput_two_streams": two,
             "config": {"workload": "rf50mm, 1024x1024 synthetic RGB + depth plane, 10 focus distances, 11x11 PSF grid, "
                                    "ks 11, spp 2048 (+2048 chief), mode M1 (refocus -> psf_map -> render_psf_map)",
                        "stacks_per_step_per_gpu": 1, "pupil_samples": "device RNG" if args.device_rng else "host torch RNG, reference call order",

@@ -1142,6 +1142,54 @@ def test_staged_upload_late_block_is_read_from_pinned_memory(repo_root, monkeypa
             raise_psf_flags(bits[True])
 
 
+def _render_steps(repo_root, make, steps, consume):
+    from aadff import focal_stack as fs
+    H = W = 64
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(H, W), device=DEV)
+    img = tt(synth_rgb(H, W))[None].to(DEV)
+    fds = [-600.0, -800.0, -1100.0, -1500.0, -2500.0, -5000.0]
+    obj = make(fs, lens, len(fds), H, W)
+    res = []
+    for step in range(steps):
+        torch.manual_seed(300 + step)
+        res.append(consume(obj, lens, img, fds))
+    torch.cuda.synchronize()
+    return obj, res
+
+
+def test_focus_traces_on_side_stream_give_the_same_stacks(repo_root):
+    """StackPlan(overlap_refocus=True) launches the focus traces of a stack on the plan's side stream (they run beside the
+    previous stack's kernels) with one focus-state block per ring slot: over 2*RING + 3 steps the stacks equal those of
+    the in-line order, and the caller's stream sees finished outputs (clone on the current stream right after the call)."""
+    from aadff.focal_stack import StackPlan
+    run = lambda ov: _render_steps(
+        repo_root, lambda fs, lens, S, H, W: fs.StackPlan(lens, S, H, W, 1, 3, 5, 11, 512, overlap_refocus=ov), 2 * StackPlan.RING + 3,
+        lambda plan, lens, img, fds: render_focal_stack_m1(lens, img, -1200.0, fds, grid=5, ks=11, spp=512, plan=plan).clone())
+    (pa, a), (pb, b) = run(True), run(False)
+    assert pa.side is not None and pb.side is None and int(pa.flags.item()) & ~8 == 0
+    for x, y in zip(a, b):
+        assert rel_l2(x.cpu().numpy(), y.cpu().numpy()) <= 1e-5           # histogram atomics: sum order only
+    assert (a[0] - a[1]).abs().max().item() > 1e-4
+
+
+def test_stack_pipeline_two_streams_equals_one_plan(repo_root):
+    """StackPipeline(depth=2): stacks alternate between two plans on two streams (two in flight).  The host still draws the
+    samples in call order, so stack i equals stack i of a single plan; `done` orders the consumer behind the slot's stream."""
+    def consume(pipe, lens, img, fds):
+        out, done = pipe.render(lens, img, -1200.0, fds)
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
+        return out.clone()
+    mk = lambda depth: (lambda fs, lens, S, H, W: fs.StackPipeline(lens, S, H, W, 1, 3, 5, 11, 512, depth=depth))
+    (p2, a), (p1, b) = _render_steps(repo_root, mk(2), 19, consume), _render_steps(repo_root, mk(1), 19, consume)
+    assert len(p2.plans) == 2 and p2.streams[0] is not None and p1.streams == [None]
+    p2.check_flags()
+    for x, y in zip(a, b):
+        assert rel_l2(x.cpu().numpy(), y.cpu().numpy()) <= 1e-5
+    assert (a[0] - a[1]).abs().max().item() > 1e-4
+    p2.wait()                                                               # no-op ordering call must not raise
+
+
 def test_staged_upload_rejects_unpinned_host_block(repo_root):
     lens = Lensgroup(lens_path(repo_root), sensor_res=(64, 64), device=DEV)
     u_host = torch.rand(4 * GEO_SPP)                           # pageable, not device-mapped
