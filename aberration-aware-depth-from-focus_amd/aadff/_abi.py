@@ -45,6 +45,19 @@ class Stage(C.Structure):
                 ("first_slice", C.c_int), ("generation", C.c_uint), ("counters", C.c_void_p)]
 
 
+FIT_MAX_LAYERS = 16
+
+
+class FitNet(C.Structure):
+    """aadff_fit_net: the PSF network and its buffers for aadff_fit_chain (offsets in elements)."""
+    _L, _L1 = C.c_int * FIT_MAX_LAYERS, C.c_int * (FIT_MAX_LAYERS + 1)
+    _fields_ = [("n_layers", C.c_int), ("batch", C.c_int), ("ld_batch", C.c_int),
+                ("k", _L), ("n", _L), ("ld_k", _L), ("ld_n", _L), ("off_w", _L), ("off_wt", _L), ("off_b", _L),
+                ("off_xt", _L1), ("off_dzt", _L1), ("off_gw", _L), ("off_gb", _L),
+                ("param_bf16", C.c_void_p), ("scratch_bf16", C.c_void_p), ("grad", C.c_void_p),
+                ("inp", C.c_void_p), ("target", C.c_void_p), ("pred", C.c_void_p)]
+
+
 assert C.sizeof(Stage) == 40
 assert C.sizeof(Surface) == 132 and C.sizeof(LensState) == 32 and C.sizeof(LensConst) == 52
 
@@ -73,6 +86,7 @@ PROTOTYPES = {
     "aadff_relu_bwd_bias": [_P, _P, _P, _P, _I, _I, _I, _P],
     "aadff_psfnet_head_loss_grad": [_P, _P, _P, _P, _I, _I, _I, _P],
     "aadff_fit_gemm_nt": [_P, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P],
+    "aadff_fit_chain": [_P, _P, _P, _F, _I, _F, _F, _F, _P],
     "aadff_fit_layer_bwd": [_P, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P],
     "aadff_fit_input": [_P, _P, _I, _P, _I, _I, _I, _P],
     "aadff_fit_head": [_P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _F, _I, _F, _F, _F, _P],

@@ -86,7 +86,10 @@ class StackPlan:
         # convolution kernels of stack i (which read block i) are still running; `states` is the block of the last stack
         self.states_ring = [torch.zeros(S * C.sizeof(_abi.LensState), dtype=torch.uint8, device=dev) for _ in range(self.RING)]
         self.states = self.states_ring[0]
-        self.side = torch.cuda.Stream(dev) if (REFOCUS_OVERLAP if overlap_refocus is None else overlap_refocus) else None
+        # high priority: its few workgroups take the first slots the running PSF-grid kernel frees, instead of queueing
+        # behind that kernel's remaining workgroups and then running beside (and slowing) the convolution
+        prio = int(os.environ.get("AADFF_REFOCUS_PRIORITY", "-1"))
+        self.side = torch.cuda.Stream(dev, priority=prio) if (REFOCUS_OVERLAP if overlap_refocus is None else overlap_refocus) else None
         self.side_events = [torch.cuda.Event() for _ in range(self.RING)]
         self.side_primed = False
         self.psf_maps = torch.empty((S, 3, grid * ks, grid * ks), dtype=torch.float32, device=dev)

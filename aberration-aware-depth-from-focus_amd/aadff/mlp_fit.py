@@ -2,7 +2,10 @@
 chain of hand-written bf16 MFMA kernels (csrc/mlp_train.hip) instead of torch autograd over hipBLASLt.
 
 For a batch of 128 rows every GEMM of the step is at most 256 x 256 x 256: launch latency, not arithmetic, sets the time
-(33 hipBLASLt launches of 8-10 us each).  One NT GEMM kernel form covers forward, dX and dW once every activation,
+(33 hipBLASLt launches of 8-10 us each).  Default ("chain", 3 launches): rows of the batch only meet in dW, so ONE kernel takes
+16 rows per workgroup through the input cast, all layers, the head and the whole dX chain with the activations in LDS
+(`aadff_fit_chain`), a second computes dW of every layer, the third is the optimiser.  `AADFF_FIT_CHAIN=0` selects the
+layer-by-layer form below (25 launches), which also serves as its cross-check.  One NT GEMM kernel form covers forward, dX and dW once every activation,
 gradient and weight also exists transposed; its epilogues absorb bias + ReLU, the ReLU mask of the backward pass and the
 bias gradient.  25 launches per step (input cast, 11 forward, head + optimiser scalars, 11 layer backwards [dW and dX together],
 optimiser),
@@ -10,6 +13,7 @@ captured in one HIP graph.  Master parameters, Adam moments and gradients stay f
 autocast computes in), refreshed by the optimiser kernel through per-element destination maps.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -92,6 +96,24 @@ class FusedFit:
         self.psf = torch.zeros(self.bs, self.N[-1], dtype=torch.float32, device=dev)
         self.pred = torch.zeros(self.bs, self.N[-1], dtype=torch.float32, device=dev)
         self.graph, self.side, self.t = None, torch.cuda.Stream(dev), 0
+        # ---- chain form: one bf16 scratch for every X_l^T / dZ_l^T and the descriptor of aadff_fit_chain
+        self.chain = os.environ.get("AADFF_FIT_CHAIN", "1") != "0" and self.L <= _abi.FIT_MAX_LAYERS and all(k % 4 == 0 for k in self.K)
+        if self.chain:
+            net, off = _abi.FitNet(), 0
+            net.n_layers, net.batch, net.ld_batch = self.L, self.bs, self.ldb
+            for l in range(self.L):
+                net.k[l], net.n[l], net.ld_k[l], net.ld_n[l] = self.K[l], self.N[l], self.ldk[l], self.ldn[l]
+                net.off_w[l], net.off_wt[l], net.off_b[l] = self.o_w[l], self.o_wt[l], self.o_b[l]
+                net.off_gw[l], net.off_gb[l] = self.w_off[l], self.b_off[l]
+                net.off_xt[l] = off
+                off += _up(self.K[l], 4) * self.ldb
+            for l in range(1, self.L + 1):
+                net.off_dzt[l] = off
+                off += self.N4[l - 1] * self.ldb
+            self.scratch16 = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+            net.param_bf16, net.scratch_bf16, net.grad = self.p16.data_ptr(), self.scratch16.data_ptr(), self.grad.data_ptr()
+            net.inp, net.target, net.pred = self.inp.data_ptr(), self.psf.data_ptr(), self.pred.data_ptr()
+            self.net_desc = net
 
     def refresh_operands(self):
         """bf16 operand copies from the fp32 master parameters (after construction or an external load_state_dict)."""
@@ -106,8 +128,19 @@ class FusedFit:
     def _g(self, off):
         return C.c_void_p(self.grad.data_ptr() + 4 * off)
 
+    def _adamw(self, st):
+        _abi.call("aadff_fit_adamw", _abi.ptr(self.flat), _abi.ptr(self.grad), _abi.ptr(self.m), _abi.ptr(self.v), _abi.ptr(self.p16),
+                  _abi.ptr(self.dst), _abi.ptr(self.dst_t), self.n, _abi.ptr(self.scal), C.c_float(self.BETAS[0]), C.c_float(self.BETAS[1]),
+                  C.c_float(self.EPS), st)
+
     def _body(self, optimise=True):
         B, st, L = self.bs, _abi.stream_ptr(self.dev), self.L
+        if self.chain:
+            _abi.call("aadff_fit_chain", C.byref(self.net_desc), _abi.ptr(self.step_dev) if optimise else None, _abi.ptr(self.scal),
+                      C.c_float(self.lr0), self.T, C.c_float(self.BETAS[0]), C.c_float(self.BETAS[1]), C.c_float(self.WD), st)
+            if optimise:
+                self._adamw(st)
+            return
         _abi.call("aadff_fit_input", _abi.ptr(self.inp), _abi.ptr(self.X[0]), self.X[0].shape[1], _abi.ptr(self.XT[0]), self.ldb, B, self.K[0], st)
         for l in range(L):                                                         # ---- forward: X_{l+1} = relu(X_l W_l^T + b_l)
             last = l == L - 1
@@ -126,9 +159,7 @@ class FusedFit:
                       _abi.ptr(self.X[i]) if dx else None, self.X[i].shape[1], _abi.ptr(self.dZ[i]) if dx else None, self.ldn[i - 1] if dx else 0,
                       _abi.ptr(self.dZT[i]) if dx else None, self.ldb, self._g(self.b_off[i - 1]) if dx else None, st)
         if optimise:
-            _abi.call("aadff_fit_adamw", _abi.ptr(self.flat), _abi.ptr(self.grad), _abi.ptr(self.m), _abi.ptr(self.v), _abi.ptr(self.p16),
-                      _abi.ptr(self.dst), _abi.ptr(self.dst_t), self.n, _abi.ptr(self.scal), C.c_float(self.BETAS[0]), C.c_float(self.BETAS[1]),
-                      C.c_float(self.EPS), st)
+            self._adamw(st)
 
     def gradients(self, inp, psf):
         """Forward + backward WITHOUT the optimiser: the flat fp32 gradient (a copy; the buffer is cleared) and the prediction.  For tests."""

@@ -10,8 +10,16 @@ which `aadff_refocus_staged` uploads from inside the refocus launch (the focus w
 PCIe meanwhile); `aadff_psf_points` then traces the bs target PSFs from the device copy.  Two launches per batch, no
 memcpy, no host synchronisation: the kernels' error flags (NaN residual, no valid chief ray: the reference's asserts)
 are published to a pinned mirror every few batches and polled when the ring wraps.
+
+Optionally (`overlap=True` / AADFF_FIT_OVERLAP=1) the launches go to the plan's own side stream and batch j+1 is produced while the optimisation step of batch j runs (the
+step is a chain of small latency-bound kernels on a few CUs; the traces use the rest of the chip): `next()` hands out
+the batch launched by the previous call and - unless told `prefetch=False` - draws and launches the following one.  The
+host draws are the reference's, in the reference's order (nothing else consumes the RNGs between two batches of the fit
+loop); only the moment they are drawn moves.  The focus state is traced into the plan's own two-slot buffer and copied
+to the lens when the flags are checked / with the last batch, so nothing on the caller's stream races with the producer.
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -25,8 +33,16 @@ class TrainingDataPlan:
     RING = 8
     GUARD_EVERY = 4
 
-    def __init__(self, net, bs, spp):
+    def __init__(self, net, bs, spp, overlap=None):
         dev = net._gpu()
+        if overlap is None:
+            # Off by default: at bs 128 / spp 2048 the fit loop is bound by the HOST side of a batch (draws + ~8 torch CPU ops
+            # + launches, 0.15 ms) once the step runs as aadff_fit_chain; the extra stream bookkeeping then costs more than
+            # the overlap returns (measured 4 810 against 5 000 it/s).  It pays when the traces are the long pole (large spp).
+            overlap = os.environ.get("AADFF_FIT_OVERLAP", "0") == "1"
+        self.side = torch.cuda.Stream(dev) if overlap else None
+        self.state = [torch.zeros(C.sizeof(_abi.LensState), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.pending, self.last_slot = None, None
         self.net, self.bs, self.spp, self.dev, self.ks = net, int(bs), int(spp), dev, net.kernel_size
         self.o_main = 2 * GEO_SPP
         self.o_chief = self.o_main + 2 * self.spp
@@ -58,14 +74,39 @@ class TrainingDataPlan:
     def check_flags(self):
         """Synchronous form: raise the reference's errors for anything flagged so far."""
         from deeplens.optics import raise_psf_flags
+        self._sync_lens_state()
+        if self.side is not None:
+            self.side.synchronize()
         bits = int(self.flags.item())
         if bits:
             self.flags.zero_()
             self.flags_mirror[0] = 0
         raise_psf_flags(bits)
 
-    def next(self):
-        """(inp [bs,4], psf [bs,ks*ks]) of the next batch as DEVICE views that stay valid for RING - 1 further calls."""
+    def _sync_lens_state(self):
+        """The lens is left focused where the last batch handed out was traced (reference: refocus inside get_training_data)."""
+        if self.side is not None and self.last_slot is not None:
+            self.net._state_device().copy_(self.state[self.last_slot])
+            self.net._state_stale = True
+
+    def next(self, prefetch=True):
+        """(inp [bs,4], psf [bs,ks*ks]) of the next batch as DEVICE views that stay valid for RING - 2 further calls; the
+        caller's current stream is ordered behind the launches that produce them.  prefetch=False: do not draw / launch
+        the following batch (single batches, the last iteration: the RNGs stay where the reference leaves them)."""
+        if self.pending is None:
+            self.pending = self._launch()
+        k, ev, slot = self.pending
+        if ev is not None:
+            torch.cuda.current_stream(self.dev).wait_event(ev)
+        self.last_slot = slot
+        self.pending = self._launch() if (prefetch and self.side is not None) else None
+        if self.pending is None:
+            self._sync_lens_state()
+        bs = self.bs
+        return self.u_dev[k][self.o_inp:self.o_inp + 4 * bs].view(bs, 4), self.psf[k]
+
+    def _launch(self):
+        """Draw batch `turn` on the host and enqueue its two launches (side stream when overlapping)."""
         net, bs, spp = self.net, self.bs, self.spp
         k = self.turn % self.RING
         last = self.turn - self.RING
@@ -93,9 +134,16 @@ class TrainingDataPlan:
         # ---- two launches
         dev_blk = self.u_dev[k]
         ub = dev_blk.data_ptr()
-        st_dev = net._state_device()
+        slot = self.turn % 2
+        st_dev = net._state_device() if self.side is None else self.state[slot]
         with torch.cuda.device(self.dev):
-            st = _abi.stream_ptr(self.dev)
+            if self.side is None:
+                st, rec = _abi.stream_ptr(self.dev), None
+            else:
+                # behind everything the consumer has enqueued so far: the step that read this ring slot RING batches ago,
+                # and any copy of the focus state to the lens
+                self.side.wait_stream(torch.cuda.current_stream(self.dev))
+                st, rec = C.c_void_p(self.side.cuda_stream), self.side
             _abi.call("aadff_refocus_staged", C.c_void_p(self.dep_all.data_ptr() + 4 * idx), 1, C.c_void_p(pin.data_ptr()),
                       C.c_void_p(ub), self.per, GEO_SPP, self.per, _abi.ptr(self.tab_green), self.lc, _abi.ptr(st_dev),
                       _abi.ptr(self.scratch), st)
@@ -106,11 +154,17 @@ class TrainingDataPlan:
             if self.turn % self.GUARD_EVERY == self.GUARD_EVERY - 1:
                 _abi.call("aadff_publish_flags", _abi.ptr(self.flags), C.c_void_p(self.flags_mirror.data_ptr()), st)
                 e = torch.cuda.Event()
-                e.record()
+                e.record(rec) if rec is not None else e.record()
                 m = self.turn // self.GUARD_EVERY
                 self.guards[m] = e
                 for old in [q for q in self.guards if q < m - self.RING // self.GUARD_EVERY - 1]:
                     del self.guards[old]
-        net._state_stale = True
+        ev = None
+        if rec is not None:
+            self.events = getattr(self, "events", None) or [torch.cuda.Event() for _ in range(self.RING)]
+            ev = self.events[k]
+            ev.record(rec)
+        else:
+            net._state_stale = True
         self.turn += 1
-        return dev_blk[self.o_inp:self.o_inp + 4 * bs].view(bs, 4), self.psf[k]
+        return k, ev, slot

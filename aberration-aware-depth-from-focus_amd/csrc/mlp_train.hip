@@ -119,7 +119,7 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmArgs& g, int bx, int by) 
             for (int i = 0; i < 4; ++i) {
                 float s = colsum[i];
                 s += __shfl_xor(s, 1, kWave); s += __shfl_xor(s, 2, kWave); s += __shfl_xor(s, 4, kWave); s += __shfl_xor(s, 8, kWave);
-                if (lo4 == 0 && a + i < g.na) atomicAdd(g.dbias + a + i, s);
+                if (lo4 == 0 && a + i < g.na) unsafeAtomicAdd(g.dbias + a + i, s);
             }
         }
     }
@@ -144,6 +144,267 @@ __global__ __launch_bounds__(256) void fit_input_kernel(const float* __restrict_
     const uint16_t h = f2bf(inp[i]);
     x[(size_t)r * ld + c] = h;
     xT[(size_t)c * ldT + r] = h;
+}
+
+
+// ------------------------------------------------------------------------------------
+// The whole forward + loss + dX chain of the fit step in ONE launch.  A row of the batch never meets another row before
+// dW, so a workgroup takes 16 rows (the MFMA N extent) through all layers: activations stay in LDS (they are the ReLU
+// masks of the backward pass), the weights stream from L2 as MFMA A fragments (W for the forward, W^T for dX), and the
+// only things written to HBM are what dW needs - every X_l^T and dZ_l^T - plus the bias gradients (one atomic per
+// column and workgroup).  22 dependent launches of ~6 us become one kernel of ~22 layer passes.  Eight waves split the
+// feature tiles of a layer, two tiles per wave and pass with all their weight fragments in flight together.
+// LDS: X_l [16][up32(width_l) + 8] bf16 for l = 0..L (the +8 halves shift consecutive rows by one 16-byte slot:
+// the ds_read_b128 of 16 rows x one k-group touches every bank once), two dZ buffers [16][up32(max width) + 8].
+// ------------------------------------------------------------------------------------
+constexpr int kChainThreads = 512, kChainWaves = 8, kChainRows = 16;
+__host__ __device__ inline int chain_pitch(int w) { return (w + 31) / 32 * 32 + 8; }
+__host__ __device__ inline int chain_width(const aadff_fit_net& a, int l) { return l == 0 ? a.k[0] : a.n[l - 1]; }
+
+// The A operand of one layer pass for this wave: weight rows of feature tiles `wave` and `wave + 8` (widths <= 256: at most
+// 16 tiles), all 8 k-steps.  Loaded for the NEXT pass before the epilogue stores of the current one are issued: gfx9 counts
+// loads and stores in one in-order counter, so loads issued after the stores could not be waited for without the stores.
+struct ChainFrag { uint4v a0[8], a1[8]; uint2 bias0, bias1; };     // + the forward pass's bias values of the two tiles
+
+__device__ __forceinline__ void chain_load(ChainFrag& f, const uint16_t* M, int rows, int ld, int wave, int lo4, int kg) {
+    const uint16_t* pa0 = M + (size_t)min(wave * 16 + lo4, rows - 1) * ld;
+    const uint16_t* pa1 = M + (size_t)min((wave + kChainWaves) * 16 + lo4, rows - 1) * ld;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int c = 32 * s + 8 * kg, ca = c + 8 <= ld ? c : 0;       // columns past the leading dimension: masked in chain_mma
+        f.a0[s] = *reinterpret_cast<const uint4v*>(pa0 + ca);
+        f.a1[s] = *reinterpret_cast<const uint4v*>(pa1 + ca);
+    }
+}
+
+// acc{0,1} = A{0,1}[feat][c] . B[row][c] over the contraction, B rows from LDS (pitch pb).
+__device__ __forceinline__ void chain_mma(const ChainFrag& f, int lda, const uint16_t* Bl, int pb, int ksteps, int lo4, int kg,
+                                          float4v& acc0, float4v& acc1) {
+    acc0 = acc1 = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (s < ksteps) {
+            const int c = 32 * s + 8 * kg;
+            const unsigned keep = c + 8 <= lda ? 0xffffffffu : 0u;
+            const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(Bl + lo4 * pb + c));
+            const uint4v m0 = {f.a0[s][0] & keep, f.a0[s][1] & keep, f.a0[s][2] & keep, f.a0[s][3] & keep};
+            const uint4v m1 = {f.a1[s][0] & keep, f.a1[s][1] & keep, f.a1[s][2] & keep, f.a1[s][3] & keep};
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, m0), b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, m1), b, acc1, 0, 0, 0);
+        }
+    }
+}
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() would also wait for every global store in flight
+// (the X^T / dZ^T rows nobody reads in this kernel), once per layer.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(kChainThreads) void fit_chain_kernel(aadff_fit_net a, AdamwSchedule sch) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, kg = lane >> 4, lo4 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = a.n_layers, B = a.batch, r0 = blockIdx.x * kChainRows, ldb = a.ld_batch;
+    const uint16_t* p16 = static_cast<const uint16_t*>(a.param_bf16);
+    uint16_t* scr = static_cast<uint16_t*>(a.scratch_bf16);
+    // pass p = 0..L-1: forward layer p (A = W_p); pass p = L..2L-2: dX of layer i = 2L-1-p (A = W_i^T).  The weights depend on
+    // nothing computed here, so the A fragments are fetched TWO passes ahead into two register sets (one L2/HBM round trip
+    // is longer than one pass).
+    const int P = 2 * L - 1;
+    auto fetch = [&](int q, ChainFrag& f) {
+        if (q < L) {
+            const int n4 = (a.n[q] + 3) & ~3;
+            chain_load(f, p16 + a.off_w[q], n4, a.ld_k[q], wave, lo4, kg);
+            // fetched with the weights: a load issued later (in the epilogue) could only be waited for together with every
+            // prefetch issued before it (one in-order counter)
+            const uint16_t* bias = p16 + a.off_b[q];
+            f.bias0 = *reinterpret_cast<const uint2*>(bias + min(wave * 16 + 4 * kg, n4 - 4));
+            f.bias1 = *reinterpret_cast<const uint2*>(bias + min((wave + kChainWaves) * 16 + 4 * kg, n4 - 4));
+        } else if (q < P) { const int i = 2 * L - 1 - q; chain_load(f, p16 + a.off_wt[i], a.k[i], a.ld_n[i], wave, lo4, kg); }
+    };
+    ChainFrag f0, f1;
+    fetch(0, f0);
+    fetch(1, f1);
+    int xtotal = 0, maxw = 0;
+    for (int l = 0; l <= L; ++l) {
+        const int w = chain_width(a, l);
+        xtotal += kChainRows * chain_pitch(w);
+        maxw = w > maxw ? w : maxw;
+    }
+    const int PZ = chain_pitch(maxw);
+    uint16_t* dzbuf[2] = {lds + xtotal, lds + xtotal + kChainRows * PZ};
+    {   // zero everything once: the padding columns are contraction inputs
+        const int n16 = (xtotal + 2 * kChainRows * PZ) / 8;
+        uint4v* z = reinterpret_cast<uint4v*>(lds);
+        for (int i = tid; i < n16; i += kChainThreads) z[i] = (uint4v){0u, 0u, 0u, 0u};
+    }
+    lds_barrier();
+    {   // network input of the 16 rows: fp32 -> bf16 into X_0 and X_0^T
+        const int K0 = a.k[0], p0 = chain_pitch(K0);
+        uint16_t* xt0 = scr + a.off_xt[0];
+        for (int i = tid; i < kChainRows * K0; i += kChainThreads) {
+            const int row = i / K0, c = i - row * K0, g = r0 + row;
+            if (g < B) {
+                const uint16_t h = f2bf(a.inp[(size_t)g * K0 + c]);
+                lds[row * p0 + c] = h;
+                xt0[(size_t)c * ldb + g] = h;
+            }
+        }
+    }
+    // ---- forward
+    int xoff = 0;
+    auto forward = [&](int l, ChainFrag& f) {
+        lds_barrier();
+        const int K = a.k[l], N = a.n[l], N4 = (N + 3) & ~3, ldk = a.ld_k[l];
+        const int pl = chain_pitch(K), pn = chain_pitch(N);
+        uint16_t* Xn = lds + xoff + kChainRows * pl;
+        uint16_t* xt = scr + a.off_xt[l + 1 < L ? l + 1 : 0];
+        const bool last = l == L - 1;
+        float4v acc[2];
+        chain_mma(f, ldk, lds + xoff, pl, (K + 31) >> 5, lo4, kg, acc[0], acc[1]);
+        const uint2 bias2[2] = {f.bias0, f.bias1};
+        fetch(l + 2, f);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int feat = (wave + t * kChainWaves) * 16 + 4 * kg;
+            if (feat < N4) {
+                const uint2 bb = bias2[t];
+                const uint16_t bh[4] = {(uint16_t)(bb.x & 0xffffu), (uint16_t)(bb.x >> 16), (uint16_t)(bb.y & 0xffffu), (uint16_t)(bb.y >> 16)};
+                uint16_t h[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x = acc[t][i] + bf2f(bh[i]);
+                    if (!last) x = fmaxf(x, 0.f);
+                    h[i] = f2bf(x);
+                }
+                *reinterpret_cast<uint2*>(Xn + lo4 * pn + feat) =
+                    make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+                if (!last && r0 + lo4 < B) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xt[(size_t)(feat + i) * ldb + r0 + lo4] = h[i];
+                }
+            }
+        }
+        xoff += kChainRows * pl;
+    };
+    for (int l = 0; l < L; l += 2) {
+        forward(l, f0);
+        if (l + 1 < L) forward(l + 1, f1);
+    }
+    lds_barrier();
+    // ---- head: sigmoid, L1 normalise, d MSE / dz (the arithmetic of fit_head_kernel), two rows per wave
+    const int NL = a.n[L - 1], pL = chain_pitch(NL);
+    {
+        const uint16_t* Z = lds + xoff;
+        uint16_t* dzt = scr + a.off_dzt[L];
+        if (blockIdx.x == 0 && tid == 0 && sch.step) adamw_prepare(sch);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr, g = r0 + row;
+            const bool valid = g < B;
+            float sg[2], tg[2], S = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = lane + 64 * k;
+                sg[k] = 0.f; tg[k] = 0.f;
+                if (c < NL) {
+                    sg[k] = bf2f(f2bf(1.f / (1.f + __expf(-bf2f(Z[row * pL + c])))));
+                    tg[k] = valid ? a.target[(size_t)g * NL + c] : 0.f;
+                    S += sg[k];
+                }
+            }
+            S = fmaxf(wave_sum(S), 1e-12f);
+            const float inv = 1.f / S, scale = 2.f / ((float)B * (float)NL);
+            float gr[2], pr[2], dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                pr[k] = sg[k] * inv;
+                gr[k] = scale * (pr[k] - tg[k]);
+                dot += gr[k] * pr[k];
+            }
+            dot = wave_sum(dot);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = lane + 64 * k;
+                if (c < NL) {
+                    const uint16_t h = valid ? f2bf((gr[k] - dot) * inv * sg[k] * (1.f - sg[k])) : (uint16_t)0;
+                    dzbuf[0][row * PZ + c] = h;
+                    if (valid) {
+                        a.pred[(size_t)g * NL + c] = pr[k];
+                        dzt[(size_t)c * ldb + g] = h;
+                    }
+                }
+            }
+        }
+    }
+    lds_barrier();
+    for (int c = tid; c < NL; c += kChainThreads) {           // bias gradient of the last layer: one atomic per column and workgroup
+        float s = 0.f;
+#pragma unroll
+        for (int row = 0; row < kChainRows; ++row) s += bf2f(dzbuf[0][row * PZ + c]);
+        unsafeAtomicAdd(a.grad + a.off_gb[L - 1] + c, s);
+    }
+    // ---- dX chain: dZ_{i-1} = (dZ_i . W_i) * (X_i > 0) for i = L-1 .. 1 (X_i = input of layer i, in LDS since the forward)
+    int cur = 0;
+    auto backward = [&](int q, ChainFrag& f) {
+        const int i = 2 * L - 1 - q;
+        const int K = a.k[i], N = a.n[i], ldn = a.ld_n[i];
+        const int pi = chain_pitch(K);
+        xoff -= kChainRows * pi;                                  // X_i
+        const uint16_t* Xi = lds + xoff;
+        uint16_t* dZn = dzbuf[cur ^ 1];
+        uint16_t* dzt = scr + a.off_dzt[i];
+        float* gb = a.grad + a.off_gb[i - 1];
+        float4v acc[2];
+        chain_mma(f, ldn, dzbuf[cur], PZ, (N + 31) >> 5, lo4, kg, acc[0], acc[1]);
+        fetch(q + 2, f);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int kk = (wave + t * kChainWaves) * 16 + 4 * kg;
+            const bool in = kk < K;                              // K is a multiple of 4
+            float cs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (in) {
+                const uint2 m = *reinterpret_cast<const uint2*>(Xi + lo4 * pi + kk);
+                const uint16_t mk[4] = {(uint16_t)(m.x & 0xffffu), (uint16_t)(m.x >> 16), (uint16_t)(m.y & 0xffffu), (uint16_t)(m.y >> 16)};
+                uint16_t h[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    h[q] = f2bf(bf2f(mk[q]) > 0.f ? acc[t][q] : 0.f);
+                    cs[q] = bf2f(h[q]);
+                }
+                *reinterpret_cast<uint2*>(dZn + lo4 * PZ + kk) =
+                    make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+                if (r0 + lo4 < B) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dzt[(size_t)(kk + q) * ldb + r0 + lo4] = h[q];
+                }
+            }
+            if ((wave + t * kChainWaves) * 16 < K) {              // wave-uniform: this tile exists
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float s = cs[q];
+                    s += __shfl_xor(s, 1, kWave); s += __shfl_xor(s, 2, kWave); s += __shfl_xor(s, 4, kWave); s += __shfl_xor(s, 8, kWave);
+                    if (lo4 == 0 && in) unsafeAtomicAdd(gb + kk + q, s);
+                }
+            }
+        }
+        cur ^= 1;
+        lds_barrier();
+    };
+    // pass q uses register set q & 1 (the forward ended on set (L-1) & 1)
+    for (int q = L; q < P; ++q) {
+        if (q & 1) backward(q, f1);
+        else backward(q, f0);
+    }
+}
+
+// dW of every layer in one launch: blockIdx.z = layer, dW_l [n][k] = dZ_{l+1}^T [n][:B] . X_l^T [k][:B]  (fp32, plain stores).
+template <int KSW>
+__global__ __launch_bounds__(256) void fit_dw_all_kernel(aadff_fit_net a) {
+    const int l = blockIdx.z;
+    const uint16_t* scr = static_cast<const uint16_t*>(a.scratch_bf16);
+    GemmArgs g{scr + a.off_xt[l], a.ld_batch, a.k[l], scr + a.off_dzt[l + 1], a.ld_batch, a.n[l], a.batch,
+               a.grad + a.off_gw[l], a.k[l], nullptr, 0, nullptr, nullptr, 0, nullptr};
+    gemm_nt_tile<EPI_DW, KSW>(g, blockIdx.x, blockIdx.y);
 }
 
 // Head of the network + loss gradient for the fused fit step: per row  s = sigmoid(z), pred = s / max(sum s, 1e-12),
@@ -184,7 +445,7 @@ __global__ __launch_bounds__(64) void fit_head_kernel(const uint16_t* __restrict
             const uint16_t h = f2bf((g[k] - dot) * inv * s[k] * (1.f - s[k]));
             dz[(size_t)r * ld_dz + c] = h;
             dzT[(size_t)c * ld_dzT + r] = h;
-            atomicAdd(dbias + c, bf2f(h));
+            unsafeAtomicAdd(dbias + c, bf2f(h));
         }
     }
 }
@@ -280,6 +541,53 @@ extern "C" int aadff_fit_layer_bwd(const void* xT_prev, int ld_xT, int k, const 
     else if (kw == 4) AADFF_BWD_X(4);
     else AADFF_BWD_X(8);
 #undef AADFF_BWD_X
+    AADFF_CHECK_LAUNCH();
+    return 0;
+}
+
+
+extern "C" int aadff_fit_chain(const aadff_fit_net* net, int* step_dev, float* scratch4, float lr0, int t_max, float beta1, float beta2,
+                               float weight_decay, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(net && net->param_bf16 && net->scratch_bf16 && net->grad && net->inp && net->target && net->pred, "fit_chain: NULL pointer");
+    const aadff_fit_net& a = *net;
+    AADFF_CHECK_ARG(a.n_layers >= 2 && a.n_layers <= AADFF_FIT_MAX_LAYERS && a.batch > 0 && a.batch <= 256 && a.ld_batch % 8 == 0 && a.ld_batch >= a.batch,
+                    "fit_chain: layers %d (2..%d), batch %d (<= 256), ld_batch %d", a.n_layers, AADFF_FIT_MAX_LAYERS, a.batch, a.ld_batch);
+    AADFF_CHECK_ARG(!step_dev || (scratch4 && t_max > 0), "fit_chain: optimiser schedule needs scratch4 and t_max > 0");
+    int xtotal = 0, maxw = 0, gx = 0, gy = 0;
+    for (int l = 0; l < a.n_layers; ++l) {
+        AADFF_CHECK_ARG(a.k[l] > 0 && a.k[l] <= 256 && a.n[l] > 0 && a.n[l] <= 256 && a.k[l] % 4 == 0 && a.ld_k[l] % 8 == 0 && a.ld_n[l] % 8 == 0 &&
+                        a.ld_k[l] >= a.k[l] && a.ld_n[l] >= a.n[l], "fit_chain: layer %d: widths %d -> %d (<= 256, inputs multiples of 4), ld %d / %d",
+                        l, a.k[l], a.n[l], a.ld_k[l], a.ld_n[l]);
+        AADFF_CHECK_ARG(l == 0 || a.k[l] == a.n[l - 1], "fit_chain: layer %d input width %d != previous output %d", l, a.k[l], a.n[l - 1]);
+        AADFF_CHECK_ARG((a.off_w[l] | a.off_wt[l] | a.off_b[l] | a.off_xt[l] | a.off_dzt[l + 1]) % 8 == 0 && a.off_gw[l] % 4 == 0,
+                        "fit_chain: layer %d: buffer offsets must keep 16-byte alignment", l);
+        gx = std::max(gx, (a.k[l] + 31) / 32);
+        gy = std::max(gy, (a.n[l] + 63) / 64);
+    }
+    AADFF_CHECK_ARG(a.n[a.n_layers - 1] <= 128, "fit_chain: the head handles <= 128 outputs");
+    for (int l = 0; l <= a.n_layers; ++l) {
+        const int w = fit::chain_width(a, l);
+        xtotal += fit::kChainRows * fit::chain_pitch(w);
+        maxw = std::max(maxw, w);
+    }
+    const size_t lds_bytes = 2 * (size_t)(xtotal + 2 * fit::kChainRows * fit::chain_pitch(maxw)) + 64;
+    AADFF_CHECK_ARG(lds_bytes <= 160 * 1024, "fit_chain: %zu bytes of LDS needed (160 KB per workgroup)", lds_bytes);
+    static size_t lds_set = 0;
+    if (lds_bytes > lds_set) {
+        AADFF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fit::fit_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        lds_set = lds_bytes;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const AdamwSchedule sch{step_dev, scratch4, lr0, t_max, beta1, beta2, weight_decay};
+    hipLaunchKernelGGL(fit::fit_chain_kernel, dim3((a.batch + fit::kChainRows - 1) / fit::kChainRows), dim3(fit::kChainThreads), lds_bytes, st, a, sch);
+    AADFF_CHECK_LAUNCH();
+    const dim3 grid(gx, gy, a.n_layers);
+    switch (ksteps_class(a.batch)) {
+        case 1: hipLaunchKernelGGL(fit::fit_dw_all_kernel<1>, grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(fit::fit_dw_all_kernel<2>, grid, dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL(fit::fit_dw_all_kernel<4>, grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(fit::fit_dw_all_kernel<8>, grid, dim3(256), 0, st, a);
+    }
     AADFF_CHECK_LAUNCH();
     return 0;
 }

@@ -385,7 +385,7 @@ class PSFNet(Lensgroup):
         plan = self._training_plan(bs, spp)
         if plan is None:
             return self._get_training_data_unpipelined(bs, spp)
-        inp, psf = plan.next()
+        inp, psf = plan.next(prefetch=False)
         if getattr(self, "check_flags", True):
             plan.check_flags()
         return inp.clone(), psf.clone()
@@ -427,7 +427,7 @@ class PSFNet(Lensgroup):
         plan = self._training_plan(bs, spp)
         for i in tqdm(range(iters + 1)):
             if plan is not None:
-                inp, psf = plan.next()                   # device views, consumed in stream order by the step below
+                inp, psf = plan.next(prefetch=i < iters)    # device views; batch i+1 is traced while the step below runs
             else:
                 inp, psf = self.get_training_data(bs=bs, spp=spp)
             pred = step(inp.to(dev), psf.to(dev))

@@ -317,6 +317,34 @@ int aadff_psfnet_head_loss_grad(const void* z, const float* target, float* pred,
  *   aadff_adamw_step, step counter += 1) for the aadff_fit_adamw that follows in the same stream;
  * aadff_fit_adamw: AdamW on flat fp32 parameters with fp32 gradients (zeroed after use), refreshing the bf16 operand
  *   copies param_bf16[dst[i]] and, where dst_t[i] >= 0, param_bf16[dst_t[i]] (the transposed weights). */
+/* The same step in THREE launches (aadff_fit_chain = 2, then aadff_fit_adamw): a workgroup takes 16 rows of the batch through
+ * input cast, every Linear(+ReLU), the head and the whole dX chain with the activations in LDS (rows only meet in dW), then
+ * one launch computes dW of all layers.  `aadff_fit_net` describes the network and its buffers:
+ *   param_bf16:   W_l [up4(n)][ld_k] at off_w, W_l^T [k][ld_n] at off_wt, bias_l at off_b (bf16, zero padded; offsets in elements,
+ *                 multiples of 8; refreshed by aadff_fit_adamw);
+ *   scratch_bf16: X_l^T [k_l][ld_batch] at off_xt[l] (l = 0..L-1) and dZ_l^T [n_{l-1}][ld_batch] at off_dzt[l] (l = 1..L), written
+ *                 by the chain kernel, read by the dW kernel (zero padded columns batch..ld_batch);
+ *   grad (fp32):  dW_l [n][k] at off_gw (stored), db_l [n] at off_gb (ADDED by atomics: must be zero on entry; aadff_fit_adamw
+ *                 leaves it zero);
+ *   inp [B][k_0], target / pred [B][n_last] fp32.   Widths <= 256, input widths multiples of 4, n_last <= 128, B <= 256.
+ * When step_dev != NULL the chain also prepares the optimiser step as aadff_fit_head does. */
+#define AADFF_FIT_MAX_LAYERS 16
+typedef struct aadff_fit_net {
+    int n_layers, batch, ld_batch;
+    int k[AADFF_FIT_MAX_LAYERS], n[AADFF_FIT_MAX_LAYERS];
+    int ld_k[AADFF_FIT_MAX_LAYERS], ld_n[AADFF_FIT_MAX_LAYERS];
+    int off_w[AADFF_FIT_MAX_LAYERS], off_wt[AADFF_FIT_MAX_LAYERS], off_b[AADFF_FIT_MAX_LAYERS];
+    int off_xt[AADFF_FIT_MAX_LAYERS + 1], off_dzt[AADFF_FIT_MAX_LAYERS + 1];
+    int off_gw[AADFF_FIT_MAX_LAYERS], off_gb[AADFF_FIT_MAX_LAYERS];
+    const void* param_bf16;
+    void* scratch_bf16;
+    float* grad;
+    const float* inp;
+    const float* target;
+    float* pred;
+} aadff_fit_net;
+int aadff_fit_chain(const aadff_fit_net* net, int* step_dev, float* scratch4, float lr0, int t_max, float beta1, float beta2,
+                    float weight_decay, aadff_stream_t stream);
 int aadff_fit_gemm_nt(const void* A, int lda, int na, const void* B, int ldb, int nb, int nc, int epilogue, void* out,
                       int ld_out, void* outT, int ld_outT, const void* bias, const void* mask, int ld_mask, float* dbias,
                       aadff_stream_t stream);

@@ -14,6 +14,20 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle is torch on the CPU.  The GPU box shows 256 logical CPUs under a 16-CPU quota and this container 8: an
+    # OpenMP pool sized by the logical count stalls small ops (and has been seen to wedge a run), so size it by what is usable.
+    try:
+        import torch
+        usable = len(os.sched_getaffinity(0))
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+            if quota != "max":
+                usable = min(usable, max(1, int(quota) // int(period)))
+        except (OSError, ValueError):
+            pass
+        torch.set_num_threads(max(1, min(usable, 16)))
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope="session")

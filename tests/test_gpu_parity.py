@@ -788,8 +788,10 @@ def test_thinlens_kernel_matches_tensor_form_and_edge_cases(g67):
     assert torch.equal(out, img)                                          # delta PSF
 
 
-def test_pipelined_training_batches_equal_unpipelined(repo_root):
-    """aadff.training.TrainingDataPlan (one pinned block per batch uploaded inside the refocus launch, two launches, no
+@pytest.mark.parametrize("overlap", [False, True])
+def test_pipelined_training_batches_equal_unpipelined(repo_root, overlap):
+    """overlap=True: the producer runs one batch ahead on its own stream (same host draws in the same order).
+    aadff.training.TrainingDataPlan (one pinned block per batch uploaded inside the refocus launch, two launches, no
     sync) against the call-by-call form (refocus, then psf) on the same numpy/torch RNG streams, for 2*RING + 5 batches:
     every pinned block is reused twice, the guard wait and the flags mirror run."""
     from aadff.training import TrainingDataPlan
@@ -800,13 +802,17 @@ def test_pipelined_training_batches_equal_unpipelined(repo_root):
     want = [net._get_training_data_unpipelined(bs=32, spp=512) for _ in range(n)]
     np.random.seed(11)
     torch.manual_seed(11)
-    plan = net._training_plan(32, 512)
-    assert plan is not None
+    plan = TrainingDataPlan(net, 32, 512, overlap=overlap)
+    assert (plan.side is not None) == overlap
     got = []
-    for _ in range(n):
-        inp, psf = plan.next()
+    for j in range(n):
+        inp, psf = plan.next(prefetch=j + 1 < n)
         got.append((inp.clone(), psf.clone()))
     plan.check_flags()
+    lens_ref = PSFNet(lens_path(repo_root), sensor_res=(480, 640), kernel_size=11, device=DEV)
+    torch.manual_seed(5)
+    lens_ref.refocus(float(got[-1][0][0, 3].item()) * (lens_ref.d_max - lens_ref.d_min) + lens_ref.d_min)
+    assert net.d_sensor == pytest.approx(lens_ref.d_sensor, rel=1e-4)          # the lens is left focused where the last batch was traced
     assert len(plan.guards) <= TrainingDataPlan.RING // TrainingDataPlan.GUARD_EVERY + 2
     for i, ((ia, pa), (ib, pb)) in enumerate(zip(got, want)):
         assert torch.equal(ia.cpu(), ib.cpu()), i
@@ -927,8 +933,9 @@ def test_graph_captured_training_step_matches_eager(repo_root):
         assert rel_l2(nets[1][k], nets[2][k]) <= 1e-4 or np.abs(nets[1][k] - nets[2][k]).max() <= 1e-6, k
 
 
+@pytest.mark.parametrize("chain", ["1", "0"])
 @pytest.mark.parametrize("bs,ks,hidden,layers", [(128, 11, 256, 8), (50, 9, 128, 3), (256, 7, 64, 1), (8, 11, 256, 2)])
-def test_fit_kernels_gradients_match_torch(bs, ks, hidden, layers):
+def test_fit_kernels_gradients_match_torch(bs, ks, hidden, layers, chain, monkeypatch):
     """The hand-written fit step (csrc/mlp_train.hip via aadff/mlp_fit.py): prediction and every dW / db of one
     forward + backward against torch autograd on the same network (deeplens/psfnet.py:94-106).  bf16 operands: tolerance
     1e-2 against torch's bf16 autocast, 2e-2 against fp32 autograd.  Ragged batches / widths exercise the zero padding."""
@@ -943,7 +950,9 @@ def test_fit_kernels_gradients_match_torch(bs, ks, hidden, layers):
     psf = tt(rng.random((bs, ks * ks), dtype=np.float32)).to(DEV)
     psf /= psf.sum(-1, keepdim=True)
     assert supported(net, bs)
+    monkeypatch.setenv("AADFF_FIT_CHAIN", chain)                 # "1": 3-launch chain form, "0": layer-by-layer GEMM launches
     fit = FusedFit(net, 1e-3, 100, bs, torch.device(DEV))
+    assert fit.chain == (chain == "1")
     grad, pred = fit.gradients(inp, psf)
     torch.cuda.synchronize()
     lin = [m for m in ref.net if isinstance(m, torch.nn.Linear)]
@@ -964,7 +973,8 @@ def test_fit_kernels_gradients_match_torch(bs, ks, hidden, layers):
             assert rel_l2(got, want[False][1][l][k]) <= max(1.5 * rel_l2(want[True][1][l][k], want[False][1][l][k]), 5e-3), (l, k)
 
 
-def test_fit_kernels_follow_torch_adamw_and_cosine_schedule():
+@pytest.mark.parametrize("chain", ["1", "0"])
+def test_fit_kernels_follow_torch_adamw_and_cosine_schedule(chain, monkeypatch):
     """20 fused steps (one HIP graph after two plain runs) against torch.optim.AdamW + CosineAnnealingLR in fp32 on the same
     batches: parameters agree to bf16-gradient noise, the module's own tensors hold the result (state_dict works)."""
     import copy
@@ -979,8 +989,9 @@ def test_fit_kernels_follow_torch_adamw_and_cosine_schedule():
         inp = tt(rng.random((128, 4), dtype=np.float32) * 2 - 1).to(DEV)
         psf = tt(rng.random((128, 121), dtype=np.float32)).to(DEV) ** 4
         data.append((inp, psf / psf.sum(-1, keepdim=True)))
+    monkeypatch.setenv("AADFF_FIT_CHAIN", chain)
     step = _TrainStep(net, 1e-3, 20, 128, 121, torch.device(DEV), True, True)
-    assert step.fused is not None
+    assert step.fused is not None and step.fused.chain == (chain == "1")
     opt = torch.optim.AdamW(ref.parameters(), 1e-3)
     sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=20, eta_min=0)
     first = last = None

@@ -15,21 +15,27 @@ for s, e, t in rows:
 dur = {t: sum(e - s for s, e in v) / len(v) / 1e3 for t, v in by.items()}
 print("mean duration us:", {k: round(v, 1) for k, v in dur.items()})
 psf, conv, ref = by["psf"], by["conv"], by["refocus"]
-n = min(len(psf), len(conv)) - 1
-g1 = [conv[i][0] - psf[i][1] for i in range(n) if conv[i][0] > psf[i][0]]
-period = [(psf[i + 1][0] - psf[i][0]) / 1e3 for i in range(n)]
-print("period us (psf start to next psf start): mean %.1f" % (sum(period) / len(period)))
-print("gap psf end -> conv start: mean %.2f us" % (sum(g1) / len(g1) / 1e3))
-g2 = []
-for i in range(n):
-    nxt = [p for p in psf if p[0] >= conv[i][0]]
-    if nxt: g2.append(nxt[0][0] - conv[i][1])
-print("gap conv end -> next psf start: mean %.2f us" % (sum(g2) / len(g2) / 1e3))
+period = [(psf[i + 1][0] - psf[i][0]) / 1e3 for i in range(len(psf) - 1)]
+period = [p for p in period if p < 2 * sorted(period)[len(period) // 2]]
+print("period us (psf start to next psf start): median %.1f" % sorted(period)[len(period) // 2])
+g1, g2 = [], []
+for c in conv:
+    prv = [p for p in psf if p[1] <= c[0] + 1000]
+    nxt = [p for p in psf if p[0] >= c[1] - 1000]
+    if prv: g1.append(c[0] - prv[-1][1])
+    if nxt: g2.append(nxt[0][0] - c[1])
+med = lambda v: sorted(v)[len(v) // 2] / 1e3
+print("gap psf end -> conv start: median %.2f us; conv end -> next psf start: median %.2f us" % (med(g1), med(g2)))
 ov = []
 for s, e in ref:
     inside = [c for c in conv if c[0] < e and c[1] > s] + [p for p in psf if p[0] < e and p[1] > s]
     ov.append(1 if inside else 0)
 print("refocus launches overlapping another kernel: %d of %d" % (sum(ov), len(ov)))
+oc = sum(1 for s, e in ref if any(c[0] < e and c[1] > s for c in conv))
+print("refocus launches overlapping a convolution: %d of %d" % (oc, len(ref)))
+solo = [c[1] - c[0] for c in conv if not any(r[0] < c[1] and r[1] > c[0] for r in ref)]
+both = [c[1] - c[0] for c in conv if any(r[0] < c[1] and r[1] > c[0] for r in ref)]
+print("conv duration us: alone %.1f (n=%d), beside a refocus %.1f (n=%d)" % (sum(solo) / max(1, len(solo)) / 1e3, len(solo), sum(both) / max(1, len(both)) / 1e3, len(both)))
 for s, e in ref[:4]:
     prev_psf = [p for p in psf if p[0] <= s]
     if prev_psf:
