@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AADFF_ABI_VERSION 2
+#define AADFF_ABI_VERSION 3
 
 #define AADFF_EINVAL      (-1)   /* bad shape / size / NULL pointer                  */
 #define AADFF_EUNSUPPORTED (-2)  /* parameter outside what the kernels were built for */
