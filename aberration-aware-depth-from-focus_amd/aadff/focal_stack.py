@@ -65,7 +65,10 @@ def draw_stack_uniforms(sampler, S, spp, L=3, spp_chief=GEO_SPP, spp_focus=GEO_S
 
 
 STAGED_UPLOAD = os.environ.get("AADFF_STAGED_UPLOAD", "1") != "0"
-REFOCUS_OVERLAP = os.environ.get("AADFF_REFOCUS_OVERLAP", "1") != "0"    # staged path: focus traces on a side stream
+# staged path: focus traces of a stack on the plan's side stream, beside the previous stack's kernels.  Opt-in: +1-3 % of
+# throughput, but in ~1 of 6 stacks the traces land beside the convolution, whose own duration then reads ~5 us longer -
+# the default keeps every kernel alone on the device so that per-kernel measurements mean what they say.
+REFOCUS_OVERLAP = os.environ.get("AADFF_REFOCUS_OVERLAP", "0") == "1"
 try:                                                          # focus states uploaded by the refocus launch (tuning override, clamped)
     STAGE_FIRST = max(0, min(64, int(os.environ.get("AADFF_STAGE_FIRST", "3"))))
 except ValueError:

@@ -96,8 +96,13 @@ def main():
                     help="bracket the conv launch with HIP events on every n-th timed step (an event pair costs ~6 us of queue gap)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("AADFF_BENCH_STREAMS", "1")),
                     help="M1: stacks in flight on this many HIP streams of the one GPU (aadff.focal_stack.StackPipeline).  Default 1: "
-                         "every kernel runs alone, so the HIP-event duration of the convolution is the kernel's own (the roofline "
-                         "block); the line also carries the 2-stream throughput measured in an untimed extra leg")
+                         "the PSF-grid and convolution kernels run one after the other, so the HIP-event duration of the convolution "
+                         "is the kernel's own (the roofline block).  --streams 2: two stacks in flight (higher throughput, per-kernel "
+                         "durations no longer meaningful)")
+    ap.add_argument("--two-stream-leg", action="store_true",
+                    help="M1, with --streams 1: after the timed region also measure the same stacks with two in flight on two streams and "
+                         "report it as `throughput_two_streams` (untimed extra; off by default so that a profile of the default command "
+                         "contains only the contract's launches)")
     ap.add_argument("--mode", choices=("m1", "m2", "fit", "c3"), default="m1",
                     help="m1 (default, BASELINE.json metric): ray-traced PSF grid + patch convolution; "
                          "m2: RGB-D stack through the PSF surrogate network (PSFNet.render, SURVEY.md 8f-1); "
@@ -229,13 +234,14 @@ def main():
     torch.cuda.synchronize(dev)
     got = out0[0].cpu().numpy() if rank == 0 else None              # [3,S,H,W]
 
-    conv_ms = float(np.mean([a.elapsed_time(b) for a, b in ev.values()]))
+    conv_all = [a.elapsed_time(b) for a, b in ev.values()]
+    conv_ms = float(np.mean(conv_all))
     achieved = ALG_BYTES_PER_SLICE * S / (conv_ms * 1e-3)
     # ---- untimed extra: the same stacks with two in flight on two streams (StackPipeline).  Kernels of different stacks
     # then share the device, so per-kernel durations stop meaning anything (the convolution reads 2.6x longer while the PSF
     # kernel of the next stack runs beside it) - which is why the contract line above is measured on one stream.
     two = None
-    if n_streams == 1 and ring is None and args.steps >= 20:
+    if args.two_stream_leg and n_streams == 1 and ring is None and args.steps >= 20:
         pipe2 = StackPipeline(lens, S, H, W, 1, 3, GRID, KS, SPP, depth=2)
         n2 = min(args.steps, 200)
         for i in range(20):
@@ -291,7 +297,10 @@ def main():
                          "traffic_source": "profiles/conv_traffic.json (static: rocprofv3 PMC passes of an earlier run of this command, not measured in this run)",
                          "frac_stack_fused": round(unique / (conv_ms * 1e-3) / HBM_PEAK, 4) if unique else None,
                          "stack_fused_bytes_per_launch": unique,
-                         "kernel_ms": round(conv_ms, 4), "algorithmic_bytes_per_launch": ALG_BYTES_PER_SLICE * S,
+                         "kernel_ms": round(conv_ms, 4), "kernel_ms_median": round(float(np.median(conv_all)), 4),
+                         "kernel_ms_note": "HIP events on the launch stream around every 8th launch of the timed region (mean; an event pair adds "
+                                           "~4 us over rocprofv3's kernel duration)",
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_SLICE * S,
                          "tflops": round(2 * 3 * KS * KS * H * W * S / (conv_ms * 1e-3) / 1e12, 2)},
             "trace": {"kernel": "psf_points_kernel (fused chief-ray centre + ray trace + LDS histogram + normalise)",
                       "us_per_stack": round(psf_ms * 1e3, 2), "ray_surface_steps_per_stack": steps_per_stack,

@@ -45,7 +45,7 @@ for name, sub in (("kernel_stats", "stats"), ("fit_kernel_stats", "fit_stats"), 
     src = one(f"{tag}_{sub}/**/*_kernel_stats.csv")
     if src:
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.csv"))
-for name in ("bench", "bench_fit", "bench_m2"):
+for name in ("bench", "bench_fit", "bench_m2", "bench_2streams", "bench_refocus_overlap"):
     src = os.path.join(G, f"{tag}_{name}.json")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.json"))
