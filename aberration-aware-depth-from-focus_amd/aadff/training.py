@@ -11,7 +11,7 @@ PCIe meanwhile); `aadff_psf_points` then traces the bs target PSFs from the devi
 memcpy, no host synchronisation: the kernels' error flags (NaN residual, no valid chief ray: the reference's asserts)
 are published to a pinned mirror every few batches and polled when the ring wraps.
 
-Optionally (`overlap=True` / AADFF_FIT_OVERLAP=1) the launches go to the plan's own side stream and batch j+1 is produced while the optimisation step of batch j runs (the
+By default (`overlap=False` / AADFF_FIT_OVERLAP=0 turns it off) the launches go to the plan's own side stream and batch j+1 is produced while the optimisation step of batch j runs (the
 step is a chain of small latency-bound kernels on a few CUs; the traces use the rest of the chip): `next()` hands out
 the batch launched by the previous call and - unless told `prefetch=False` - draws and launches the following one.  The
 host draws are the reference's, in the reference's order (nothing else consumes the RNGs between two batches of the fit
@@ -36,10 +36,9 @@ class TrainingDataPlan:
     def __init__(self, net, bs, spp, overlap=None):
         dev = net._gpu()
         if overlap is None:
-            # Off by default: at bs 128 / spp 2048 the fit loop is bound by the HOST side of a batch (draws + ~8 torch CPU ops
-            # + launches, 0.15 ms) once the step runs as aadff_fit_chain; the extra stream bookkeeping then costs more than
-            # the overlap returns (measured 4 810 against 5 000 it/s).  It pays when the traces are the long pole (large spp).
-            overlap = os.environ.get("AADFF_FIT_OVERLAP", "0") == "1"
+            # On by default: with the batch arithmetic in numpy the host needs 0.10 ms per batch and the GPU (traces 60 us +
+            # fit step 137 us back to back) is the limit; side by side they take 0.15 ms (5 070 -> 6 570 it/s).
+            overlap = os.environ.get("AADFF_FIT_OVERLAP", "1") != "0"
         self.side = torch.cuda.Stream(dev) if overlap else None
         self.state = [torch.zeros(C.sizeof(_abi.LensState), dtype=torch.uint8, device=dev) for _ in range(2)]
         self.pending, self.last_slot = None, None
@@ -50,6 +49,7 @@ class TrainingDataPlan:
         self.o_inp = self.o_pts + 3 * self.bs
         self.per = (self.o_inp + 4 * self.bs + 3) // 4 * 4
         self.u_pin = [torch.zeros(self.per, dtype=torch.float32).pin_memory() for _ in range(self.RING)]
+        self.u_np = [t.numpy() for t in self.u_pin]                                  # the same pinned memory as numpy views
         self.u_dev = [torch.zeros(self.per, dtype=torch.float32, device=dev) for _ in range(self.RING)]
         self.psf = [torch.empty((self.bs, self.ks * self.ks), dtype=torch.float32, device=dev) for _ in range(self.RING)]
         self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -122,15 +122,22 @@ class TrainingDataPlan:
         idx = int(np.random.choice(len(self.foc_z32)))          # == np.random.choice(foc_z_arr): one randint either way
         foc_z = self.foc_z32[idx]
         net.sampler.rand_into(pin[:self.o_main])                # refocus: theta, r (surfaces.py:192-193)
-        x = (torch.rand(bs) - 0.5) * 2
-        y = (torch.rand(bs) - 0.5) * 2
-        zg = torch.clamp(torch.randn(bs), min=-3, max=3)
-        # the reference's masked assignments (z = 0 where z_gauss == 0) as selects: the same fp32 operations per element,
-        # a third of the host time of boolean indexing
-        z = torch.where(zg > 0, (1 - foc_z) * zg / 3 + foc_z, torch.where(zg < 0, foc_z * zg / 3 + foc_z, torch.zeros_like(zg)))
+        # x, y, z, depth: torch's generator for the draws (the reference's stream), numpy for the 128-element arithmetic on
+        # them - the same IEEE fp32 operations per element as the reference's tensor expressions (bit-equal, checked over
+        # seeds against both the masked-assignment form and G10), at ~1 us per op instead of ~4
+        f32 = np.float32
+        x = (torch.rand(bs).numpy() - f32(0.5)) * f32(2)
+        y = (torch.rand(bs).numpy() - f32(0.5)) * f32(2)
+        zg = torch.randn(bs).numpy()
+        zg = np.minimum(np.maximum(zg, f32(-3)), f32(3))
+        fz = f32(foc_z)
+        z = np.where(zg > 0, f32(1 - foc_z) * zg / f32(3) + fz, np.where(zg < 0, fz * zg / f32(3) + fz, f32(0))).astype(np.float32)
         net.sampler.rand_into(pin[self.o_main:self.o_pts])      # psf: main theta, main r, chief theta, chief r
-        pin[self.o_pts:self.o_inp].view(bs, 3).copy_(torch.stack((x, y, net.z2depth(z)), dim=-1))
-        pin[self.o_inp:self.o_inp + 4 * bs].view(bs, 4).copy_(torch.stack((x, y, z, torch.full_like(x, foc_z)), dim=-1))
+        blk = self.u_np[k]
+        pts = blk[self.o_pts:self.o_inp].reshape(bs, 3)
+        pts[:, 0], pts[:, 1], pts[:, 2] = x, y, z * f32(net.d_max - net.d_min) + f32(net.d_min)       # z2depth
+        inp = blk[self.o_inp:self.o_inp + 4 * bs].reshape(bs, 4)
+        inp[:, 0], inp[:, 1], inp[:, 2], inp[:, 3] = x, y, z, fz
         # ---- two launches
         dev_blk = self.u_dev[k]
         ub = dev_blk.data_ptr()
