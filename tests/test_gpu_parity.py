@@ -1026,6 +1026,28 @@ def test_fit_kernels_can_be_switched_off(monkeypatch):
     assert _TrainStep(wide, 1e-3, 20, 16, 121, torch.device(DEV), True, True).fused is None      # width 512: torch-GEMM path
 
 
+def test_train_psfnet_bf16_runs_on_the_fit_kernels_end_to_end(repo_root, tmp_path):
+    """Config 4 as the script runs it (1_fit_psfnet.py with bf16): train_psfnet(autocast_bf16=True) takes the hand-written fit
+    step and the one-batch-ahead producer, writes its checkpoints / preview tiles, leaves the module's own parameters updated
+    (state_dict round trip) and the fused inference kernel sees the new weights."""
+    net = PSFNet(lens_path(repo_root), sensor_res=(64, 64), kernel_size=11, device=DEV)
+    net.psfnet.load_state_dict({k: tt(v) for k, v in mlp_state_dict(seed=4321).items()})
+    before = {k: v.detach().clone() for k, v in net.psfnet.state_dict().items()}
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net.train_psfnet(iters=7, bs=16, lr=1e-3, spp=256, evaluate_every=4, result_dir=str(tmp_path), autocast_bf16=True)
+    torch.cuda.synchronize()
+    assert (tmp_path / "iter4.png").exists() and (tmp_path / "iter4_PSFNet_mlp.pkl").exists() and (tmp_path / "PSFNet_mlp.pkl").exists()
+    sd = torch.load(str(tmp_path / "PSFNet_mlp.pkl"), map_location="cpu")
+    moved = [k for k in before if not torch.equal(sd[k], before[k].cpu())]
+    assert len(moved) == len(before)                              # every weight and bias took a step
+    assert all(torch.isfinite(v).all() for v in sd.values())
+    x = tt(np.random.Generator(np.random.PCG64(5)).random((50, 4), dtype=np.float32)).to(DEV)
+    with torch.no_grad():
+        assert (net.pred(x) - net.psfnet(x).reshape(50, 11, 11)).abs().max().item() <= 2e-7
+    assert net._training_plan(16, 256).pending is None          # the last iteration did not draw a batch it would not use
+
+
 def test_fused_inference_sees_weights_after_graph_training(repo_root, tmp_path):
     """The packed weights of the fused kernel are rebuilt after train_psfnet (graph replays do not bump tensor versions)."""
     net = PSFNet(lens_path(repo_root), sensor_res=(64, 64), kernel_size=11, device=DEV)
