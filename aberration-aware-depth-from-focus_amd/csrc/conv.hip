@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <type_traits>
+#include <hip/hip_ext.h>
 #include "common.h"
 
 namespace aadff {
@@ -736,6 +737,10 @@ __global__ __launch_bounds__(256) void conv_psf_map_generic_kernel(const float* 
     }
 }
 
+// events handed over by aadff_render_psf_map_stack_timed for the launch made on this host thread (consumed by the
+// slice-batched launch; any other path leaves them for the entry point to record around the call)
+static thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
+
 template <int KS>
 static int launch_fast(const float* img, const float* psf, float* out, int B, int C, int S, int H, int W,
                        int grid, int ntx, int nty, const PatchBounds& pb, hipStream_t st) {
@@ -778,7 +783,12 @@ static int launch_fast(const float* img, const float* psf, float* out, int B, in
             pbs.m_ntx = magic_of(sntx); pbs.m_nty = magic_of(snty); pbs.m_nchunk = magic_of(npass); pbs.m_c = magic_of(C);
             dim3 gs(sntx * grid, snty * grid, B * C * npass);
             static const int stagger = [] { const char* e = getenv("AADFF_CONV_STAGGER"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 64 ? 64 : v); }();   // default 1: -1 % in bench, -7 % back to back
-#define AADFF_LAUNCH_S(NCV) hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV>), gs, dim3(64 * NCV), 0, st, img, psf, out, C, S, H, W, grid, sntx, snty, npass, pbs, stagger)
+            // aadff_render_psf_map_stack_timed: the two events ride ON this dispatch (kernel begin / end timestamps)
+            hipEvent_t ev0 = g_time_start, ev1 = g_time_stop;
+            g_time_start = g_time_stop = nullptr;
+#define AADFF_LAUNCH_S(NCV) do { \
+                if (ev0) hipExtLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV>), gs, dim3(64 * NCV), 0, st, ev0, ev1, 0, img, psf, out, C, S, H, W, grid, sntx, snty, npass, pbs, stagger); \
+                else hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV>), gs, dim3(64 * NCV), 0, st, img, psf, out, C, S, H, W, grid, sntx, snty, npass, pbs, stagger); } while (0)
             switch (nc) {
                 case 1: AADFF_LAUNCH_S(1); break;
                 case 2: AADFF_LAUNCH_S(2); break;
@@ -1190,6 +1200,24 @@ int aadff_render_psf_map(const float* img, const float* psf_map, float* out, int
 int aadff_render_psf_map_stack(const float* img, const float* psf_maps, float* out, int B, int C, int S, int H,
                                int W, int grid, int ks, aadff_stream_t stream) {
     return conv_dispatch(img, psf_maps, out, B, C, S, H, W, grid, ks, (hipStream_t)stream);
+}
+
+int aadff_render_psf_map_stack_timed(const float* img, const float* psf_maps, float* out, int B, int C, int S, int H, int W,
+                                     int grid, int ks, void* start_event, void* stop_event, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(start_event && stop_event, "render_psf_map_stack_timed: NULL event");
+    g_time_start = (hipEvent_t)start_event;
+    g_time_stop = (hipEvent_t)stop_event;
+    hipStream_t st = (hipStream_t)stream;
+    // paths other than the slice-batched kernel do not consume the events: bracket the call instead
+    const bool sbatch = ks == 11 && S >= 3 && !getenv("AADFF_CONV_PATH");
+    if (!sbatch) {
+        g_time_start = g_time_stop = nullptr;
+        AADFF_CHECK_HIP(hipEventRecord((hipEvent_t)start_event, st));
+    }
+    const int rc = conv_dispatch(img, psf_maps, out, B, C, S, H, W, grid, ks, st);
+    g_time_start = g_time_stop = nullptr;
+    if (!sbatch && rc == 0) AADFF_CHECK_HIP(hipEventRecord((hipEvent_t)stop_event, st));
+    return rc;
 }
 
 int aadff_render_psf(const float* img, const float* psf, float* out, int B, int C, int H, int W, int ks,

@@ -110,6 +110,13 @@ int aadff_render_psf_map(const float* img, const float* psf_map, float* out,
 int aadff_render_psf_map_stack(const float* img, const float* psf_maps, float* out,
                                int B, int C, int S, int H, int W, int grid, int ks,
                                aadff_stream_t stream);
+/* Measurement aid for aadff_render_psf_map_stack: the same call, with two HIP events (hipEvent_t created with timing
+ * enabled) attached to the dispatch of the slice-batched kernel (hipExtLaunchKernelGGL), so that hipEventElapsedTime gives
+ * the kernel's own begin-to-end time - what rocprofv3 reports - instead of the bracket of two stream events, which adds the
+ * two dispatch gaps (~4 us).  Paths that do not run the slice-batched kernel (S < 3, ks != 11, AADFF_CONV_PATH set) record
+ * the events around the call. */
+int aadff_render_psf_map_stack_timed(const float* img, const float* psf_maps, float* out, int B, int C, int S, int H, int W,
+                                     int grid, int ks, void* start_event, void* stop_event, aadff_stream_t stream);
 
 /* One PSF for the whole image.  Replaces render_psf, deeplens/render_psf.py:12-28.
  * psf [C,ks,ks]. */
