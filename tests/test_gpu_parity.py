@@ -1175,6 +1175,45 @@ def test_staged_upload_late_block_is_read_from_pinned_memory(repo_root, monkeypa
             raise_psf_flags(bits[True])
 
 
+def test_timed_stack_convolution_entry_is_the_same_launch():
+    """aadff_render_psf_map_stack_timed (bench.py's roofline block): identical pixels to the plain entry, and the two HIP
+    events attached to the dispatch give a positive kernel time no longer than the bracket of two stream events; the
+    single-slice path (no slice-batched kernel) falls back to recording the events around the call."""
+    hip = C.CDLL("libamdhip64.so")
+
+    def event():
+        e = C.c_void_p()
+        assert hip.hipEventCreate(C.byref(e)) == 0
+        return e
+
+    def elapsed(a, b):
+        ms = C.c_float()
+        assert hip.hipEventSynchronize(b) == 0 and hip.hipEventElapsedTime(C.byref(ms), a, b) == 0
+        return ms.value
+
+    H = W = 256
+    rng = np.random.Generator(np.random.PCG64(21))
+    img = tt(synth_rgb(H, W))[None].to(DEV)
+    st = _abi.stream_ptr(torch.device(DEV))
+    for S in (10, 1):
+        maps = tt(rng.random((S, 3, 55, 55), dtype=np.float32)).to(DEV) / 121
+        a, b = torch.empty((1, 3, S, H, W), device=DEV), torch.empty((1, 3, S, H, W), device=DEV)
+        _abi.call("aadff_render_psf_map_stack", _abi.ptr(img), _abi.ptr(maps), _abi.ptr(a), 1, 3, S, H, W, 5, 11, st)
+        e0, e1 = event(), event()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            t0.record()
+            _abi.call("aadff_render_psf_map_stack_timed", _abi.ptr(img), _abi.ptr(maps), _abi.ptr(b), 1, 3, S, H, W, 5, 11, e0, e1, st)
+            t1.record()
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        kernel_ms, bracket_ms = elapsed(e0, e1), t0.elapsed_time(t1)
+        assert 0 < kernel_ms <= bracket_ms + 2e-3, (S, kernel_ms, bracket_ms)
+        assert hip.hipEventDestroy(e0) == 0 and hip.hipEventDestroy(e1) == 0
+    with pytest.raises(RuntimeError, match="NULL event"):
+        _abi.call("aadff_render_psf_map_stack_timed", _abi.ptr(img), _abi.ptr(maps), _abi.ptr(b), 1, 3, 1, H, W, 5, 11, None, None, st)
+
+
 def _render_steps(repo_root, make, steps, consume):
     from aadff import focal_stack as fs
     H = W = 64
