@@ -105,6 +105,7 @@ class StackPlan:
         self.pts_xy = lens.point_source_grid(depth=0.0, grid=grid).reshape(-1, 3)
         self.conv_events = None      # optional (start, end) torch.cuda.Event pair around the conv launch
         self.conv_kernel_events = None   # optional (start, stop) raw hipEvent_t handles attached to the conv dispatch itself
+        self.psf_kernel_events = None    # likewise for the PSF-grid kernel (aadff_time_next_launch)
         self.psf_events = None       # optional (start, end) pair around the fused trace/PSF launch
         self.per, self.o_main, self.o_chief, self.per_l = stack_uniform_layout(spp)
         self.u_dev = [torch.empty(S * self.per, dtype=torch.float32, device=dev) for _ in range(self.RING)]
@@ -255,6 +256,8 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
                                plan.stage_counters.data_ptr())
         if plan.psf_events is not None:
             plan.psf_events[0].record()
+        if plan.psf_kernel_events is not None:
+            _abi.call("aadff_time_next_launch", plan.psf_kernel_events[0], plan.psf_kernel_events[1])
         if stage is None:
             _abi.call("aadff_psf_points", _abi.ptr(pts), S, N, 3, _abi.ptr(plan.tab_rgb), _abi.ptr(plan.tab_green),
                       plan.lc, _abi.ptr(plan.states), C.c_void_p(ub + 4 * plan.o_main), spp, plan.per, plan.per_l,
@@ -270,11 +273,9 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
         if plan.conv_events is not None:
             plan.conv_events[0].record()
         if plan.conv_kernel_events is not None:
-            _abi.call("aadff_render_psf_map_stack_timed", _abi.ptr(x), _abi.ptr(plan.psf_maps), _abi.ptr(plan.out), B, C_, S,
-                      H, W, grid, ks, plan.conv_kernel_events[0], plan.conv_kernel_events[1], st)
-        else:
-            _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(plan.psf_maps), _abi.ptr(plan.out), B, C_, S,
-                      H, W, grid, ks, st)
+            _abi.call("aadff_time_next_launch", plan.conv_kernel_events[0], plan.conv_kernel_events[1])
+        _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(plan.psf_maps), _abi.ptr(plan.out), B, C_, S,
+                  H, W, grid, ks, st)
         if plan.conv_events is not None:
             plan.conv_events[1].record()
         if stage is not None:

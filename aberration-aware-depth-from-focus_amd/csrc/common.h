@@ -30,6 +30,9 @@ void set_error(const char* fmt, ...);
 
 constexpr int kWave = 64;   // gfx950 wavefront
 
+// armed by aadff_time_next_launch, consumed (and cleared) by the next slice-batched convolution or PSF-grid launch of the thread
+extern thread_local hipEvent_t g_time_start, g_time_stop;
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);

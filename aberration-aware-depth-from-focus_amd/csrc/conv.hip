@@ -737,9 +737,8 @@ __global__ __launch_bounds__(256) void conv_psf_map_generic_kernel(const float* 
     }
 }
 
-// events handed over by aadff_render_psf_map_stack_timed for the launch made on this host thread (consumed by the
-// slice-batched launch; any other path leaves them for the entry point to record around the call)
-static thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
+// events armed by aadff_time_next_launch for the next stack-convolution / PSF-grid launch of this host thread (common.h)
+thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
 
 template <int KS>
 static int launch_fast(const float* img, const float* psf, float* out, int B, int C, int S, int H, int W,
@@ -783,7 +782,7 @@ static int launch_fast(const float* img, const float* psf, float* out, int B, in
             pbs.m_ntx = magic_of(sntx); pbs.m_nty = magic_of(snty); pbs.m_nchunk = magic_of(npass); pbs.m_c = magic_of(C);
             dim3 gs(sntx * grid, snty * grid, B * C * npass);
             static const int stagger = [] { const char* e = getenv("AADFF_CONV_STAGGER"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 64 ? 64 : v); }();   // default 1: -1 % in bench, -7 % back to back
-            // aadff_render_psf_map_stack_timed: the two events ride ON this dispatch (kernel begin / end timestamps)
+            // aadff_time_next_launch: the two events ride ON this dispatch (kernel begin / end timestamps)
             hipEvent_t ev0 = g_time_start, ev1 = g_time_stop;
             g_time_start = g_time_stop = nullptr;
 #define AADFF_LAUNCH_S(NCV) do { \
@@ -1199,25 +1198,26 @@ int aadff_render_psf_map(const float* img, const float* psf_map, float* out, int
 
 int aadff_render_psf_map_stack(const float* img, const float* psf_maps, float* out, int B, int C, int S, int H,
                                int W, int grid, int ks, aadff_stream_t stream) {
-    return conv_dispatch(img, psf_maps, out, B, C, S, H, W, grid, ks, (hipStream_t)stream);
-}
-
-int aadff_render_psf_map_stack_timed(const float* img, const float* psf_maps, float* out, int B, int C, int S, int H, int W,
-                                     int grid, int ks, void* start_event, void* stop_event, aadff_stream_t stream) {
-    AADFF_CHECK_ARG(start_event && stop_event, "render_psf_map_stack_timed: NULL event");
-    g_time_start = (hipEvent_t)start_event;
-    g_time_stop = (hipEvent_t)stop_event;
     hipStream_t st = (hipStream_t)stream;
-    // paths other than the slice-batched kernel do not consume the events: bracket the call instead
-    const bool sbatch = ks == 11 && S >= 3 && !getenv("AADFF_CONV_PATH");
-    if (!sbatch) {
+    hipEvent_t e0 = g_time_start, e1 = g_time_stop;
+    // armed by aadff_time_next_launch: the slice-batched launch attaches the events to its dispatch; every other path
+    // records them around the call
+    const bool bracket = e0 && !(ks == 11 && S >= 3 && !getenv("AADFF_CONV_PATH"));
+    if (bracket) {
         g_time_start = g_time_stop = nullptr;
-        AADFF_CHECK_HIP(hipEventRecord((hipEvent_t)start_event, st));
+        AADFF_CHECK_HIP(hipEventRecord(e0, st));
     }
     const int rc = conv_dispatch(img, psf_maps, out, B, C, S, H, W, grid, ks, st);
     g_time_start = g_time_stop = nullptr;
-    if (!sbatch && rc == 0) AADFF_CHECK_HIP(hipEventRecord((hipEvent_t)stop_event, st));
+    if (bracket && rc == 0) AADFF_CHECK_HIP(hipEventRecord(e1, st));
     return rc;
+}
+
+int aadff_time_next_launch(void* start_event, void* stop_event) {
+    AADFF_CHECK_ARG((start_event == nullptr) == (stop_event == nullptr), "time_next_launch: give both events or neither");
+    g_time_start = (hipEvent_t)start_event;
+    g_time_stop = (hipEvent_t)stop_event;
+    return 0;
 }
 
 int aadff_render_psf(const float* img, const float* psf, float* out, int B, int C, int H, int W, int ks,

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <hip/hip_ext.h>
 #include "common.h"
 
 namespace aadff {
@@ -1282,10 +1283,18 @@ static int psf_points_launch(const float* points, int S, int N, int L, const aad
         AADFF_CHECK_ARG(u_main >= lo && u_main < hi && (!u_chief || (u_chief >= lo && u_chief < hi)),
                         "psf_points_staged: u_main/u_chief must point into dst_dev[0 .. S*slice_stride)");
     }
-    hipLaunchKernelGGL(psf_points_kernel, dim3(N, L, sa.src ? S + 1 : S), dim3(kPsfThreads), (size_t)ks * ks * sizeof(float), (hipStream_t)stream, points, N, L, surf_main,
-                       surf_chief, lc, states, u_main, spp, main_stride_s, main_stride_l, u_chief, spp_chief, chief_stride_s,
-                       chief_stride_l, make_splat_geom(lc.pixel_size, ks),
-                       centre_mode, map_grid, psf, centre_out_or_null, flags_or_null, sa);
+    hipEvent_t ev0 = g_time_start, ev1 = g_time_stop;                    // aadff_time_next_launch
+    g_time_start = g_time_stop = nullptr;
+    if (ev0)
+        hipExtLaunchKernelGGL(psf_points_kernel, dim3(N, L, sa.src ? S + 1 : S), dim3(kPsfThreads), (size_t)ks * ks * sizeof(float), (hipStream_t)stream,
+                              ev0, ev1, 0, points, N, L, surf_main, surf_chief, lc, states, u_main, spp, main_stride_s, main_stride_l, u_chief,
+                              spp_chief, chief_stride_s, chief_stride_l, make_splat_geom(lc.pixel_size, ks), centre_mode, map_grid, psf,
+                              centre_out_or_null, flags_or_null, sa);
+    else
+        hipLaunchKernelGGL(psf_points_kernel, dim3(N, L, sa.src ? S + 1 : S), dim3(kPsfThreads), (size_t)ks * ks * sizeof(float), (hipStream_t)stream, points, N, L, surf_main,
+                           surf_chief, lc, states, u_main, spp, main_stride_s, main_stride_l, u_chief, spp_chief, chief_stride_s,
+                           chief_stride_l, make_splat_geom(lc.pixel_size, ks),
+                           centre_mode, map_grid, psf, centre_out_or_null, flags_or_null, sa);
     AADFF_CHECK_LAUNCH();
     return 0;
 }

@@ -152,7 +152,7 @@ def main():
     pipe = StackPipeline(lens, S, H, W, 1, 3, GRID, KS, SPP, depth=n_streams)
     plan = pipe.plans[0]
     # On every `--conv-events-every`-th timed step the convolution kernel carries two HIP events ON its dispatch
-    # (aadff_render_psf_map_stack_timed -> hipExtLaunchKernelGGL): the kernel's own begin-to-end time on its launch stream,
+    # (aadff_time_next_launch -> hipExtLaunchKernelGGL): the kernel's own begin-to-end time on its launch stream,
     # the quantity rocprofv3 reports.  On the steps half-way between, two stream events BRACKET the launch instead (the round-1
     # method: adds the two dispatch gaps); reported beside it.
     import ctypes as C_
@@ -242,15 +242,15 @@ def main():
         torch.cuda.synchronize(dev)
         lat.append(time.perf_counter() - t1)
     # ---- untimed: the fused trace/PSF kernel bracketed by HIP events on its own launch stream
-    pev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    pev = [(hip_event(), hip_event()) for _ in range(20)]
     for i, e in enumerate(pev):
         torch.cuda.synchronize(dev)                                   # alone on the device: the kernel's own duration
         cur = pipe.plans[pipe.turn % pipe.depth]
-        cur.psf_events = e
+        cur.psf_kernel_events = e
         step(i)
-        cur.psf_events = None
+        cur.psf_kernel_events = None
     torch.cuda.synchronize(dev)
-    psf_ms = float(np.median([a.elapsed_time(b) for a, b in pev]))
+    psf_ms = float(np.median([hip_elapsed_ms(a, b) for a, b in pev]))
     # ---- untimed: the pixels of a seed-0 step for the parity block
     torch.cuda.synchronize(dev)
     out0 = step(0)

@@ -110,13 +110,12 @@ int aadff_render_psf_map(const float* img, const float* psf_map, float* out,
 int aadff_render_psf_map_stack(const float* img, const float* psf_maps, float* out,
                                int B, int C, int S, int H, int W, int grid, int ks,
                                aadff_stream_t stream);
-/* Measurement aid for aadff_render_psf_map_stack: the same call, with two HIP events (hipEvent_t created with timing
- * enabled) attached to the dispatch of the slice-batched kernel (hipExtLaunchKernelGGL), so that hipEventElapsedTime gives
+/* Measurement aid (no reference counterpart): arm the NEXT aadff_render_psf_map_stack (slice-batched kernel: ks 11, S >= 3)
+ * or aadff_psf_points / aadff_psf_points_staged call made by this host thread so that its kernel is launched with the two
+ * HIP events (hipEvent_t, timing enabled) attached to the dispatch (hipExtLaunchKernelGGL): hipEventElapsedTime then gives
  * the kernel's own begin-to-end time - what rocprofv3 reports - instead of the bracket of two stream events, which adds the
- * two dispatch gaps (~4 us).  Paths that do not run the slice-batched kernel (S < 3, ks != 11, AADFF_CONV_PATH set) record
- * the events around the call. */
-int aadff_render_psf_map_stack_timed(const float* img, const float* psf_maps, float* out, int B, int C, int S, int H, int W,
-                                     int grid, int ks, void* start_event, void* stop_event, aadff_stream_t stream);
+ * dispatch gaps (~2-4 us).  NULL, NULL disarms.  Other launches ignore it. */
+int aadff_time_next_launch(void* start_event, void* stop_event);
 
 /* One PSF for the whole image.  Replaces render_psf, deeplens/render_psf.py:12-28.
  * psf [C,ks,ks]. */

@@ -1175,10 +1175,10 @@ def test_staged_upload_late_block_is_read_from_pinned_memory(repo_root, monkeypa
             raise_psf_flags(bits[True])
 
 
-def test_timed_stack_convolution_entry_is_the_same_launch():
-    """aadff_render_psf_map_stack_timed (bench.py's roofline block): identical pixels to the plain entry, and the two HIP
-    events attached to the dispatch give a positive kernel time no longer than the bracket of two stream events; the
-    single-slice path (no slice-batched kernel) falls back to recording the events around the call."""
+def test_time_next_launch_attaches_events_to_the_kernel():
+    """aadff_time_next_launch (bench.py's roofline / trace blocks): the armed call produces identical results, the two HIP
+    events attached to the dispatch give a positive kernel time no longer than the bracket of two stream events, the arming
+    is consumed by exactly one launch; the single-slice convolution (no slice-batched kernel) records the events around the call."""
     hip = C.CDLL("libamdhip64.so")
 
     def event():
@@ -1201,17 +1201,32 @@ def test_timed_stack_convolution_entry_is_the_same_launch():
         _abi.call("aadff_render_psf_map_stack", _abi.ptr(img), _abi.ptr(maps), _abi.ptr(a), 1, 3, S, H, W, 5, 11, st)
         e0, e1 = event(), event()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(3):
-            t0.record()
-            _abi.call("aadff_render_psf_map_stack_timed", _abi.ptr(img), _abi.ptr(maps), _abi.ptr(b), 1, 3, S, H, W, 5, 11, e0, e1, st)
-            t1.record()
+        t0.record()
+        _abi.call("aadff_time_next_launch", e0, e1)
+        _abi.call("aadff_render_psf_map_stack", _abi.ptr(img), _abi.ptr(maps), _abi.ptr(b), 1, 3, S, H, W, 5, 11, st)
+        t1.record()
         torch.cuda.synchronize()
         assert torch.equal(a, b)
         kernel_ms, bracket_ms = elapsed(e0, e1), t0.elapsed_time(t1)
         assert 0 < kernel_ms <= bracket_ms + 2e-3, (S, kernel_ms, bracket_ms)
+        # consumed: an unarmed call leaves the events alone
+        _abi.call("aadff_render_psf_map_stack", _abi.ptr(img), _abi.ptr(maps), _abi.ptr(b), 1, 3, S, H, W, 5, 11, st)
+        torch.cuda.synchronize()
+        assert elapsed(e0, e1) == kernel_ms
         assert hip.hipEventDestroy(e0) == 0 and hip.hipEventDestroy(e1) == 0
-    with pytest.raises(RuntimeError, match="NULL event"):
-        _abi.call("aadff_render_psf_map_stack_timed", _abi.ptr(img), _abi.ptr(maps), _abi.ptr(b), 1, 3, 1, H, W, 5, 11, None, None, st)
+    with pytest.raises(RuntimeError, match="both events or neither"):
+        _abi.call("aadff_time_next_launch", event(), None)
+    # the PSF-grid kernel: same PSFs with and without the events
+    lens = Lensgroup(lens_path(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), sensor_res=(128, 128), device=DEV)
+    pts = torch.tensor([[0.0, 0.0, -1500.0], [0.5, -0.3, -1500.0]])
+    torch.manual_seed(3)
+    want = lens.psf(pts, ks=11, spp=512)
+    e0, e1 = event(), event()
+    torch.manual_seed(3)
+    _abi.call("aadff_time_next_launch", e0, e1)
+    got = lens.psf(pts, ks=11, spp=512)
+    torch.cuda.synchronize()
+    assert rel_l2(got.cpu().numpy(), want.cpu().numpy()) <= 1e-5 and 0 < elapsed(e0, e1) < 50.0
 
 
 def _render_steps(repo_root, make, steps, consume):
