@@ -104,8 +104,10 @@ class StackPlan:
         self.lc = lens._lens_const()
         self.pts_xy = lens.point_source_grid(depth=0.0, grid=grid).reshape(-1, 3)
         self.conv_events = None      # optional (start, end) torch.cuda.Event pair around the conv launch
-        self.conv_kernel_events = None   # optional (start, stop) raw hipEvent_t handles attached to the conv dispatch itself
-        self.psf_kernel_events = None    # likewise for the PSF-grid kernel (aadff_time_next_launch)
+        # optional (start, stop) torch.cuda.Event pairs (enable_timing=True, recorded once so that their HIP events exist)
+        # to be ATTACHED to the dispatch of the conv / PSF-grid kernel (aadff_time_next_launch): the kernel's own time
+        self.conv_kernel_events = None
+        self.psf_kernel_events = None
         self.psf_events = None       # optional (start, end) pair around the fused trace/PSF launch
         self.per, self.o_main, self.o_chief, self.per_l = stack_uniform_layout(spp)
         self.u_dev = [torch.empty(S * self.per, dtype=torch.float32, device=dev) for _ in range(self.RING)]
@@ -257,7 +259,7 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
         if plan.psf_events is not None:
             plan.psf_events[0].record()
         if plan.psf_kernel_events is not None:
-            _abi.call("aadff_time_next_launch", plan.psf_kernel_events[0], plan.psf_kernel_events[1])
+            _abi.call("aadff_time_next_launch", C.c_void_p(plan.psf_kernel_events[0].cuda_event), C.c_void_p(plan.psf_kernel_events[1].cuda_event))
         if stage is None:
             _abi.call("aadff_psf_points", _abi.ptr(pts), S, N, 3, _abi.ptr(plan.tab_rgb), _abi.ptr(plan.tab_green),
                       plan.lc, _abi.ptr(plan.states), C.c_void_p(ub + 4 * plan.o_main), spp, plan.per, plan.per_l,
@@ -272,8 +274,9 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
             plan.psf_events[1].record()
         if plan.conv_events is not None:
             plan.conv_events[0].record()
-        if plan.conv_kernel_events is not None:
-            _abi.call("aadff_time_next_launch", plan.conv_kernel_events[0], plan.conv_kernel_events[1])
+        kev = plan.conv_kernel_events
+        if kev is not None:
+            _abi.call("aadff_time_next_launch", C.c_void_p(kev[0].cuda_event), C.c_void_p(kev[1].cuda_event))
         _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(plan.psf_maps), _abi.ptr(plan.out), B, C_, S,
                   H, W, grid, ks, st)
         if plan.conv_events is not None:

@@ -155,20 +155,14 @@ def main():
     # (aadff_time_next_launch -> hipExtLaunchKernelGGL): the kernel's own begin-to-end time on its launch stream,
     # the quantity rocprofv3 reports.  On the steps half-way between, two stream events BRACKET the launch instead (the round-1
     # method: adds the two dispatch gaps); reported beside it.
-    import ctypes as C_
-    hip = C_.CDLL("libamdhip64.so")
-
     def hip_event():
-        e = C_.c_void_p()
-        if hip.hipEventCreate(C_.byref(e)) != 0:
-            raise SystemExit("bench: hipEventCreate failed")
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()                                   # creates the HIP event behind it (its handle goes to the launch)
         return e
 
     def hip_elapsed_ms(a, b):
-        ms = C_.c_float()
-        if hip.hipEventSynchronize(b) != 0 or hip.hipEventElapsedTime(C_.byref(ms), a, b) != 0:
-            raise SystemExit("bench: hipEventElapsedTime failed")
-        return float(ms.value)
+        b.synchronize()
+        return float(a.elapsed_time(b))
 
     every = max(1, args.conv_events_every)
     kev = {i: (hip_event(), hip_event()) for i in range(0, args.steps, every)}
