@@ -137,6 +137,25 @@ def test_render_psf_map_stack_slice_batched_path_vs_oracle(B, H, W, g, S):
         assert np.abs(got[:, :, s] - want).max() <= 4e-6 * 40, f"slice {s}"
 
 
+@pytest.mark.parametrize("Cn", [1, 2, 4, 6])
+def test_channel_counts_other_than_three_vs_oracle(Cn):
+    """The reference's functions are channel-generic (depthwise conv2d with groups = C; the gather stacks the kernel C
+    times): grey images, pairs, RGBA and 6 planes through the single-slice conv, the slice-batched stack conv and the
+    per-pixel gather (compile-time channel paths exist for C = 1 and 3 only; the rest take the runtime-C code)."""
+    rng = np.random.Generator(np.random.PCG64(100 + Cn))
+    B, H, W, g, ks, S = 2, 61, 83, 3, 11, 5
+    img = tt(rng.random((B, Cn, H, W), dtype=np.float32))
+    maps = tt(rng.random((S, Cn, g * ks, g * ks), dtype=np.float32)) / (ks * ks)
+    got1 = rp.render_psf_map(img.to(DEV), maps[0].to(DEV), g).cpu().numpy()
+    assert np.abs(got1 - oconv.render_psf_map(img, maps[0], g).numpy()).max() <= 4e-6
+    gots = rp.render_psf_map_stack(img.to(DEV), maps.to(DEV), g).cpu().numpy()
+    for s in range(S):
+        assert np.abs(gots[:, :, s] - oconv.render_psf_map(img, maps[s], g).numpy()).max() <= 4e-6, s
+    psf = tt(rng.random((B, H, W, ks, ks), dtype=np.float32)) / (ks * ks)
+    gotl = rp.local_psf_render(img.to(DEV), psf.to(DEV), ks).cpu().numpy()
+    assert np.abs(gotl - oconv.local_psf_render(img, psf, ks).numpy()).max() <= 4e-6
+
+
 def test_render_psf_map_1024_golden_crops(golden_dir):
     g = np.load(os.path.join(golden_dir, "g5_conv_1024.npz"))
     img = tt(synth_rgb(1024, 1024))[None].to(DEV)
