@@ -14,6 +14,12 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Watchdogs outside the per-test timeout (pytest.ini): a run of this suite takes 1-5 minutes; one that is still alive
+    # after 30 dumps every thread's stack and exits instead of hanging the caller (seen three times in this container
+    # with the output piped: no test was running, the process simply never ended).
+    import faulthandler
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(1800, exit=True)
     # The oracle is torch on the CPU.  The GPU box shows 256 logical CPUs under a 16-CPU quota and this container 8: an
     # OpenMP pool sized by the logical count stalls small ops (and has been seen to wedge a run), so size it by what is usable.
     try:
@@ -51,6 +57,27 @@ def margin():
         _MARGINS.append((name, float(value), float(tol)))
         assert value <= tol, f"{name}: {value:.3e} exceeds {tol:.1e}"
     return record
+
+
+_STATUS = {"exit": 0}
+
+
+def pytest_sessionfinish(session, exitstatus):
+    _STATUS["exit"] = int(exitstatus)
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_unconfigure(config):
+    # Everything is reported and pytest's own clean-up (tmp_path, capture) has run.  Leave without interpreter finalisation:
+    # that is where worker processes, native thread pools and process groups can wedge a run whose tests all passed, and
+    # nothing in this suite registers exit handlers it needs.
+    import faulthandler
+    faulthandler.cancel_dump_traceback_later()
+    if os.environ.get("AADFF_TEST_NORMAL_EXIT", "0") == "1":
+        return
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(_STATUS["exit"])
 
 
 def pytest_terminal_summary(terminalreporter):
