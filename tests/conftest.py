@@ -68,13 +68,19 @@ def pytest_sessionfinish(session, exitstatus):
 
 @pytest.hookimpl(trylast=True)
 def pytest_unconfigure(config):
-    # Everything is reported and pytest's own clean-up (tmp_path, capture) has run.  Leave without interpreter finalisation:
-    # that is where worker processes, native thread pools and process groups can wedge a run whose tests all passed, and
-    # nothing in this suite registers exit handlers it needs.
+    # Everything is reported and pytest's own clean-up (tmp_path, capture) has run.  Python-level exit handlers still run
+    # (whatever the caller registered with atexit included), then the process leaves WITHOUT the native finalisation
+    # (destructors of the OpenMP / HIP runtimes, thread pools): that is where a run whose tests had all passed has wedged.
+    # A C-level watchdog covers the exit handlers themselves.
+    import atexit
     import faulthandler
     faulthandler.cancel_dump_traceback_later()
     if os.environ.get("AADFF_TEST_NORMAL_EXIT", "0") == "1":
         return
+    faulthandler.dump_traceback_later(120, exit=True)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    atexit._run_exitfuncs()
     sys.stdout.flush()
     sys.stderr.flush()
     os._exit(_STATUS["exit"])
