@@ -171,8 +171,40 @@ class FusedFit:
         self.grad.zero_()
         return g, self.pred.clone()
 
+    MAX_BOUND = 16            # graphs kept for distinct (inp, psf) buffer pairs (a producer ring has 8)
+
+    def _direct(self, inp, psf):
+        """(inp, psf) can be read in place by the chain kernel: fp32, contiguous, on this device, of the step's shapes."""
+        ok = lambda t, shape: (t.is_cuda and t.device == self.dev and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape)
+        return self.chain and ok(inp, (self.bs, self.K[0])) and ok(psf, (self.bs, self.N[-1]))
+
     def __call__(self, inp, psf):
-        """One optimisation step on (inp [B,4], psf [B,ks*ks]); returns the network's prediction for the batch."""
+        """One optimisation step on (inp [B,4], psf [B,ks*ks]); returns the network's prediction for the batch.
+        Batches that arrive in a small set of recurring device buffers (the producer's ring: aadff/training.py) are read IN
+        PLACE: one captured graph per buffer pair, no copies into static inputs (two launches and ~16 us of host time less)."""
+        key = (inp.data_ptr(), psf.data_ptr()) if self._direct(inp, psf) else None
+        bound = getattr(self, "bound", None)
+        if bound is None:
+            bound = self.bound = {}
+        if key is not None and self.t >= 2 and (key in bound or len(bound) < self.MAX_BOUND):
+            with torch.cuda.device(self.dev):
+                g = bound.get(key)
+                if g is None:
+                    desc = _abi.FitNet()
+                    C.memmove(C.byref(desc), C.byref(self.net_desc), C.sizeof(desc))
+                    desc.inp, desc.target = key
+                    saved, self.net_desc = self.net_desc, desc
+                    try:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=self.side):
+                            self._body()
+                    finally:
+                        self.net_desc = saved
+                    bound[key] = (g, desc, inp, psf)                   # keep the descriptor and the buffers alive
+                    g = bound[key]
+                g[0].replay()
+            self.t += 1
+            return self.pred
         self.inp.copy_(inp)
         self.psf.copy_(psf)
         with torch.cuda.device(self.dev):

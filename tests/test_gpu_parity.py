@@ -1024,7 +1024,8 @@ def test_fit_kernels_follow_torch_adamw_and_cosine_schedule(chain, monkeypatch):
         opt.step()
         sch.step()
     torch.cuda.synchronize()
-    assert step.fused.graph is not None and int(step.fused.step_dev.item()) == 20 and last < first
+    assert (step.fused.graph is not None or len(step.fused.bound) == 4) and int(step.fused.step_dev.item()) == 20 and last < first
+    assert (len(step.fused.bound) == 4) == (chain == "1")           # chain form: the four recurring batches are read in place
     for (k, a), b in zip(net.state_dict().items(), ref.state_dict().values()):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 2e-2, k
     with torch.no_grad():                                       # the bf16 operand copies follow the fp32 master parameters
