@@ -166,31 +166,30 @@ __host__ __device__ inline int chain_width(const aadff_fit_net& a, int l) { retu
 // loads and stores in one in-order counter, so loads issued after the stores could not be waited for without the stores.
 struct ChainFrag { uint4v a0[8], a1[8]; uint2 bias0, bias1; };     // + the forward pass's bias values of the two tiles
 
-__device__ __forceinline__ void chain_load(ChainFrag& f, const uint16_t* M, int rows, int ld, int wave, int lo4, int kg) {
-    const uint16_t* pa0 = M + (size_t)min(wave * 16 + lo4, rows - 1) * ld;
-    const uint16_t* pa1 = M + (size_t)min((wave + kChainWaves) * 16 + lo4, rows - 1) * ld;
+// M is stored in MFMA fragment order: [tile][k-step][lane] x 16 bytes (zero padded to whole tiles / k-steps), so one
+// wave-instruction reads 1 KiB of contiguous memory: a workgroup streams every weight once per step, and one CU takes in
+// 66 GB/s this way against 35 GB/s from the rows of a row-major matrix (tools/cu_stream_probe.hip, cold caches).
+__device__ __forceinline__ void chain_load(ChainFrag& f, const uint16_t* M, int ntiles, int ksteps, int wave, int lane) {
+    const uint4v* m0 = reinterpret_cast<const uint4v*>(M) + (size_t)min(wave, ntiles - 1) * ksteps * 64 + lane;
+    const uint4v* m1 = reinterpret_cast<const uint4v*>(M) + (size_t)min(wave + kChainWaves, ntiles - 1) * ksteps * 64 + lane;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const int c = 32 * s + 8 * kg, ca = c + 8 <= ld ? c : 0;       // columns past the leading dimension: masked in chain_mma
-        f.a0[s] = *reinterpret_cast<const uint4v*>(pa0 + ca);
-        f.a1[s] = *reinterpret_cast<const uint4v*>(pa1 + ca);
+        const int ss = min(s, ksteps - 1);                               // steps past the contraction re-read the last one; never used
+        f.a0[s] = m0[ss * 64];
+        f.a1[s] = m1[ss * 64];
     }
 }
 
 // acc{0,1} = A{0,1}[feat][c] . B[row][c] over the contraction, B rows from LDS (pitch pb).
-__device__ __forceinline__ void chain_mma(const ChainFrag& f, int lda, const uint16_t* Bl, int pb, int ksteps, int lo4, int kg,
+__device__ __forceinline__ void chain_mma(const ChainFrag& f, const uint16_t* Bl, int pb, int ksteps, int lo4, int kg,
                                           float4v& acc0, float4v& acc1) {
     acc0 = acc1 = (float4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         if (s < ksteps) {
-            const int c = 32 * s + 8 * kg;
-            const unsigned keep = c + 8 <= lda ? 0xffffffffu : 0u;
-            const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(Bl + lo4 * pb + c));
-            const uint4v m0 = {f.a0[s][0] & keep, f.a0[s][1] & keep, f.a0[s][2] & keep, f.a0[s][3] & keep};
-            const uint4v m1 = {f.a1[s][0] & keep, f.a1[s][1] & keep, f.a1[s][2] & keep, f.a1[s][3] & keep};
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, m0), b, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, m1), b, acc1, 0, 0, 0);
+            const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(Bl + lo4 * pb + 32 * s + 8 * kg));
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.a0[s]), b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.a1[s]), b, acc1, 0, 0, 0);
         }
     }
 }
@@ -213,13 +212,13 @@ __global__ __launch_bounds__(kChainThreads) void fit_chain_kernel(aadff_fit_net 
     auto fetch = [&](int q, ChainFrag& f) {
         if (q < L) {
             const int n4 = (a.n[q] + 3) & ~3;
-            chain_load(f, p16 + a.off_w[q], n4, a.ld_k[q], wave, lo4, kg);
+            chain_load(f, p16 + a.off_w[q], (a.n[q] + 15) >> 4, (a.k[q] + 31) >> 5, wave, lane);
             // fetched with the weights: a load issued later (in the epilogue) could only be waited for together with every
             // prefetch issued before it (one in-order counter)
             const uint16_t* bias = p16 + a.off_b[q];
             f.bias0 = *reinterpret_cast<const uint2*>(bias + min(wave * 16 + 4 * kg, n4 - 4));
             f.bias1 = *reinterpret_cast<const uint2*>(bias + min((wave + kChainWaves) * 16 + 4 * kg, n4 - 4));
-        } else if (q < P) { const int i = 2 * L - 1 - q; chain_load(f, p16 + a.off_wt[i], a.k[i], a.ld_n[i], wave, lo4, kg); }
+        } else if (q < P) { const int i = 2 * L - 1 - q; chain_load(f, p16 + a.off_wt[i], (a.k[i] + 15) >> 4, (a.n[i] + 31) >> 5, wave, lane); }
     };
     ChainFrag f0, f1;
     fetch(0, f0);
@@ -254,13 +253,13 @@ __global__ __launch_bounds__(kChainThreads) void fit_chain_kernel(aadff_fit_net 
     int xoff = 0;
     auto forward = [&](int l, ChainFrag& f) {
         lds_barrier();
-        const int K = a.k[l], N = a.n[l], N4 = (N + 3) & ~3, ldk = a.ld_k[l];
+        const int K = a.k[l], N = a.n[l], N4 = (N + 3) & ~3;
         const int pl = chain_pitch(K), pn = chain_pitch(N);
         uint16_t* Xn = lds + xoff + kChainRows * pl;
         uint16_t* xt = scr + a.off_xt[l + 1 < L ? l + 1 : 0];
         const bool last = l == L - 1;
         float4v acc[2];
-        chain_mma(f, ldk, lds + xoff, pl, (K + 31) >> 5, lo4, kg, acc[0], acc[1]);
+        chain_mma(f, lds + xoff, pl, (K + 31) >> 5, lo4, kg, acc[0], acc[1]);
         const uint2 bias2[2] = {f.bias0, f.bias1};
         fetch(l + 2, f);
 #pragma unroll
@@ -347,7 +346,7 @@ __global__ __launch_bounds__(kChainThreads) void fit_chain_kernel(aadff_fit_net 
     int cur = 0;
     auto backward = [&](int q, ChainFrag& f) {
         const int i = 2 * L - 1 - q;
-        const int K = a.k[i], N = a.n[i], ldn = a.ld_n[i];
+        const int K = a.k[i], N = a.n[i];
         const int pi = chain_pitch(K);
         xoff -= kChainRows * pi;                                  // X_i
         const uint16_t* Xi = lds + xoff;
@@ -355,7 +354,7 @@ __global__ __launch_bounds__(kChainThreads) void fit_chain_kernel(aadff_fit_net 
         uint16_t* dzt = scr + a.off_dzt[i];
         float* gb = a.grad + a.off_gb[i - 1];
         float4v acc[2];
-        chain_mma(f, ldn, dzbuf[cur], PZ, (N + 31) >> 5, lo4, kg, acc[0], acc[1]);
+        chain_mma(f, dzbuf[cur], PZ, (N + 31) >> 5, lo4, kg, acc[0], acc[1]);
         fetch(q + 2, f);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -555,9 +554,8 @@ extern "C" int aadff_fit_chain(const aadff_fit_net* net, int* step_dev, float* s
     AADFF_CHECK_ARG(!step_dev || (scratch4 && t_max > 0), "fit_chain: optimiser schedule needs scratch4 and t_max > 0");
     int xtotal = 0, maxw = 0, gx = 0, gy = 0;
     for (int l = 0; l < a.n_layers; ++l) {
-        AADFF_CHECK_ARG(a.k[l] > 0 && a.k[l] <= 256 && a.n[l] > 0 && a.n[l] <= 256 && a.k[l] % 4 == 0 && a.ld_k[l] % 8 == 0 && a.ld_n[l] % 8 == 0 &&
-                        a.ld_k[l] >= a.k[l] && a.ld_n[l] >= a.n[l], "fit_chain: layer %d: widths %d -> %d (<= 256, inputs multiples of 4), ld %d / %d",
-                        l, a.k[l], a.n[l], a.ld_k[l], a.ld_n[l]);
+        AADFF_CHECK_ARG(a.k[l] > 0 && a.k[l] <= 256 && a.n[l] > 0 && a.n[l] <= 256 && a.k[l] % 4 == 0,
+                        "fit_chain: layer %d: widths %d -> %d (<= 256, inputs multiples of 4)", l, a.k[l], a.n[l]);
         AADFF_CHECK_ARG(l == 0 || a.k[l] == a.n[l - 1], "fit_chain: layer %d input width %d != previous output %d", l, a.k[l], a.n[l - 1]);
         AADFF_CHECK_ARG((a.off_w[l] | a.off_wt[l] | a.off_b[l] | a.off_xt[l] | a.off_dzt[l + 1]) % 8 == 0 && a.off_gw[l] % 4 == 0,
                         "fit_chain: layer %d: buffer offsets must keep 16-byte alignment", l);

@@ -326,8 +326,11 @@ int aadff_psfnet_head_loss_grad(const void* z, const float* target, float* pred,
 /* The same step in THREE launches (aadff_fit_chain = 2, then aadff_fit_adamw): a workgroup takes 16 rows of the batch through
  * input cast, every Linear(+ReLU), the head and the whole dX chain with the activations in LDS (rows only meet in dW), then
  * one launch computes dW of all layers.  `aadff_fit_net` describes the network and its buffers:
- *   param_bf16:   W_l [up4(n)][ld_k] at off_w, W_l^T [k][ld_n] at off_wt, bias_l at off_b (bf16, zero padded; offsets in elements,
- *                 multiples of 8; refreshed by aadff_fit_adamw);
+ *   param_bf16:   W_l at off_w and W_l^T at off_wt in MFMA FRAGMENT ORDER - a matrix M [rows][cols] (W: n x k, W^T: k x n) is stored as
+ *                 [row / 16][col / 32][lane = ((col % 32) / 8) * 16 + row % 16][col % 8], zero padded to whole 16-row tiles and
+ *                 32-column steps, so that a wave-instruction reads 1 KiB contiguously; bias_l [up4(n)] at off_b (bf16; offsets in
+ *                 elements, multiples of 8; refreshed by aadff_fit_adamw through its destination maps; ld_k / ld_n are not used
+ *                 by this entry);
  *   scratch_bf16: X_l^T [k_l][ld_batch] at off_xt[l] (l = 0..L-1) and dZ_l^T [n_{l-1}][ld_batch] at off_dzt[l] (l = 1..L), written
  *                 by the chain kernel, read by the dW kernel (zero padded columns batch..ld_batch);
  *   grad (fp32):  dW_l [n][k] at off_gw (stored), db_l [n] at off_gb (ADDED by atomics: must be zero on entry; aadff_fit_adamw
