@@ -539,7 +539,9 @@ def render_scenes_sharded(renderer, gather=True, stream=None):
     share = adist.padded_share(n, world)
     img0 = renderer.scenes[0][0]
     dev = renderer.lens._gpu()
-    local = torch.zeros((share,) + tuple(img0.shape[1:]), dtype=torch.float32, device=dev)
+    local = torch.empty((share,) + tuple(img0.shape[1:]), dtype=torch.float32, device=dev)
+    if len(mine) < share:
+        local[len(mine):].zero_()                     # padding units of the equal-share all-gather (n not a multiple of world)
     renderer.render(mine, out=local[:len(mine)])
     if not gather:
         return local, mine
