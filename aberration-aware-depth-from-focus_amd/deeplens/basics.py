@@ -25,11 +25,22 @@ MINT, MAXT = 1e-5, 1e5
 DELTA = 1e-6
 EPSILON = 1e-9
 
-# (n_d, V_d) of the media the shipped lenses use by name; any other glass is given as an
-# "n/V" string (the form both reference lens files use).  Catalogue glasses are optional:
-# register more with Material.register(name, n, V).
-_UNIT_MEDIA = ("vacuum", "air", "occluder")
-_CATALOGUE = {"bk7": (1.5168, 64.17), "n-bk7": (1.5168, 64.17), "pmma": (1.491756, 58.00)}
+_CAT = None
+
+
+def _catalogue():
+    """Glass tables of the reference (deeplens/basics.py:40-160) as data: {"material": name -> [n_d, V_d], "sellmeier":
+    name -> [k1,l1,k2,l2,k3,l3], "schott": name -> [a0..a5], "glass_name": name -> display name}."""
+    global _CAT
+    if _CAT is None:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "glass_catalogue.json")) as f:
+            _CAT = json.load(f)
+        for v in _CAT["material"].values():
+            if v[1] == "inf":
+                v[1] = math.inf
+    return _CAT
 
 
 class DeepObj:
@@ -92,29 +103,37 @@ class Ray(DeepObj):
 class Material:
     """Refractive index n(lambda) in float64 on the host (deeplens/basics.py:298-379).
 
-    "n/V" strings and catalogue names use Cauchy's n = A + B/lambda_nm^2 with (A,B) from
-    (n_d, V_d); air/vacuum/occluder are exactly 1."""
+    Three dispersion branches, chosen by the (lower-cased) name exactly as the reference does (:298-313):
+    a name with Sellmeier coefficients (incl. air / vacuum / occluder, whose coefficients are all zero -> n = 1) uses the
+    Sellmeier equation (:325-327); a name with Schott coefficients (the plastics) the Schott polynomial in nested form
+    (:329-332); anything else - catalogue names that only have (n_d, V_d), and "n/V" strings - Cauchy's
+    n = A + B / lambda_nm^2 (:334-335).  (A, B) are computed for every glass (find_aperture reads A, optics.py:190-198).
+    The coefficient tables are data (glass_catalogue.json, emitted by tests/golden/make_golden.py)."""
 
     def __init__(self, name=None):
         self.name = "vacuum" if name is None else name.lower()
-        if self.name in _UNIT_MEDIA:
-            self.n, self.V = 1.0, math.inf
-            self.dispersion = "unit"
-        elif self.name in _CATALOGUE:
-            self.n, self.V = _CATALOGUE[self.name]
-            self.dispersion = "naive"
+        cat = _catalogue()
+        self.A, self.B = self._lookup_material()
+        if self.name in cat["sellmeier"]:
+            self.dispersion = "sellmeier"
+            self.k1, self.l1, self.k2, self.l2, self.k3, self.l3 = cat["sellmeier"][self.name]
+            self.glassname = self.name
+        elif self.name in cat["schott"]:
+            self.dispersion = "schott"
+            self.a0, self.a1, self.a2, self.a3, self.a4, self.a5 = cat["schott"][self.name]
+            self.glassname = cat["glass_name"][self.name]
         else:
-            parts = self.name.split("/")
-            if len(parts) != 2:
-                raise KeyError(f"unknown glass {name!r}: use an 'n/V' string or Material.register()")
-            self.n, self.V = float(parts[0]), float(parts[1])
             self.dispersion = "naive"
-        self.A, self.B = self.nV_to_AB(self.n, self.V)
-        self.glassname = self.name
+            self.glassname = self.name
 
     @staticmethod
     def register(name, n, V):
-        _CATALOGUE[name.lower()] = (float(n), float(V))
+        """Add an (n_d, V_d) glass under a name of its own (Cauchy branch)."""
+        _catalogue()["material"][name.lower()] = [float(n), float(V)]
+
+    def load_sellmeier_param(self, params=None):
+        """Set the Sellmeier coefficients k1, l1, k2, l2, k3, l3 by hand (deeplens/basics.py:339-347)."""
+        self.k1, self.l1, self.k2, self.l2, self.k3, self.l3 = (0, 0, 0, 0, 0, 0) if params is None else params
 
     @staticmethod
     def nV_to_AB(n, V):
@@ -123,8 +142,26 @@ class Material:
         A = n - B * (1.0 / lam_d ** 2)
         return A, B
 
+    def _lookup_material(self):
+        """(A, B) from the catalogue's (n_d, V_d) or from an "n/V" string (deeplens/basics.py:363-379)."""
+        hit = _catalogue()["material"].get(self.name)
+        if hit is not None:
+            n, V = hit
+        else:
+            parts = self.name.split("/")
+            try:
+                n, V = float(parts[0]), float(parts[1])
+            except (ValueError, IndexError):
+                raise ValueError(f"unknown glass {self.name!r}: not in the catalogue and not an 'n/V' string") from None
+        self.n, self.V = n, V
+        return self.nV_to_AB(n, V)
+
     def ior(self, wvln):
-        wv = wvln if wvln < 10 else wvln * 1e-3
-        if self.dispersion == "unit":
-            return 1.0
+        wv = wvln if wvln < 10 else wvln * 1e-3          # [um]
+        if self.dispersion == "sellmeier":
+            w2 = wv ** 2
+            return np.sqrt(1 + self.k1 * w2 / (w2 - self.l1) + self.k2 * w2 / (w2 - self.l2) + self.k3 * w2 / (w2 - self.l3))
+        if self.dispersion == "schott":
+            ws = wv ** 2
+            return np.sqrt(self.a0 + self.a1 * ws + (self.a2 + (self.a3 + (self.a4 + self.a5 / ws) / ws) / ws) / ws)
         return self.A + self.B / (wv * 1e3) ** 2

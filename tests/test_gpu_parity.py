@@ -315,6 +315,32 @@ def test_refocus_seeded(golden_dir, repo_root, name):
             assert getattr(lens, k) == pytest.approx(want[k], rel=1e-5), (f, k)
 
 
+def test_named_glass_lens_end_to_end(golden_dir, repo_root):
+    """G14: a prescription whose elements NAME catalogue glasses of all three dispersion branches (COC: Schott, N-LAK34:
+    Sellmeier, SF5: table n/V; deeplens/basics.py:298-336) - load scalars, pupils, refocus scalars and a PSF map against
+    the reference.  (Round 2 answered named glasses with the Cauchy formula: n off by 1e-4, which moves every PSF.)"""
+    g = json.load(open(os.path.join(golden_dir, "g14_glass.json")))["named_lens"]
+    gm = np.load(os.path.join(golden_dir, "g14_named_psf_map.npz"))
+    path = lens_path(repo_root, "rf50mm_named")
+    lens = Lensgroup(path, sensor_res=(256, 256), device=DEV)
+    for k in ("d_sensor", "hfov", "foclen", "fnum", "pixel_size"):
+        assert getattr(lens, k) == pytest.approx(g["load"][k], rel=1e-5), k
+    assert lens.aper_idx == g["load"]["aper_idx"]
+    assert list(lens.entrance_pupil()) == pytest.approx(g["entrance_pupil"], rel=1e-5)
+    assert list(lens.exit_pupil()) == pytest.approx(g["exit_pupil"], rel=1e-5)
+    for f, want in g["refocus"].items():
+        torch.manual_seed(0)
+        lens.refocus(float(f))
+        for k in ("d_sensor", "hfov", "foclen", "fnum"):
+            assert getattr(lens, k) == pytest.approx(want[k], rel=1e-5), (f, k)
+    lens = Lensgroup(path, sensor_res=(256, 256), device=DEV)
+    torch.manual_seed(0)
+    lens.refocus(-1500.0)
+    pm = lens.psf_map(depth=-1200.0, grid=5, ks=11, spp=512).cpu().numpy()
+    assert lens.d_sensor == pytest.approx(float(gm["d_sensor"]), rel=1e-5)
+    assert rel_l2(pm, gm["psf_map"]) <= 2e-3
+
+
 # ================================================================= G2/G3: trace and splat
 @pytest.fixture(scope="module")
 def g23(golden_dir):

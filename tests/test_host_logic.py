@@ -28,8 +28,29 @@ def test_material_ior_matches_reference(golden_dir):
     for key in ("rf50mm@1024x1024", "50mm_f2.8@1024x1024"):
         for m, vals in g[key]["ior"].items():
             assert [float(Material(m).ior(w)) for w in WAVE_RGB] == pytest.approx(vals, abs=1e-14), m
-    with pytest.raises(KeyError):
+    with pytest.raises(ValueError):                    # the reference fails in float("unobtainium") (basics.py:372-374)
         Material("unobtainium")
+
+
+def test_material_named_glasses_match_reference(golden_dir):
+    """Every catalogue name (Sellmeier / Schott / table n-V branches, deeplens/basics.py:298-336) at six wavelengths,
+    bit-equal to the reference (fixture G14), incl. A / B / dispersion / glassname and upper-case names."""
+    g = json.load(open(os.path.join(golden_dir, "g14_glass.json")))
+    seen = set()
+    for name, rec in g["ior"].items():
+        m = Material(name)
+        seen.add(m.dispersion)
+        assert m.dispersion == rec["dispersion"] and m.glassname == rec["glassname"], name
+        assert (m.A, m.B) == (rec["A"], rec["B"]), name
+        assert [float(m.ior(w)) for w in g["waves"]] == rec["n"], name
+    assert seen == {"sellmeier", "schott", "naive"} and len(g["ior"]) >= 40
+    bk7 = Material("n-bk7")
+    assert abs(bk7.ior(0.589) - (bk7.A + bk7.B / 589.0 ** 2)) > 5e-5      # NOT the Cauchy value (round-2 bug)
+    air = Material("air")
+    assert air.dispersion == "sellmeier" and float(air.ior(0.5)) == 1.0 and air.A == 1.0
+    m = Material("f2")
+    m.load_sellmeier_param()
+    assert float(m.ior(0.6)) == 1.0
 
 
 def test_lens_loads_on_cpu_without_kernels(repo_root, golden_dir):

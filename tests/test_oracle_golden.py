@@ -59,6 +59,38 @@ def test_g1_refocus(golden_dir, repo_root, name, res):
             assert getattr(lens, k) == pytest.approx(want[k], rel=0, abs=1e-9), (f, k)
 
 
+def test_g14_named_glasses(golden_dir, repo_root):
+    """G14: every catalogue glass (all three dispersion branches) bit-equal; a lens that names Schott / Sellmeier / table
+    glasses end to end (load scalars, pupils, refocus scalars, PSF map)."""
+    g = json.load(open(os.path.join(golden_dir, "g14_glass.json")))
+    for name, rec in g["ior"].items():
+        gl = Glass(name)
+        assert gl.dispersion == rec["dispersion"], name
+        assert (gl.A, gl.B) == (rec["A"], rec["B"]), name
+        assert [float(gl.ior(w)) for w in g["waves"]] == rec["n"], name
+    nl = g["named_lens"]
+    path = lens_path(repo_root, "rf50mm_named")
+    lens = OracleLens(path, sensor_res=(256, 256))
+    for k in ("d_sensor", "hfov", "foclen", "fnum", "pixel_size"):
+        assert getattr(lens, k) == pytest.approx(nl["load"][k], rel=0, abs=1e-9), k
+    assert lens.aper_idx == nl["load"]["aper_idx"]
+    assert list(lens.entrance_pupil()) == pytest.approx(nl["entrance_pupil"], abs=1e-9)
+    assert list(lens.exit_pupil()) == pytest.approx(nl["exit_pupil"], abs=1e-9)
+    for f, want in nl["refocus"].items():
+        lens = OracleLens(path, sensor_res=(256, 256))
+        torch.manual_seed(0)
+        lens.refocus(float(f))
+        for k in ("d_sensor", "hfov", "foclen", "fnum"):
+            assert getattr(lens, k) == pytest.approx(want[k], rel=0, abs=1e-9), (f, k)
+    gm = np.load(os.path.join(golden_dir, "g14_named_psf_map.npz"))
+    lens = OracleLens(path, sensor_res=(256, 256))
+    torch.manual_seed(0)
+    lens.refocus(-1500.0)
+    pm = lens.psf_map(depth=-1200.0, grid=5, ks=11, spp=512)
+    assert lens.d_sensor == pytest.approx(float(gm["d_sensor"]), abs=1e-9)
+    assert np.abs(pm.numpy() - gm["psf_map"]).max() <= ATOL
+
+
 def test_appendix_d_known_answers(repo_root):
     """SURVEY.md Appendix D values measured on the reference (independent of the fixtures)."""
     lens = OracleLens(lens_path(repo_root, "rf50mm"), sensor_res=(1024, 1024))

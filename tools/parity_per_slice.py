@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Per-slice distance of the bench stack (BASELINE.json configs[1], seed 0) to the REFERENCE's own result (fixture G9),
+for one build of the trace kernels.
+
+    AADFF_LIB=.../libaadff_literal.so python tools/parity_per_slice.py          # reference op order (csrc/Makefile: LITERAL)
+    python tools/parity_per_slice.py [--strict]                                 # shipped build (fast / parity="strict")
+
+Per slice: rel-L2 of the PSF map vs G9's, rel-L2 of the WHOLE rendered slice vs the image rendered from G9's PSF map by
+the same convolution kernel (the convolution is deterministic to 2e-6 abs, so this isolates the trace), rel-L2 on G9's
+three stored 64x64 crops, and G13's fp32 floor of the slice.  Prints one JSON object; no oracle involved."""
+import argparse
+import importlib
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "aberration-aware-depth-from-focus_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--strict", action="store_true", help="Lensgroup(parity='strict')")
+    ap.add_argument("--label", default=None)
+    args = ap.parse_args()
+    from aadff import _abi
+    from aadff.focal_stack import StackPlan, render_focal_stack_m1
+    from aadff.synth import synth_depth_mm, synth_rgb
+    from deeplens.optics import Lensgroup
+    rp = importlib.import_module("deeplens.render_psf")
+    g = np.load(os.path.join(REPO, "tests", "golden", "g9_stack_m1_1024.npz"))
+    fl = np.load(os.path.join(REPO, "tests", "golden", "g13_fp32_floor.npz"))
+    H = W = 1024
+    S = 10
+    dev = "cuda:0"
+    kw = {"parity": "strict"} if args.strict else {}
+    lens = Lensgroup(os.path.join(REPO, "lenses", "rf50mm", "lens.json"), sensor_res=(H, W), device=dev, **kw)
+    img = torch.from_numpy(synth_rgb(H, W, seed=1234))[None].to(dev)
+    depth = synth_depth_mm(H, W, seed=5678)
+    dbar, fds = -float(depth.mean()), -np.linspace(depth.min(), depth.max(), S)
+    plan = StackPlan(lens, S, H, W, 1, 3, 11, 11, 2048)
+    torch.manual_seed(0)
+    out = render_focal_stack_m1(lens, img, dbar, fds, 11, 11, 2048, plan=plan, update_lens=False)
+    plan.check_flags()
+    s = out[0].cpu().numpy()
+    maps = plan.psf_maps.cpu().numpy()
+    st = np.frombuffer(plan.states.cpu().numpy().tobytes(), dtype=np.float32).reshape(S, 8)
+    rows = []
+    crops = {"seam": (slice(61, 125), slice(154, 218)), "centre": (slice(480, 544), slice(480, 544)), "corner": (slice(960, 1024), slice(960, 1024))}
+    num = den = 0.0
+    for k in range(S):
+        ref_img = rp.render_psf_map(img, torch.from_numpy(g["psf_maps"][k]).to(dev), 11)[0].cpu().numpy().astype(np.float64)
+        d = s[:, k].astype(np.float64) - ref_img
+        num += float((d * d).sum())
+        den += float((ref_img * ref_img).sum())
+        rows.append({"slice": k, "focus_mm": round(float(fds[k]), 1),
+                     "d_sensor_rel": float(f"{abs(st[k, 0] / g['d_sensor'][k] - 1):.2e}"),
+                     "psf_rel_l2": float(f"{rel(maps[k], g['psf_maps'][k]):.3e}"),
+                     "img_rel_l2": float(f"{np.sqrt((d * d).sum() / (ref_img * ref_img).sum()):.3e}"),
+                     "crops_rel_l2": {n: float(f"{rel(s[:, k][(slice(None),) + c], g['crop_' + n][:, k]):.3e}") for n, c in crops.items()},
+                     "fp32_floor_img": float(f"{fl['img_floor'][k]:.2e}"), "fp32_floor_psf": float(f"{fl['psf_floor'][k]:.2e}")})
+    res = {"build": args.label or os.environ.get("AADFF_LIB", "libaadff.so") + (" parity=strict" if args.strict else ""),
+           "stack_img_rel_l2": float(f"{np.sqrt(num / den):.3e}"), "stack_psf_rel_l2": float(f"{rel(maps, g['psf_maps']):.3e}"),
+           "worst_slice_img_rel_l2": max(r["img_rel_l2"] for r in rows), "slices": rows}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
