@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AADFF_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libaadff.so")   # AADFF_LIB: A/B builds (tools/)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_GRID, MAX_KS, MAX_SURF, MAX_AI = 64, 51, 32, 8
 SURF_STOP, SURF_SPHERIC, SURF_ASPHERIC = 0, 1, 2
 
@@ -24,7 +24,7 @@ class Surface(C.Structure):
                 ("eta_fwd", C.c_float), ("eta_fwd2", C.c_float), ("eta_bwd", C.c_float), ("eta_bwd2", C.c_float),
                 ("kind", C.c_int), ("n_ai", C.c_int), ("refract_fwd", C.c_int), ("refract_bwd", C.c_int),
                 ("k_gt_m1", C.c_int), ("ai", C.c_float * MAX_AI), ("dai", C.c_float * MAX_AI),
-                ("cos2_min_fwd", C.c_float), ("cos2_min_bwd", C.c_float)]
+                ("cos2_min_fwd", C.c_float), ("cos2_min_bwd", C.c_float), ("newton_step_tol", C.c_float)]
 
 
 class LensState(C.Structure):
@@ -59,7 +59,7 @@ class FitNet(C.Structure):
 
 
 assert C.sizeof(Stage) == 40
-assert C.sizeof(Surface) == 132 and C.sizeof(LensState) == 32 and C.sizeof(LensConst) == 52
+assert C.sizeof(Surface) == 136 and C.sizeof(LensState) == 32 and C.sizeof(LensConst) == 52
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 

@@ -12,6 +12,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 import torch
 import torch.distributed as dist
@@ -25,7 +26,8 @@ def free_port():
 
 def spawn_ranks(argv, world, emulate=False, env=None, timeout=None):
     """Run `python argv...` as `world` rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) and wait.
-    Returns the largest exit code.  The caller must not have initialised the GPU (no HIP call, no
+    Returns the largest exit code (the first failing rank's when one fails: its peers are then torn down; 124 when
+    `timeout` seconds - one deadline for the whole job - expire).  The caller must not have initialised the GPU (no HIP call, no
     torch.cuda.is_available()): on this pool a GPU-initialised parent must not start GPU children by exec, and a
     parent that holds a context would also take memory on device 0."""
     port = free_port()
@@ -38,16 +40,35 @@ def spawn_ranks(argv, world, emulate=False, env=None, timeout=None):
         if emulate:
             e["AADFF_EMULATE_RANKS"] = "1"
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+    # One poll loop over ALL ranks with ONE overall deadline (torchrun's behaviour): the first rank that exits non-zero,
+    # or the deadline, ends the job - the remaining ranks (which would otherwise sit in init_process_group or in a
+    # collective, holding their GPUs until the backend's own 10-30 min timeout) are terminated, then killed.
+    deadline = None if timeout is None else time.monotonic() + timeout
     rc = 0
     try:
-        for p in procs:
-            rc = max(rc, abs(p.wait(timeout=timeout)))
-    except subprocess.TimeoutExpired:
-        rc = 124
+        live = list(procs)
+        while live and rc == 0:
+            for p in list(live):
+                code = p.poll()
+                if code is not None:
+                    live.remove(p)
+                    rc = max(rc, abs(code))
+            if live and rc == 0:
+                if deadline is not None and time.monotonic() > deadline:
+                    rc = 124
+                    break
+                time.sleep(0.02)
     finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()                 # exact PIDs we started
+        left = [p for p in procs if p.poll() is None]
+        for p in left:
+            p.terminate()                # exact PIDs we started
+        t_kill = time.monotonic() + 5.0
+        for p in left:
+            try:
+                p.wait(timeout=max(0.0, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
     return rc
 
 
@@ -151,8 +172,9 @@ def render_sharded(n_units, render_unit, unit_shape, dtype=torch.float32, device
     """Render this rank's units with `render_unit(u) -> tensor[unit_shape]` and, if `gather`,
     return the full `[n_units, *unit_shape]` tensor on every rank (None otherwise: the consumer is
     rank-local, e.g. DDP training).  With `stream` the all-gather AND the reorder into unit order run on that
-    side stream and the third return value is the event the consumer must wait on (the caller may render the
-    next batch meanwhile); without it the result is ready on the current stream."""
+    side stream and the call ALWAYS returns three values `(out, mine, done)`: `done` is the event the consumer must wait
+    on (the caller may render the next batch meanwhile), or None when nothing ran on the side stream (one rank, or
+    `gather=False`).  Without `stream` it returns `(out, mine)` and the result is ready on the current stream."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     share = padded_share(n_units, world)
@@ -161,9 +183,9 @@ def render_sharded(n_units, render_unit, unit_shape, dtype=torch.float32, device
     for i, u in enumerate(mine):
         local[i].copy_(render_unit(u))
     if not gather:
-        return local, mine
+        return (local, mine) if stream is None else (local, mine, None)
     if world == 1:
-        return local[:n_units], mine
+        return (local[:n_units], mine) if stream is None else (local[:n_units], mine, None)
     full = torch.empty((world * share,) + tuple(unit_shape), dtype=dtype, device=device)
     if stream is None:
         all_gather_into(full, local)

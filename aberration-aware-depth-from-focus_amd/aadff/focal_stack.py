@@ -529,7 +529,8 @@ class SceneUnitRenderer:
 
 def render_scenes_sharded(renderer, gather=True, stream=None):
     """This rank's share of all (scene, slice) units through the HIP renderer and, with `gather`, ONE all-gather that
-    leaves the full `[n_scenes*S, C, H, W]` set in unit order on every rank (aadff.dist.render_sharded semantics)."""
+    leaves the full `[n_scenes*S, C, H, W]` set in unit order on every rank (aadff.dist.render_sharded semantics: with
+    `stream` always `(out, mine, done_or_None)`, without it `(out, mine)`)."""
     import torch.distributed as dist
     from . import dist as adist
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -544,9 +545,9 @@ def render_scenes_sharded(renderer, gather=True, stream=None):
         local[len(mine):].zero_()                     # padding units of the equal-share all-gather (n not a multiple of world)
     renderer.render(mine, out=local[:len(mine)])
     if not gather:
-        return local, mine
+        return (local, mine) if stream is None else (local, mine, None)
     if world == 1:
-        return local[:n], mine
+        return (local[:n], mine) if stream is None else (local[:n], mine, None)
     full = torch.empty((world * share,) + tuple(local.shape[1:]), dtype=torch.float32, device=dev)
     if stream is None:
         adist.all_gather_into(full, local)

@@ -21,7 +21,8 @@ constexpr int kNewtonMaxIter = 10;       // deeplens/surfaces.py:26
 constexpr float kTolTight = 10e-6f;      // deeplens/surfaces.py:27
 constexpr float kTolLoose = 50e-6f;      // deeplens/surfaces.py:28
 constexpr float kStepBound = 5.f;        // deeplens/surfaces.py:29
-constexpr float kStepConverged = 1e-2f;  // fused kernels: a Newton update below 10 um ends the loop (see newton2)
+// fused kernels: a Newton update shorter than aadff_surface_t::newton_step_tol (<= 10 um, set per surface by the host from
+// the surface's largest profile curvature) ends the loop (see newton2)
 [[maybe_unused]] constexpr float kTwoPiHi = 3.14159274101257324f;   // (float)np.pi (libm sin/cos builds)
 
 struct Ray {
@@ -404,18 +405,23 @@ __device__ __forceinline__ void newton2(const aadff_surface_t& s, const Ray2& r,
     }
 #endif
     // The reference leaves its loop when the residual BEFORE the last update is below 5e-5 mm, i.e. it spends one
-    // whole evaluation confirming a converged point, then takes its extra (strict) step.  A Newton update shorter than
-    // kStepConverged = 1e-2 mm leaves an error of f''/(2 f') x step^2 <= 0.03 x 1e-4 = 3e-6 mm (f'' is the surface
-    // curvature seen along the ray, f' ~ -dz), i.e. a residual 3x under the strict step's |residual| < 1e-5 test, and the
-    // strict step — a full Newton update like any other — then takes the point to ~1e-12 mm: the confirming evaluation is
-    // skipped without moving the hit (with 1e-3 the rim rays of nearly every wave forced one more whole evaluation).
+    // whole evaluation confirming a converged point, then takes its extra (strict) step.  A Newton update of length
+    // `step` leaves a residual of f''/(2 f') x step^2 (f'' <= the largest curvature kappa of the surface profile, f' ~ -dz);
+    // the host sets newton_step_tol = min(1e-2, sqrt(4e-6 / kappa)) mm per surface (deeplens/surfaces.py: pack), so that
+    // this residual stays <= 3e-6 mm, 3x under the strict step's |residual| < 1e-5 test, for ANY lens file (kappa = 0.03/mm
+    // gives the 10 um that the shipped 50 mm lenses run with); the strict step — a full Newton update like any other —
+    // then takes the point to ~1e-12 mm: the confirming evaluation is skipped without moving the hit (with 1 um the rim
+    // rays of nearly every wave forced one more whole evaluation).
+    [[maybe_unused]] const float step_tol = s.newton_step_tol;
     f2 ft = f2s(kMaxT), step = f2s(kMaxT);
+    i2 nanm = {0, 0};                                    // NaN seen in ANY residual (the reference exits on the first, surfaces.py:555)
 #if !defined(AADFF_NEWTON_LITERAL_EXIT) && !defined(AADFF_NEWTON_CHECK_EVERY_STEP)
     // The first evaluation always runs (the reference enters its loop with ft = MAXT) and the second does whenever any
     // ray of the batch started more than 5e-5 mm off the surface, which from the conic root of an asphere is every
     // batch: run both without the wave-wide exit test, then continue under it.  (Steps on converged rays are no-ops
-    // at the 1e-9 level, which is also what the reference's batch-wide loop does to them.)  A NaN residual survives
-    // every later update, so it is tested once, on the strict step's residual.
+    // at the 1e-9 level, which is also what the reference's batch-wide loop does to them.)  A NaN residual does NOT
+    // survive the updates (the step clamp is v_max/v_min: maxnum/minnum drop a NaN operand, where torch.clamp propagates
+    // it), so every residual is tested as it is produced - one compare and a scalar OR each - and the flag is raised once.
 #if !defined(AADFF_NEWTON_PLANE_START) && !defined(AADFF_NEWTON_GENERIC_FIRST)
     if (s.n_ai > 0 && !__any(any2(alive & ~hit0))) {
         // Every live ray of the wave starts ON the conic (tau = its conic root), where the residual is the polynomial
@@ -427,6 +433,7 @@ __device__ __forceinline__ void newton2(const aadff_surface_t& s, const Ray2& r,
         f2 ps, pd;
         poly2(s, r2, ps, pd);
         ft = ps * r2;
+        nanm |= ft != ft;
         const f2 sf = 1.f - ((1.f + s.k) * s.c) * (r.dz * tau);
         const f2 slope = (0.5f * s.c) * vrcp(sf) + pd;
         const f2 dfdt = slope * (2.f * (dxy2 * tau + od)) - r.dz;
@@ -435,25 +442,31 @@ __device__ __forceinline__ void newton2(const aadff_surface_t& s, const Ray2& r,
         tau -= step;
     } else
 #endif
-    ft = newton_step2<false>(s, r, dxy2, od, tau, nullptr, &step);
-    ft = newton_step2<false>(s, r, dxy2, od, tau, nullptr, &step);
-    for (int it = 2; it < kNewtonMaxIter; ++it) {
-        if (!__any(any2(alive & (vabs(ft) > kTolLoose) & (vabs(step) > kStepConverged)))) break;
+    {
         ft = newton_step2<false>(s, r, dxy2, od, tau, nullptr, &step);
+        nanm |= ft != ft;
+    }
+    ft = newton_step2<false>(s, r, dxy2, od, tau, nullptr, &step);
+    nanm |= ft != ft;
+    for (int it = 2; it < kNewtonMaxIter; ++it) {
+        if (!__any(any2(alive & (vabs(ft) > kTolLoose) & (vabs(step) > step_tol)))) break;
+        ft = newton_step2<false>(s, r, dxy2, od, tau, nullptr, &step);
+        nanm |= ft != ft;
     }
 #else
     for (int it = 0; it < kNewtonMaxIter; ++it) {
 #ifndef AADFF_NEWTON_LITERAL_EXIT
-        if (!__any(any2(alive & (vabs(ft) > kTolLoose) & (vabs(step) > kStepConverged)))) break;
+        if (!__any(any2(alive & (vabs(ft) > kTolLoose) & (vabs(step) > step_tol)))) break;
 #else
         if (!__any(any2(alive & (vabs(ft) > kTolLoose)))) break;
 #endif
         ft = newton_step2<false>(s, r, dxy2, od, tau, nullptr, &step);
-        if (any2(alive & (ft != ft))) nan_flag = 1;
+        nanm |= ft != ft;
     }
 #endif
     ft = newton_step2<true>(s, r, dxy2, od, tau, slope_out);
-    if (any2(alive & (ft != ft))) nan_flag = 1;
+    nanm |= ft != ft;
+    if (any2(alive & nanm)) nan_flag = 1;
     const f2 px = r.ox + r.dx * tau, py = r.oy + r.dy * tau;
     valid_out = valid_strict2(s, px * px + py * py) & (vabs(ft) < kTolTight) & (t0 + tau > 0.f);
     tau_out = tau;

@@ -88,7 +88,26 @@ class Aspheric(Surface):
         for i in range(self.ai_degree):
             s.ai[i] = float(self.ai[i].item())
             s.dai[i] = float(f32(i + 1) * f32(self.ai[i].item()))
+        s.newton_step_tol = self.newton_step_tol()
         return s
+
+    def newton_step_tol(self):
+        """Length [mm] of a Newton update below which the fused kernels go straight to the strict step (aadff.h:
+        aadff_surface_t::newton_step_tol).  An update of length t leaves a residual of about kappa t^2 / (2 |f'|) with
+        kappa = max |d^2 sag / d r^2| over the aperture and |f'| >= 0.7: tol = sqrt(4e-6 / kappa) keeps it <= 3e-6 mm, 3x
+        under the strict step's 1e-5 test; capped at 10 um (kappa <= 0.04 / mm: both shipped 50 mm lenses)."""
+        if self.kind() != _abi.SURF_ASPHERIC:
+            return 0.0
+        c, k = float(self.c.item()), float(self.k.item())
+        rr = np.linspace(0.0, float(self.r), 257)
+        q = 1.0 - (1.0 + k) * c * c * rr * rr
+        rr, q = rr[q > 1e-6], q[q > 1e-6]
+        curv = c / q ** 1.5                                   # second r-derivative of the conic sag
+        for j in range(self.ai_degree):                       # + sum a_j (2j+2)(2j+1) r^(2j)
+            n = 2 * (j + 1)
+            curv = curv + float(self.ai[j].item()) * n * (n - 1) * rr ** (n - 2)
+        kappa = float(np.abs(curv).max()) if len(rr) else abs(c)
+        return float(min(1e-2, np.sqrt(4e-6 / max(kappa, 1e-12))))
 
     def ray_reaction(self, ray):
         """Intersect + refract one Ray bundle at this surface (reference: surfaces.py:391-520).

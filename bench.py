@@ -379,10 +379,10 @@ def main_c3(args):
     side = torch.cuda.Stream(dev) if world > 1 else None
 
     def step():
-        r = render_scenes_sharded(rend, gather=True, stream=side)
-        if side is not None:
-            torch.cuda.current_stream(dev).wait_event(r[2])
-        return r[0]
+        full, _, done = render_scenes_sharded(rend, gather=True, stream=side or torch.cuda.current_stream(dev))
+        if done is not None:
+            torch.cuda.current_stream(dev).wait_event(done)
+        return full
 
     for _ in range(warm):
         step()

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AADFF_ABI_VERSION 3
+#define AADFF_ABI_VERSION 4
 
 #define AADFF_EINVAL      (-1)   /* bad shape / size / NULL pointer                  */
 #define AADFF_EUNSUPPORTED (-2)  /* parameter outside what the kernels were built for */
@@ -39,7 +39,7 @@ enum { AADFF_SURF_STOP = 0, AADFF_SURF_SPHERIC = 1, AADFF_SURF_ASPHERIC = 2 };
 
 /* One surface at ONE wavelength.  Host code fills it (deeplens/optics.py: LensTable);
  * values that the reference forms in float64 Python arithmetic and then feeds to fp32
- * tensor ops are rounded to fp32 exactly once, here.  132 bytes. */
+ * tensor ops are rounded to fp32 exactly once, here.  136 bytes. */
 typedef struct aadff_surface {
     float d;            /* vertex z [mm]                            surfaces.py:11-14 */
     float c;            /* curvature 1/roc                          surfaces.py:304   */
@@ -60,6 +60,10 @@ typedef struct aadff_surface {
     float dai[AADFF_MAX_AI];  /* (j+1) * ai[j] in fp32: derivative coefficients surfaces.py:823 */
     float cos2_min_fwd; /* max(0.1, 1 - 1/eta_fwd^2): the two refraction validity tests of surfaces.py:660-663   */
     float cos2_min_bwd; /* (cos^2 i > 0.1 and eta^2 (1 - cos^2 i) < 1) as ONE threshold on cos^2 i (fused kernels) */
+    float newton_step_tol; /* fused kernels: a Newton update shorter than this [mm] ends the loose loop before the strict step
+                              (the reference spends one more evaluation confirming |residual| <= 5e-5, surfaces.py:547).
+                              Must satisfy kappa * tol^2 <= 4e-6 with kappa the largest |d^2 sag / d r^2| over the aperture, so
+                              that the residual the strict step sees stays 3x under its 1e-5 test; <= 1e-2.  0 = never skip. */
 } aadff_surface_t;
 
 /* Per-focus-setting lens state; lives on the device so a whole stack is rendered

@@ -102,6 +102,42 @@ def test_spawn_ranks_launcher(tmp_path, emulate, repo_root):
     assert spawn_ranks([str(script), "7"], 2, emulate=emulate, env=env, timeout=120) == 7
 
 
+def test_spawn_ranks_tears_down_peers_and_has_one_deadline(tmp_path):
+    """a rank that dies at start-up must end the job at once (its peer would otherwise sit in a rendezvous or a
+    collective until the backend's own timeout), and `timeout` is ONE deadline for the whole job, not one per rank."""
+    import time
+    from aadff.dist import spawn_ranks
+    script = tmp_path / "hang.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1' and len(sys.argv) > 1: sys.exit(int(sys.argv[1]))\n"
+                      "open(os.path.join(r'%s', 'pid_' + os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+                      "time.sleep(600)\n" % tmp_path)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    t0 = time.monotonic()
+    assert spawn_ranks([str(script), "9"], 3, env=env, timeout=300) == 9            # rank 1 fails, ranks 0 and 2 hang
+    assert time.monotonic() - t0 < 30
+    t0 = time.monotonic()
+    assert spawn_ranks([str(script)], 3, env=env, timeout=3) == 124                 # all hang: one 3 s deadline, not 3 x 3 s
+    assert time.monotonic() - t0 < 3 + 6.5
+    time.sleep(0.2)
+    for f in os.listdir(tmp_path):
+        if f.startswith("pid_"):
+            pid = int(open(os.path.join(tmp_path, f)).read())
+            assert not os.path.exists(f"/proc/{pid}") or open(f"/proc/{pid}/stat").read().split()[2] == "Z", "rank left running"
+
+
+def test_render_sharded_arity_is_fixed_by_the_stream_argument():
+    """with `stream` the call returns (out, mine, done_or_None) for any world size and for gather=False."""
+    from aadff.dist import render_sharded
+    unit = lambda u: torch.full((2, 2), float(u))
+    a = render_sharded(3, unit, (2, 2))
+    assert len(a) == 2 and a[0].shape == (3, 2, 2)
+    out, mine, done = render_sharded(3, unit, (2, 2), stream=object())               # one rank: nothing runs on the stream
+    assert done is None and mine == [0, 1, 2] and torch.equal(out, a[0])
+    out, mine, done = render_sharded(3, unit, (2, 2), gather=False, stream=object())
+    assert done is None and out.shape == (3, 2, 2)
+
+
 def _config5_worker(rank, world, port, out_dir):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)

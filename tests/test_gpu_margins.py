@@ -133,6 +133,47 @@ def test_margin_bench_config_stack_plan_staged(golden_dir, repo_root, margin):
         margin(f"bench config: slice {k} PSF distance to float64 truth, HIP / reference ({ref:.1e})", ours / ref, 1.5)
 
 
+def test_margin_bench_stack_literal_op_order_build(golden_dir, repo_root, margin, monkeypatch):
+    """the same stack from the build that traces in the reference's OWN formulation
+    (csrc/libaadff_literal.so: one ray per lane, Newton from the vertex plane on every curved surface incl. spheres, IEEE
+    division / sqrt, libm sin/cos, literal d sag/d r^2 and normal, no fma contraction; deeplens/surfaces.py:456-487,523-586),
+    slice by slice against the reference (G9), next to the shipped build's numbers above.  Per slice: distance of the
+    whole rendered slice to the image rendered from G9's PSF map by the same convolution.  The literal order does NOT
+    bring the two wide-PSF slices under 1e-4 (measured 1.36e-4 / 7.8e-5 against 1.53e-4 / 1.08e-4): what separates any
+    float32 implementation from the reference there is not the formulation but which side of the 11x11 window's hard
+    edge (deeplens/monte_carlo.py:37) a few border rays fall on, and that follows the last bit of every sqrt / sin / cos
+    the reference takes from MKL's vector maths (tools/floor_sources.py, oracle/scalar_trace.py)."""
+    path = os.path.join(os.path.dirname(_abi.LIB_PATH), "libaadff_literal.so")
+    if not os.path.exists(path):
+        pytest.skip("csrc/libaadff_literal.so not built (make -C csrc libaadff_literal.so)")
+    g = np.load(os.path.join(golden_dir, "g9_stack_m1_1024.npz"))
+    fl = np.load(os.path.join(golden_dir, "g13_fp32_floor.npz"))
+    H = W = 1024
+    S = 10
+    img = tt(synth_rgb(H, W, seed=1234))[None].to(DEV)
+    depth = synth_depth_mm(H, W, seed=5678)
+    dbar, fds = -float(depth.mean()), -np.linspace(depth.min(), depth.max(), S)
+    ref_imgs = [rp.render_psf_map(img, tt(g["psf_maps"][k]).to(DEV), 11)[0].cpu().numpy().astype(np.float64) for k in range(S)]
+    worst = {}
+    for label, lib in (("shipped", None), ("literal", _abi.load_library(path))):
+        if lib is not None:
+            monkeypatch.setattr(_abi, "_lib", lib)
+        lens = Lensgroup(lp(repo_root), sensor_res=(H, W), device=DEV)
+        plan = StackPlan(lens, S, H, W, 1, 3, 11, 11, 2048)
+        torch.manual_seed(0)
+        out = render_focal_stack_m1(lens, img, dbar, fds, 11, 11, 2048, plan=plan, update_lens=False)
+        plan.check_flags()
+        s = out[0].cpu().numpy().astype(np.float64)
+        per = [float(np.linalg.norm(s[:, k] - ref_imgs[k]) / np.linalg.norm(ref_imgs[k])) for k in range(S)]
+        num = sum(float(((s[:, k] - ref_imgs[k]) ** 2).sum()) for k in range(S))
+        den = sum(float((ref_imgs[k] ** 2).sum()) for k in range(S))
+        margin(f"{label} build: whole stack, full-image rel-L2 vs reference PSFs", np.sqrt(num / den), 1e-4)
+        for k in range(S):
+            margin(f"{label} build: slice {k} full-image rel-L2 (fp32 floor {fl['img_floor'][k]:.1e})", per[k], max(1e-4, 2 * fl["img_floor"][k]))
+        worst[label] = max(per)
+    monkeypatch.undo()
+
+
 def test_margin_training_data(golden_dir, repo_root, margin):
     """PSFNet.get_training_data vs the reference's (G10): identical network inputs (host RNG order: np choice, refocus
     draws, rand x, rand y, randn z, psf draws), ray-traced target PSFs within the PSF tolerance."""

@@ -91,6 +91,38 @@ def test_g14_named_glasses(golden_dir, repo_root):
     assert np.abs(pm.numpy() - gm["psf_map"]).max() <= ATOL
 
 
+def test_scalar_restatement_tracks_the_tensor_oracle(repo_root):
+    """oracle/scalar_trace.py - the reference's surface arithmetic one float32 operation at a time - against the tensor
+    oracle on the same batch: identical validity everywhere, the first surface's Newton root (10 batch-wide iterations
+    from 1.5 m away: where the 1e-4 mm of hit noise is born) bit-equal on every ray, and >= 94 % of the sensor-side ray
+    states bit-equal after all 12 surfaces.  The rest differ in the last bit because torch's CPU sqrt is MKL's vector
+    sqrt, which is not correctly rounded (0.7 % of arguments): no implementation without that library reproduces the
+    reference bit for bit, which bounds what a 'strict' float32 mode could match."""
+    from oracle import scalar_trace as st
+    lens = OracleLens(lens_path(repo_root, "rf50mm"), sensor_res=(1024, 1024))
+    pobj = lens.object_points(lens.point_source_grid(-1500.0, 11).reshape(-1, 3))
+    torch.manual_seed(5)
+    rays = lens.sample_from_points(pobj, spp=128, wvln=0.589)
+    surfs = st.surfaces_from_oracle(lens, 0.589)
+    o = tuple(np.ascontiguousarray(rays.o[..., i].numpy()) for i in range(3))
+    d = tuple(np.ascontiguousarray(rays.d[..., i].numpy()) for i in range(3))
+    ra = rays.ra.numpy().copy()
+    its = []
+    for i, (so, ss) in enumerate(zip(lens.surfaces, surfs)):
+        rays = so.react(rays)
+        o, d, ra, it = st.react(ss, o, d, ra, True)
+        its.append(it)
+        assert np.array_equal(ra, rays.ra.numpy()), f"surface {i} validity"
+        alive = ra > 0
+        same_o = (np.stack(o, -1) == rays.o.numpy()).all(-1)[alive].mean()
+        same_d = (np.stack(d, -1) == rays.d.numpy()).all(-1)[alive].mean()
+        if i == 0:
+            assert same_o == 1.0 and same_d >= 0.99
+        assert np.abs(np.stack(o, -1) - rays.o.numpy())[alive].max() <= 5e-4      # far from bit-equal never (1e-4 mm noise scale)
+    assert its[0] == 10 and its[5] == 0 and max(its[1:4]) <= 5
+    assert same_o >= 0.94 and same_d >= 0.94
+
+
 def test_appendix_d_known_answers(repo_root):
     """SURVEY.md Appendix D values measured on the reference (independent of the fixtures)."""
     lens = OracleLens(lens_path(repo_root, "rf50mm"), sensor_res=(1024, 1024))
