@@ -126,7 +126,8 @@ def all_reduce_max(value):
 
 
 def unit_order(full, n_units, world, share):
-    """rank-major [world*share, ...] (what the all-gather delivers) -> unit order u = i*world + r."""
+    """rank-major [world*share, ...] (what ONE monolithic all-gather delivers) -> unit order u = i*world + r.  (The sharded
+    renderers no longer need it: they gather row by row into a buffer that is in unit order already.)"""
     shape = tuple(full.shape[1:])
     return full.reshape((world, share) + shape).transpose(0, 1).reshape((world * share,) + shape)[:n_units]
 
@@ -168,35 +169,52 @@ class GatherRing:
         torch.cuda.current_stream(self.dev).wait_stream(self.stream)
 
 
+def gather_row(row, rank):
+    """Complete one row `[world, *unit]` of the unit-order buffer: rank r's unit sits at row[r]; ONE all-gather fills the
+    others.  RCCL gathers in place (send buffer = receive buffer + rank x count); gloo gets a copy of the own unit."""
+    all_gather_into(row, row[rank] if not _host_backend() else row[rank].clone())
+
+
 def render_sharded(n_units, render_unit, unit_shape, dtype=torch.float32, device="cpu", gather=True, stream=None):
     """Render this rank's units with `render_unit(u) -> tensor[unit_shape]` and, if `gather`,
-    return the full `[n_units, *unit_shape]` tensor on every rank (None otherwise: the consumer is
-    rank-local, e.g. DDP training).  With `stream` the all-gather AND the reorder into unit order run on that
-    side stream and the call ALWAYS returns three values `(out, mine, done)`: `done` is the event the consumer must wait
+    return the full `[n_units, *unit_shape]` tensor on every rank (the rank's own `[share, *unit_shape]` units otherwise:
+    the consumer is rank-local, e.g. DDP training).  The gather buffer is `[share, world, *unit_shape]` - row i holds units
+    i*world .. i*world + world - 1, i.e. unit order - and row i is completed by one all-gather as soon as this rank's unit
+    of that row is rendered (per-row chunks, no reorder).  With `stream` the gathers run on that side stream
+    and the call ALWAYS returns three values `(out, mine, done)`: `done` is the event the consumer must wait
     on (the caller may render the next batch meanwhile), or None when nothing ran on the side stream (one rank, or
     `gather=False`).  Without `stream` it returns `(out, mine)` and the result is ready on the current stream."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     share = padded_share(n_units, world)
-    local = torch.zeros((share,) + tuple(unit_shape), dtype=dtype, device=device)
     mine = shard_units(n_units, rank, world)
-    for i, u in enumerate(mine):
-        local[i].copy_(render_unit(u))
-    if not gather:
-        return (local, mine) if stream is None else (local, mine, None)
-    if world == 1:
-        return (local[:n_units], mine) if stream is None else (local[:n_units], mine, None)
-    full = torch.empty((world * share,) + tuple(unit_shape), dtype=dtype, device=device)
+    if not gather or world == 1:
+        local = torch.zeros((share,) + tuple(unit_shape), dtype=dtype, device=device)
+        for i, u in enumerate(mine):
+            local[i].copy_(render_unit(u))
+        out = local[:n_units] if (gather and world == 1) else local
+        return (out, mine) if stream is None else (out, mine, None)
+    full = torch.zeros((share * world,) + tuple(unit_shape), dtype=dtype, device=device)
+    rows = full.view((share, world) + tuple(unit_shape))
+    on_gpu = full.is_cuda
+    cur = torch.cuda.current_stream(device) if on_gpu else None
+    if stream is not None and on_gpu:
+        full.record_stream(stream)
+    for i in range(share):
+        if i < len(mine):
+            rows[i, rank].copy_(render_unit(mine[i]))
+        if stream is not None and on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            stream.wait_event(ev)
+            with torch.cuda.stream(stream):
+                gather_row(rows[i], rank)
+        else:
+            gather_row(rows[i], rank)
     if stream is None:
-        all_gather_into(full, local)
-        return unit_order(full, n_units, world, share), mine
-    stream.wait_stream(torch.cuda.current_stream(device))
-    local.record_stream(stream)
-    full.record_stream(stream)
-    with torch.cuda.stream(stream):
-        all_gather_into(full, local)
-        out = unit_order(full, n_units, world, share).contiguous()
+        return full[:n_units], mine
+    done = None
+    if on_gpu:
         done = torch.cuda.Event()
         done.record(stream)
-    out.record_stream(torch.cuda.current_stream(device))        # the consumer stream uses it after waiting on `done`
-    return out, mine, done
+    return full[:n_units], mine, done

@@ -210,10 +210,14 @@ class StackPlan:
 
 @torch.no_grad()
 def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, spp=GEO_SPP, plan=None,
-                          return_maps=False, update_lens=True):
+                          return_maps=False, update_lens=True, dest=None):
     """[B,C,S,H,W] aberrated focal stack of `img` [B,C,H,W] for S focus distances (mm < 0),
     all scene points on one depth plane (mm < 0).  Three kernel launches, no host
-    synchronisation; with a reused `plan` the output buffer is reused too."""
+    synchronisation; with a reused `plan` the output buffer is reused too.
+
+    `dest=(units, first, step)` (B = 1): slice k is written as the [C,H,W] unit `units[first + k*step]` of a caller's
+    contiguous [M,C,H,W] buffer instead of into the plan's stack (aadff_render_psf_map_stack_strided) - a sharded run
+    renders straight into its all-gather buffer; the return value is then `units`."""
     focus = [float(f) for f in np.asarray(focus_mm, dtype=np.float64).reshape(-1)]
     S = len(focus)
     B, C_, H, W = img.shape
@@ -277,8 +281,15 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
         kev = plan.conv_kernel_events
         if kev is not None:
             _abi.call("aadff_time_next_launch", C.c_void_p(kev[0].cuda_event), C.c_void_p(kev[1].cuda_event))
-        _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(plan.psf_maps), _abi.ptr(plan.out), B, C_, S,
-                  H, W, grid, ks, st)
+        if dest is None:
+            _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(plan.psf_maps), _abi.ptr(plan.out), B, C_, S,
+                      H, W, grid, ks, st)
+        else:
+            units, first, ustep = dest
+            assert B == 1 and units.is_cuda and units.is_contiguous() and units.dtype == torch.float32 and tuple(units.shape[1:]) == (C_, H, W)
+            assert ustep >= 1 and 0 <= first and first + (S - 1) * ustep < units.shape[0], "dest units out of range"
+            _abi.call("aadff_render_psf_map_stack_strided", _abi.ptr(x), _abi.ptr(plan.psf_maps),
+                      C.c_void_p(units.data_ptr() + 4 * first * C_ * H * W), H * W, ustep * C_ * H * W, 1, C_, S, H, W, grid, ks, st)
         if plan.conv_events is not None:
             plan.conv_events[1].record()
         if stage is not None:
@@ -290,7 +301,8 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
         lens._state_stale = True
     if own_plan:
         plan.check_flags()                               # one-shot calls: same sync point as the reference's asserts
-    return (plan.out, plan.psf_maps) if return_maps else plan.out
+    res = plan.out if dest is None else dest[0]
+    return (res, plan.psf_maps) if return_maps else res
 
 
 class StackPipeline:
@@ -489,14 +501,19 @@ class SceneUnitRenderer:
     def n_units(self):
         return len(self.scenes) * self.S
 
-    def render(self, units, out=None):
-        """`units`: unit ids in any order -> [len(units), C, H, W] in that order (into `out` when given)."""
+    def render(self, units, out=None, out_index=None, after_group=None):
+        """`units`: unit ids in any order -> `out[out_index[k]]` = unit `units[k]` (default: `out` [len(units), C, H, W],
+        out_index[k] = k).  The slices of one scene whose destinations form an arithmetic progression - always the case for
+        a rank's share in ascending order, in the local layout and in the all-gather buffer alike - are written by the
+        convolution itself (aadff_render_psf_map_stack_strided); anything else is rendered into the plan's stack and copied.
+        `after_group(positions)` is called after the launches of each scene group (its destinations are then queued on the
+        current stream): the sharded renderer starts the group's all-gather chunks from it."""
         lens, S = self.lens, self.S
         by_scene = {}
         for pos, u in enumerate(units):
-            by_scene.setdefault(u // S, []).append((u % S, pos))
+            by_scene.setdefault(u // S, []).append((u % S, pos if out_index is None else out_index[pos]))
         img0 = self.scenes[0][0]
-        _, C_, H, W = img0.shape
+        B, C_, H, W = img0.shape
         dev = lens._gpu()
         if out is None:
             out = torch.empty((len(units), C_, H, W), dtype=torch.float32, device=dev)
@@ -507,6 +524,7 @@ class SceneUnitRenderer:
                 focus = [float(f) for f in np.asarray(focus, dtype=np.float64).reshape(-1)]
                 assert len(focus) == S
                 sl = [k for k, _ in items]
+                dst = [q for _, q in items]
                 self.seed_scene(scene)
                 block = saved.rand_block([S * self.per]).reshape(S, self.per)        # the whole stack's draws
                 lens.sampler = PresetSampler(block, rows=sl)
@@ -514,10 +532,16 @@ class SceneUnitRenderer:
                 plan = self.plans.get(n)
                 if plan is None:
                     plan = self.plans[n] = StackPlan(lens, n, H, W, 1, C_, self.grid, self.ks, self.spp)
+                step = dst[1] - dst[0] if n > 1 else 1
+                direct = (B == 1 and step >= 1 and all(dst[i] == dst[0] + i * step for i in range(n)) and out.is_cuda
+                          and out.is_contiguous() and out.dtype == torch.float32 and step * C_ * H * W < (1 << 28))
                 st = render_focal_stack_m1(lens, img, depth_plane_mm, [focus[k] for k in sl], self.grid, self.ks, self.spp,
-                                           plan=plan, update_lens=False)           # [1,C,n,H,W]
-                for i, (_, pos) in enumerate(items):
-                    out[pos].copy_(st[0, :, i])
+                                           plan=plan, update_lens=False, dest=(out, dst[0], step) if direct else None)
+                if not direct:
+                    for i, q in enumerate(dst):
+                        out[q].copy_(st[0, :, i])
+                if after_group is not None:
+                    after_group(dst)
         finally:
             lens.sampler = saved
         return out
@@ -528,9 +552,16 @@ class SceneUnitRenderer:
 
 
 def render_scenes_sharded(renderer, gather=True, stream=None):
-    """This rank's share of all (scene, slice) units through the HIP renderer and, with `gather`, ONE all-gather that
-    leaves the full `[n_scenes*S, C, H, W]` set in unit order on every rank (aadff.dist.render_sharded semantics: with
-    `stream` always `(out, mine, done_or_None)`, without it `(out, mine)`)."""
+    """This rank's share of all (scene, slice) units through the HIP renderer and, with `gather`, the full
+    `[n_scenes*S, C, H, W]` set in unit order on every rank.  Returns `(out, mine)`, or with `stream`
+    always `(out, mine, done_or_None)` (aadff.dist.render_sharded semantics).
+
+    No copy and no reorder anywhere: the buffer is laid out `[share, world, C, H, W]`, whose row i holds the units
+    i*world .. i*world + world - 1 - rank r's i-th unit is unit i*world + r, so this IS unit order.  The convolution
+    writes each of this rank's slices straight to its place (`aadff_render_psf_map_stack_strided`, slice stride =
+    world units), and row i is completed by ONE in-place all-gather of that row (12.6 MB per rank at 1024^2) as soon as
+    the scene group that produced it has been launched: with `stream` the gathers run on that side stream, overlapped
+    with the rendering of the following scenes, per-row chunks instead of one monolithic collective at the end."""
     import torch.distributed as dist
     from . import dist as adist
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -540,25 +571,37 @@ def render_scenes_sharded(renderer, gather=True, stream=None):
     share = adist.padded_share(n, world)
     img0 = renderer.scenes[0][0]
     dev = renderer.lens._gpu()
-    local = torch.empty((share,) + tuple(img0.shape[1:]), dtype=torch.float32, device=dev)
+    unit_shape = tuple(img0.shape[1:])
+    if not gather or world == 1:
+        local = torch.empty((share,) + unit_shape, dtype=torch.float32, device=dev)
+        renderer.render(mine, out=local[:len(mine)])
+        return (local[:len(mine)] if world == 1 else local, mine) if stream is None else (local[:len(mine)] if world == 1 else local, mine, None)
+    full = torch.empty((share * world,) + unit_shape, dtype=torch.float32, device=dev)
+    rows = full.view((share, world) + unit_shape)
     if len(mine) < share:
-        local[len(mine):].zero_()                     # padding units of the equal-share all-gather (n not a multiple of world)
-    renderer.render(mine, out=local[:len(mine)])
-    if not gather:
-        return (local, mine) if stream is None else (local, mine, None)
-    if world == 1:
-        return (local[:n], mine) if stream is None else (local[:n], mine, None)
-    full = torch.empty((world * share,) + tuple(local.shape[1:]), dtype=torch.float32, device=dev)
+        rows[len(mine):, rank].zero_()                # padding units of the equal-share gather (n not a multiple of world)
+    cur = torch.cuda.current_stream(dev)
+    side = stream if stream is not None else cur
+    if stream is not None:
+        full.record_stream(stream)
+
+    def gather_rows(idx):
+        if side is not cur:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            side.wait_event(ev)
+        with torch.cuda.stream(side):
+            for i in idx:
+                adist.gather_row(rows[i], rank)
+
+    def after_group(dst):
+        gather_rows([q // world for q in dst])        # destinations of this rank are full[i*world + rank]
+
+    renderer.render(mine, out=full, out_index=[i * world + rank for i in range(len(mine))], after_group=after_group)
+    if len(mine) < share:
+        gather_rows(range(len(mine), share))
     if stream is None:
-        adist.all_gather_into(full, local)
-        return adist.unit_order(full, n, world, share), mine
-    stream.wait_stream(torch.cuda.current_stream(dev))
-    local.record_stream(stream)
-    full.record_stream(stream)
-    with torch.cuda.stream(stream):
-        adist.all_gather_into(full, local)
-        res = adist.unit_order(full, n, world, share).contiguous()
-        done = torch.cuda.Event()
-        done.record(stream)
-    res.record_stream(torch.cuda.current_stream(dev))
-    return res, mine, done
+        return full[:n], mine
+    done = torch.cuda.Event()
+    done.record(stream)
+    return full[:n], mine, done

@@ -105,7 +105,7 @@ struct ConvCfg {
 // Units are one slice long (short tail) yet NW waves share each 16 KB of LDS (>= 4 waves per SIMD).
 template <int KS, int NW>
 __global__ __launch_bounds__(64 * NW, AADFF_CONV_MINWAVES) void conv_psf_map_kernel(
-    const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, int C, int S, int H, int W,
+    const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
     int grid, int ntx, int nty, PatchBounds pb) {
     using Cfg = ConvCfg<KS>;
     constexpr int PA = Cfg::PA, PB = Cfg::PB;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64 * NW, AADFF_CONV_MINWAVES) void conv_psf_map_ker
         }
 
         const int x = x0 + CX * q, yb = y0 + RR * k;
-        float* o = out + (((size_t)bc * S + s) * H + yb) * W + x;
+        float* o = out + (size_t)bc * sbc + (size_t)s * ss + (size_t)yb * W + x;
         const bool m0 = x < x_hi, m1 = x + 1 < x_hi, m2 = x + 2 < x_hi, m3 = x + 3 < x_hi;
 #pragma unroll
         for (int r = 0; r < RR; ++r) {
@@ -267,7 +267,7 @@ __device__ __forceinline__ void pow2_scale(float amax, float& s, float& inv) {
 
 template <int KS, int NW, int SPW>
 __global__ __launch_bounds__(64 * NW) void conv_psf_map_mfma_kernel(
-    const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, int C, int S, int H, int W,
+    const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
     int grid, int ntx, int nty, PatchBounds pb) {
     constexpr int PAD = KS / 2, TWP = TW + KS - 1, THP = TH + KS - 1, P = 48;
     static_assert(16 + KS - 1 <= 32 && TWP <= P, "Toeplitz band must fit K = 32");
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(64 * NW) void conv_psf_map_mfma_kernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     const float inv = isx * isw;
-    float* oplane = out + ((size_t)bc * S + s) * H * W;
+    float* oplane = out + (size_t)bc * sbc + (size_t)s * ss;
     // tap row u outermost: one Toeplitz fragment pair live at a time, four 16x16 block accumulators
     constexpr int NBY = TH / 16, NBX = TW / 16;
     float4v acc[NBY][NBX];
@@ -459,7 +459,7 @@ __device__ __forceinline__ void lds_read16(uint2v& a, uint2v& b, unsigned byte_a
 // of its own chunk and walks the band's row pairs.
 template <int RB, int NC>
 __global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
-    const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, int C, int S, int H, int W,
+    const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
     int grid, int ntx, int nty, int npass, PatchBounds pb, int stagger) {
     using namespace sb;
     if (stagger) {
@@ -605,9 +605,9 @@ __global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
 
     const int s_out = s_base + chunk * 4 + kg;
     const bool s_ok = s_out < S;
-    // stores: wave-uniform 64-bit base (first slice of the chunk) + 32-bit per-lane byte offset (host checks 16 H W < 2^32)
-    char* wbase = reinterpret_cast<char*>(out + ((size_t)bc * S + s_base + chunk * 4) * H * W);
-    const unsigned w4 = (unsigned)W * 4u;
+    // stores: wave-uniform 64-bit base (first slice of the chunk) + 32-bit per-lane byte offset (host checks 16 x slice stride + 4 H W < 2^32)
+    char* wbase = reinterpret_cast<char*>(out + (size_t)bc * sbc + (size_t)(s_base + chunk * 4) * ss);
+    const unsigned w4 = (unsigned)W * 4u, koff = (unsigned)kg * (unsigned)(ss * 4);   // slice kg of the chunk
     bool pair_ok[3], one_ok[3];
 #pragma unroll
     for (int cb = 0; cb < 3; ++cb) {
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
         const unsigned rowb_next = (unsigned)((rpi + 1 < npairs ? rpi + 1 : rpi) * RPP * 4);
         const int yl = 2 * rpi;
         const bool row1 = y0 + yl + 1 < y_hi;           // row 0 of the pair is valid by construction of npairs
-        const unsigned loff = ((unsigned)kg * (unsigned)H + (unsigned)(y0 + yl)) * w4 + (unsigned)(x0 + 2 * lo4) * 4u;
+        const unsigned loff = koff + (unsigned)(y0 + yl) * w4 + (unsigned)(x0 + 2 * lo4) * 4u;
         float4v acc;
         auto step_fn = [&](auto stepc) {
             constexpr int step = decltype(stepc)::value, cb = step / 5, st = step % 5, bf = step % 3;
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_psf_map_generic_kernel(const float* __restrict__ img,
                                                                     const float* __restrict__ psf,
-                                                                    float* __restrict__ out, int C, int S,
+                                                                    float* __restrict__ out, long sbc, long ss, int C, int S,
                                                                     int H, int W, int grid, int ks, int ntx,
                                                                     int nty, PatchBounds pb) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(256) void conv_psf_map_generic_kernel(const float* 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[r] = fmaf(wv, tile[(ly * 4 + r + u) * twp + lx + v], acc[r]);
             }
-        float* oplane = out + ((size_t)bc * S + s) * H * W;
+        float* oplane = out + (size_t)bc * sbc + (size_t)s * ss;
         const int x = x0 + lx;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void conv_psf_map_generic_kernel(const float* 
 thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
 
 template <int KS>
-static int launch_fast(const float* img, const float* psf, float* out, int B, int C, int S, int H, int W,
+static int launch_fast(const float* img, const float* psf, float* out, long sbc, long ss, int B, int C, int S, int H, int W,
                        int grid, int ntx, int nty, const PatchBounds& pb, hipStream_t st) {
     // waves per workgroup = slices of one chunk (one slice per wave): least padding, at most 5
     int nw = 1, best = 1 << 30;
@@ -777,7 +777,8 @@ static int launch_fast(const float* img, const float* psf, float* out, int B, in
             }
             const int sntx = (mw + sb::TCOLS - 1) / sb::TCOLS, snty = (mh + RB - 1) / RB;
             AADFF_CHECK_ARG((size_t)B * C * npass <= 65535 && (size_t)snty * grid <= 65535, "render_psf_map: grid too large");
-            AADFF_CHECK_ARG((size_t)H * W <= ((size_t)1 << 27), "render_psf_map: image planes above 2^27 pixels are not supported on the stack path");
+            AADFF_CHECK_ARG((size_t)H * W <= ((size_t)1 << 27) && 16 * (size_t)ss + 4 * (size_t)H * W < ((size_t)1 << 32),
+                            "render_psf_map: image planes above 2^27 pixels / slice strides above 2^28 elements are not supported on the stack path");
             PatchBounds pbs = pb;
             pbs.m_ntx = magic_of(sntx); pbs.m_nty = magic_of(snty); pbs.m_nchunk = magic_of(npass); pbs.m_c = magic_of(C);
             dim3 gs(sntx * grid, snty * grid, B * C * npass);
@@ -786,8 +787,8 @@ static int launch_fast(const float* img, const float* psf, float* out, int B, in
             hipEvent_t ev0 = g_time_start, ev1 = g_time_stop;
             g_time_start = g_time_stop = nullptr;
 #define AADFF_LAUNCH_S(NCV) do { \
-                if (ev0) hipExtLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV>), gs, dim3(64 * NCV), 0, st, ev0, ev1, 0, img, psf, out, C, S, H, W, grid, sntx, snty, npass, pbs, stagger); \
-                else hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV>), gs, dim3(64 * NCV), 0, st, img, psf, out, C, S, H, W, grid, sntx, snty, npass, pbs, stagger); } while (0)
+                if (ev0) hipExtLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV>), gs, dim3(64 * NCV), 0, st, ev0, ev1, 0, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, snty, npass, pbs, stagger); \
+                else hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV>), gs, dim3(64 * NCV), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, snty, npass, pbs, stagger); } while (0)
             switch (nc) {
                 case 1: AADFF_LAUNCH_S(1); break;
                 case 2: AADFF_LAUNCH_S(2); break;
@@ -804,7 +805,7 @@ static int launch_fast(const float* img, const float* psf, float* out, int B, in
             dim3 gm(ntx * grid, nty * grid, B * C * nchunk_m);
             PatchBounds pbmm = pbm;
             pbmm.m_nchunk = magic_of(nchunk_m);
-#define AADFF_LAUNCH_M(NWV) hipLaunchKernelGGL((conv_psf_map_mfma_kernel<KS, NWV, AADFF_MFMA_SPW>), gm, dim3(64 * NWV), 0, st, img, psf, out, C, S, H, W, grid, ntx, nty, pbmm)
+#define AADFF_LAUNCH_M(NWV) hipLaunchKernelGGL((conv_psf_map_mfma_kernel<KS, NWV, AADFF_MFMA_SPW>), gm, dim3(64 * NWV), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, ntx, nty, pbmm)
             switch (nw) {
                 case 5: if constexpr (KS == 11) { AADFF_LAUNCH_M(5); break; }
                 case 4: AADFF_LAUNCH_M(4); break;
@@ -816,7 +817,7 @@ static int launch_fast(const float* img, const float* psf, float* out, int B, in
             return 0;
         }
     }
-#define AADFF_LAUNCH(NWV) hipLaunchKernelGGL((conv_psf_map_kernel<KS, NWV>), g, dim3(64 * NWV), 0, st, img, psf, out, C, S, H, W, grid, ntx, nty, pbm)
+#define AADFF_LAUNCH(NWV) hipLaunchKernelGGL((conv_psf_map_kernel<KS, NWV>), g, dim3(64 * NWV), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, ntx, nty, pbm)
     if constexpr (KS == 11) {
         switch (nw) {
             case 5: AADFF_LAUNCH(5); break;
@@ -836,7 +837,8 @@ static int launch_fast(const float* img, const float* psf, float* out, int B, in
     return 0;
 }
 
-static int conv_dispatch(const float* img, const float* psf, float* out, int B, int C, int S, int H, int W,
+// out plane of (b, c, s) starts at out + (b*C + c)*sbc + s*ss (elements); the contiguous [B,C,S,H,W] stack is sbc = S*H*W, ss = H*W
+static int conv_dispatch(const float* img, const float* psf, float* out, long sbc, long ss, int B, int C, int S, int H, int W,
                          int grid, int ks, hipStream_t st) {
     AADFF_CHECK_ARG(img && psf && out, "render_psf_map: NULL pointer");
     AADFF_CHECK_ARG(B > 0 && C > 0 && S > 0 && H > 0 && W > 0, "render_psf_map: empty tensor (B=%d C=%d S=%d H=%d W=%d)", B, C, S, H, W);
@@ -858,14 +860,14 @@ static int conv_dispatch(const float* img, const float* psf, float* out, int B, 
     }
     const int ntx = (mw + TW - 1) / TW, nty = (mh + TH - 1) / TH;
     switch (ks) {
-#define AADFF_CASE(K) case K: { int rc = launch_fast<K>(img, psf, out, B, C, S, H, W, grid, ntx, nty, pb, st); if (rc) return rc; } break;
+#define AADFF_CASE(K) case K: { int rc = launch_fast<K>(img, psf, out, sbc, ss, B, C, S, H, W, grid, ntx, nty, pb, st); if (rc) return rc; } break;
         AADFF_CASE(3) AADFF_CASE(5) AADFF_CASE(7) AADFF_CASE(9) AADFF_CASE(11) AADFF_CASE(13)
         AADFF_CASE(15) AADFF_CASE(21)
 #undef AADFF_CASE
         default: {
             dim3 g(ntx * grid, nty * grid, B * C);
             const size_t lds = ((size_t)(TH + ks - 1) * (TW + ks - 1) + (size_t)ks * ks) * sizeof(float);
-            hipLaunchKernelGGL(conv_psf_map_generic_kernel, g, dim3(256), lds, st, img, psf, out, C, S, H, W, grid,
+            hipLaunchKernelGGL(conv_psf_map_generic_kernel, g, dim3(256), lds, st, img, psf, out, sbc, ss, C, S, H, W, grid,
                                ks, ntx, nty, pb);
         }
     }
@@ -1193,12 +1195,11 @@ int aadff_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_len) {
 
 int aadff_render_psf_map(const float* img, const float* psf_map, float* out, int B, int C, int H, int W, int grid,
                          int ks, aadff_stream_t stream) {
-    return conv_dispatch(img, psf_map, out, B, C, 1, H, W, grid, ks, (hipStream_t)stream);
+    return conv_dispatch(img, psf_map, out, (long)H * W, (long)H * W, B, C, 1, H, W, grid, ks, (hipStream_t)stream);
 }
 
-int aadff_render_psf_map_stack(const float* img, const float* psf_maps, float* out, int B, int C, int S, int H,
-                               int W, int grid, int ks, aadff_stream_t stream) {
-    hipStream_t st = (hipStream_t)stream;
+static int stack_launch(const float* img, const float* psf_maps, float* out, long sbc, long ss, int B, int C, int S, int H,
+                        int W, int grid, int ks, hipStream_t st) {
     hipEvent_t e0 = g_time_start, e1 = g_time_stop;
     // armed by aadff_time_next_launch: the slice-batched launch attaches the events to its dispatch; every other path
     // records them around the call
@@ -1207,10 +1208,25 @@ int aadff_render_psf_map_stack(const float* img, const float* psf_maps, float* o
         g_time_start = g_time_stop = nullptr;
         AADFF_CHECK_HIP(hipEventRecord(e0, st));
     }
-    const int rc = conv_dispatch(img, psf_maps, out, B, C, S, H, W, grid, ks, st);
+    const int rc = conv_dispatch(img, psf_maps, out, sbc, ss, B, C, S, H, W, grid, ks, st);
     g_time_start = g_time_stop = nullptr;
     if (bracket && rc == 0) AADFF_CHECK_HIP(hipEventRecord(e1, st));
     return rc;
+}
+
+int aadff_render_psf_map_stack(const float* img, const float* psf_maps, float* out, int B, int C, int S, int H,
+                               int W, int grid, int ks, aadff_stream_t stream) {
+    return stack_launch(img, psf_maps, out, (long)S * H * W, (long)H * W, B, C, S, H, W, grid, ks, (hipStream_t)stream);
+}
+
+int aadff_render_psf_map_stack_strided(const float* img, const float* psf_maps, float* out, long stride_bc, long stride_s,
+                                       int B, int C, int S, int H, int W, int grid, int ks, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(stride_bc >= (long)H * W && stride_s >= (long)H * W, "render_psf_map_stack_strided: strides %ld / %ld below one plane (%d x %d)",
+                    stride_bc, stride_s, H, W);
+    // the S*B*C planes must not overlap: either slices are innermost (stride_bc >= S*stride_s) or (b, c) planes are (stride_s >= B*C*stride_bc)
+    AADFF_CHECK_ARG(stride_bc >= (long)S * stride_s || stride_s >= (long)B * C * stride_bc,
+                    "render_psf_map_stack_strided: planes overlap (stride_bc %ld, stride_s %ld, B*C %d, S %d)", stride_bc, stride_s, B * C, S);
+    return stack_launch(img, psf_maps, out, stride_bc, stride_s, B, C, S, H, W, grid, ks, (hipStream_t)stream);
 }
 
 int aadff_time_next_launch(void* start_event, void* stop_event) {
@@ -1223,7 +1239,7 @@ int aadff_time_next_launch(void* start_event, void* stop_event) {
 int aadff_render_psf(const float* img, const float* psf, float* out, int B, int C, int H, int W, int ks,
                      aadff_stream_t stream) {
     // a 1x1 PSF grid: the [C,ks,ks] PSF is its own map (render_psf.py:12-28 vs :31-73)
-    return conv_dispatch(img, psf, out, B, C, 1, H, W, 1, ks, (hipStream_t)stream);
+    return conv_dispatch(img, psf, out, (long)H * W, (long)H * W, B, C, 1, H, W, 1, ks, (hipStream_t)stream);
 }
 
 int aadff_local_psf_render(const float* img, const float* psf, float* out, int B, int C, int H, int W, int ks,

@@ -92,17 +92,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--device-rng", action="store_true", help="draw pupil samples on the GPU (not sample-comparable)")
     ap.add_argument("--spinup-s", type=float, default=0.3, help="untimed device spin-up before the warm-up steps [s]")
-    ap.add_argument("--conv-events-every", type=int, default=8,
-                    help="bracket the conv launch with HIP events on every n-th timed step (an event pair costs ~6 us of queue gap)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("AADFF_BENCH_STREAMS", "1")),
-                    help="M1: stacks in flight on this many HIP streams of the one GPU (aadff.focal_stack.StackPipeline).  Default 1: "
-                         "the PSF-grid and convolution kernels run one after the other, so the HIP-event duration of the convolution "
-                         "is the kernel's own (the roofline block).  --streams 2: two stacks in flight (higher throughput, per-kernel "
-                         "durations no longer meaningful)")
-    ap.add_argument("--two-stream-leg", action="store_true",
-                    help="M1, with --streams 1: after the timed region also measure the same stacks with two in flight on two streams and "
-                         "report it as `throughput_two_streams` (untimed extra; off by default so that a profile of the default command "
-                         "contains only the contract's launches)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("AADFF_BENCH_STREAMS", "2")),
+                    help="M1: stacks in flight on this many HIP streams of the one GPU (aadff.focal_stack.StackPipeline).  Default 2: the "
+                         "VALU-bound PSF-grid kernel of stack i+1 runs beside the LDS/MFMA/HBM-bound convolution of stack i and fills the "
+                         "dispatch gaps and kernel tails (+8-10 %% over one stream).  The per-kernel durations of the `roofline` and "
+                         "`trace` blocks are measured in an untimed SOLO leg after the timed region (one stack at a time, device idle "
+                         "before each, HIP events attached to the kernels' own dispatches), because kernels of different stacks share "
+                         "the device in the timed region.  --streams 1: every kernel alone on the device throughout (round-2 default; "
+                         "rocprofv3 --stats of that command reproduces the solo-leg durations)")
+    ap.add_argument("--solo-steps", type=int, default=40, help="stacks of the untimed solo leg that times the convolution and PSF-grid kernels")
     ap.add_argument("--mode", choices=("m1", "m2", "fit", "c3"), default="m1",
                     help="m1 (default, BASELINE.json metric): ray-traced PSF grid + patch convolution; "
                          "m2: RGB-D stack through the PSF surrogate network (PSFNet.render, SURVEY.md 8f-1); "
@@ -151,10 +149,8 @@ def main():
     n_streams = 1 if (world > 1 and args.gather) else max(1, args.streams)
     pipe = StackPipeline(lens, S, H, W, 1, 3, GRID, KS, SPP, depth=n_streams)
     plan = pipe.plans[0]
-    # On every `--conv-events-every`-th timed step the convolution kernel carries two HIP events ON its dispatch
-    # (aadff_time_next_launch -> hipExtLaunchKernelGGL): the kernel's own begin-to-end time on its launch stream,
-    # the quantity rocprofv3 reports.  On the steps half-way between, two stream events BRACKET the launch instead (the round-1
-    # method: adds the two dispatch gaps); reported beside it.
+    # Kernel durations: HIP events ATTACHED to a kernel's own dispatch (aadff_time_next_launch -> hipExtLaunchKernelGGL):
+    # the kernel's begin-to-end time on its launch stream, the quantity rocprofv3 reports.  Taken in the solo leg below.
     def hip_event():
         e = torch.cuda.Event(enable_timing=True)
         e.record()                                   # creates the HIP event behind it (its handle goes to the launch)
@@ -164,11 +160,6 @@ def main():
         b.synchronize()
         return float(a.elapsed_time(b))
 
-    every = max(1, args.conv_events_every)
-    kev = {i: (hip_event(), hip_event()) for i in range(0, args.steps, every)}
-    ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for i in range(every // 2, args.steps, every) if i not in kev}
-
     # --gather: the all-gather of step i runs on a side stream while step i+1 renders into the other output buffer
     ring = None
     if world > 1 and args.gather:
@@ -177,15 +168,9 @@ def main():
     def step(i, timed=False):
         torch.manual_seed(i)
         cur = pipe.plans[pipe.turn % pipe.depth]
-        if timed and i in ev:
-            cur.conv_events = ev[i]
-        if timed and i in kev:
-            cur.conv_kernel_events = kev[i]
         if ring is not None:
             k, cur.out = ring.acquire()
         out, _ = pipe.render(lens, img, dbar, fds, inputs_ready=True)      # the image is resident; outputs are not consumed here
-        cur.conv_events = None
-        cur.conv_kernel_events = None
         if ring is not None:
             ring.submit(k)
         return out
@@ -235,49 +220,32 @@ def main():
             ring.drain()
         torch.cuda.synchronize(dev)
         lat.append(time.perf_counter() - t1)
-    # ---- untimed: the fused trace/PSF kernel bracketed by HIP events on its own launch stream
-    pev = [(hip_event(), hip_event()) for _ in range(20)]
-    for i, e in enumerate(pev):
-        torch.cuda.synchronize(dev)                                   # alone on the device: the kernel's own duration
+    # ---- untimed SOLO leg: one stack at a time, device idle before each; the PSF-grid and the convolution kernel each
+    # carry a HIP event pair on their own dispatch, and two stream events bracket the convolution launch (round-1 method)
+    solo = []
+    for i in range(max(4, args.solo_steps)):
+        torch.cuda.synchronize(dev)
         cur = pipe.plans[pipe.turn % pipe.depth]
-        cur.psf_kernel_events = e
+        rec = {"psf": (hip_event(), hip_event()), "conv": (hip_event(), hip_event()),
+               "bracket": (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))}
+        torch.cuda.synchronize(dev)
+        cur.psf_kernel_events, cur.conv_kernel_events, cur.conv_events = rec["psf"], rec["conv"], rec["bracket"]
         step(i)
-        cur.psf_kernel_events = None
+        cur.psf_kernel_events = cur.conv_kernel_events = cur.conv_events = None
+        solo.append(rec)
     torch.cuda.synchronize(dev)
-    psf_ms = float(np.median([hip_elapsed_ms(a, b) for a, b in pev]))
+    solo = solo[2:]                                                     # the first two re-warm the clocks after the latency leg
+    psf_ms = float(np.median([hip_elapsed_ms(*r["psf"]) for r in solo]))
     # ---- untimed: the pixels of a seed-0 step for the parity block
     torch.cuda.synchronize(dev)
     out0 = step(0)
     torch.cuda.synchronize(dev)
     got = out0[0].cpu().numpy() if rank == 0 else None              # [3,S,H,W]
 
-    conv_all = [hip_elapsed_ms(a, b) for a, b in kev.values()]
+    conv_all = [hip_elapsed_ms(*r["conv"]) for r in solo]
     conv_ms = float(np.mean(conv_all))
-    conv_bracket = [a.elapsed_time(b) for a, b in ev.values()]
+    conv_bracket = [r["bracket"][0].elapsed_time(r["bracket"][1]) for r in solo]
     achieved = ALG_BYTES_PER_SLICE * S / (conv_ms * 1e-3)
-    # ---- untimed extra: the same stacks with two in flight on two streams (StackPipeline).  Kernels of different stacks
-    # then share the device, so per-kernel durations stop meaning anything (the convolution reads 2.6x longer while the PSF
-    # kernel of the next stack runs beside it) - which is why the contract line above is measured on one stream.
-    two = None
-    if args.two_stream_leg and n_streams == 1 and ring is None and args.steps >= 20:
-        pipe2 = StackPipeline(lens, S, H, W, 1, 3, GRID, KS, SPP, depth=2)
-        n2 = min(args.steps, 200)
-        for i in range(20):
-            torch.manual_seed(i)
-            pipe2.render(lens, img, dbar, fds, inputs_ready=True)
-        barrier()
-        t2 = time.perf_counter()
-        for i in range(n2):
-            torch.manual_seed(i)
-            pipe2.render(lens, img, dbar, fds, inputs_ready=True)
-        barrier()
-        dt2 = adist.all_reduce_max(time.perf_counter() - t2)
-        for p_ in pipe2.plans:
-            bits |= int(p_.flags.item())
-        two = {"value": round(world * S * H * W / 1e6 * n2 / dt2, 2), "unit": "MP/s", "ms_per_step": round(dt2 / n2 * 1e3, 4), "steps": n2,
-               "what": "same stacks, two in flight on two HIP streams of the one GPU (aadff.focal_stack.StackPipeline, bench.py --streams 2); "
-                       "untimed extra leg, not `value`"}
-        del pipe2
     traffic = unique = None
     tpath = os.path.join(REPO, "profiles", "conv_traffic.json")
     if os.path.exists(tpath):
@@ -297,12 +265,15 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "latency_ms_p50": round(float(np.median(lat)) * 1e3, 4),
-            "streams": n_streams, "throughput_two_streams": two,
+            "streams": n_streams,
             "config": {"workload": "rf50mm, 1024x1024 synthetic RGB + depth plane, 10 focus distances, 11x11 PSF grid, "
                                    "ks 11, spp 2048 (+2048 chief), mode M1 (refocus -> psf_map -> render_psf_map)",
                        "stacks_per_step_per_gpu": 1, "pupil_samples": "device RNG" if args.device_rng else "host torch RNG, reference call order",
                        "gather": bool(ring is not None), "ranks_emulated_on_one_gpu": adist.emulated(),
-                       "value_is": "pipelined throughput (steps queued back to back); latency_ms_p50 = one stack, host call to device idle",
+                       "value_is": f"pipelined throughput: steps queued back to back, {n_streams} stack(s) in flight on {n_streams} HIP stream(s) "
+                                   "of the GPU; latency_ms_p50 = one stack, host call to device idle",
+                       "kernel_times_from": f"untimed solo leg after the timed region: {len(solo)} stacks, one at a time with the device idle "
+                                            "before each (kernels of different stacks overlap in the timed region when streams > 1)",
                        "arithmetic": "fp32 ray trace / PSF grid; convolution operands carried as fp16 hi+lo pairs "
                                      "(>= 21-bit significand) on MFMA with fp32 accumulation, <= 2e-6 abs from the reference's fp32 conv2d"},
             "roofline": {"kernel": {"v": "conv_psf_map_kernel<11,5> (packed fp32 FMA)",
@@ -317,16 +288,16 @@ def main():
                          "stack_fused_bytes_per_launch": unique,
                          "kernel_ms": round(conv_ms, 4), "kernel_ms_median": round(float(np.median(conv_all)), 4),
                          "kernel_ms_bracketed": round(float(np.mean(conv_bracket)), 4) if conv_bracket else None,
-                         "kernel_ms_note": "kernel_ms: HIP events attached to the kernel's dispatch (hipExtLaunchKernelGGL start/stop events) on "
-                                           "every 8th launch of the timed region = the kernel's own begin-to-end time on its launch stream, "
-                                           "what rocprofv3 reports; kernel_ms_bracketed: two stream events around the launch on the steps "
-                                           "in between (adds the two dispatch gaps, the round-1 method)",
+                         "kernel_ms_note": "kernel_ms: HIP events attached to the kernel's dispatch (hipExtLaunchKernelGGL start/stop events) in the "
+                                           "solo leg = the kernel's own begin-to-end time on its launch stream, what rocprofv3 reports for "
+                                           "`bench.py --streams 1`; kernel_ms_bracketed: two stream events around the same launches "
+                                           "(adds the two dispatch gaps, the round-1 method)",
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_SLICE * S,
                          "tflops": round(2 * 3 * KS * KS * H * W * S / (conv_ms * 1e-3) / 1e12, 2)},
             "trace": {"kernel": "psf_points_kernel (fused chief-ray centre + ray trace + LDS histogram + normalise)",
                       "us_per_stack": round(psf_ms * 1e3, 2), "ray_surface_steps_per_stack": steps_per_stack,
                       "ray_surface_steps_per_s": round(steps_per_stack / (psf_ms * 1e-3), 0),
-                      "frac_of_step": round(psf_ms / (dt / args.steps * 1e3), 4), "bound": "valu",
+                      "frac_of_step_solo": round(psf_ms / (dt / args.steps * 1e3), 4), "bound": "valu",
                       "valu_busy": valu, "valu_busy_source": "profiles/psf_kernel_pmc.json (static)" if valu is not None else None},
             "flags": bits,
         }
@@ -398,6 +369,23 @@ def main_c3(args):
     dt = adist.all_reduce_max(time.perf_counter() - t0)
     rend.check_flags()
     if rank == 0:
+        # What the first real 8-GPU run should be read against (no multi-GPU box in the build loop): every rank
+        # must RECEIVE (N-1)/N of the gathered set per step over its 7 xGMI links (~153 GB/s each, point to point).
+        unit_bytes = 3 * H * W * 4
+        total_bytes = n_scenes * S * unit_bytes
+        link_in = 7 * 153e9
+        exp = {"xgmi_inbound_GBps_per_rank": round(link_in / 1e9, 1), "gathered_bytes": total_bytes,
+               "gather_floor_ms_at_8": round(total_bytes * 7 / 8 / link_in * 1e3, 3),
+               "note": "8 ranks: render time = 1-rank time / 8 (units are independent, host draws replicate per scene); with the "
+                       "gather a step cannot be shorter than gather_floor_ms_at_8 (each rank receives 7/8 of the set), so the gathered "
+                       "configuration is link-bound and the >= 6x target of north_star is a no-gather target"}
+        if world == 1:
+            t1 = dt / steps * 1e3
+            exp.update({"render_ms_at_1": round(t1, 3), "render_ms_at_8": round(t1 / 8, 3),
+                        "speedup_at_8_no_gather": 8.0,
+                        "speedup_at_8_with_gather": round(t1 / max(t1 / 8, exp["gather_floor_ms_at_8"]), 2),
+                        "MPs_at_8_no_gather": round(n_scenes * S * H * W / 1e6 / (t1 / 8 * 1e-3), 0),
+                        "MPs_at_8_with_gather": round(n_scenes * S * H * W / 1e6 / (max(t1 / 8, exp["gather_floor_ms_at_8"]) * 1e-3), 0)})
         print(json.dumps({
             "metric": "focal-stack MP/s (config 3: 16 scenes x 10 slices sharded u = r mod N, all-gathered)",
             "value": round(n_scenes * S * H * W / 1e6 * steps / dt, 2), "unit": "MP/s", "n_gpus": world, "steps": steps, "warmup": warm,
@@ -405,7 +393,11 @@ def main_c3(args):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"rf50mm, {n_scenes} scenes x {S} slices, 1024x1024, 11x11 PSF grid, ks 11, spp 2048, mode M1",
                        "gather": world > 1, "ranks_emulated_on_one_gpu": adist.emulated(),
-                       "gathered_shape": list(full.shape)}}), flush=True)
+                       "gather_form": "slices written by the convolution straight into the unit-order buffer [share, world, C, H, W]; one in-place "
+                                      "all-gather per buffer row (12.6 MB per rank) on a side stream, started as soon as the scene group that "
+                                      "produced the row has been launched",
+                       "gathered_shape": list(full.shape)},
+            "expected_scaling": exp}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

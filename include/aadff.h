@@ -114,6 +114,15 @@ int aadff_render_psf_map(const float* img, const float* psf_map, float* out,
 int aadff_render_psf_map_stack(const float* img, const float* psf_maps, float* out,
                                int B, int C, int S, int H, int W, int grid, int ks,
                                aadff_stream_t stream);
+/* The same with the destination of every slice given by strides (elements): the plane of (b, c, s) starts at
+ * out + (b*C + c)*stride_bc + s*stride_s.  stride_bc = S*H*W, stride_s = H*W is the contiguous stack above;
+ * stride_bc = H*W, stride_s = C*H*W (B = 1) writes the slices as consecutive [C,H,W] units - the layout of a sharded
+ * run's all-gather buffer (BASELINE.json config 3), so a rank renders straight into it.  Planes must not
+ * overlap.  Same reference counterpart as aadff_render_psf_map_stack. */
+int aadff_render_psf_map_stack_strided(const float* img, const float* psf_maps, float* out,
+                                       long stride_bc, long stride_s,
+                                       int B, int C, int S, int H, int W, int grid, int ks,
+                                       aadff_stream_t stream);
 /* Measurement aid (no reference counterpart): arm the NEXT aadff_render_psf_map_stack (slice-batched kernel: ks 11, S >= 3)
  * or aadff_psf_points / aadff_psf_points_staged call made by this host thread so that its kernel is launched with the two
  * HIP events (hipEvent_t, timing enabled) attached to the dispatch (hipExtLaunchKernelGGL): hipEventElapsedTime then gives

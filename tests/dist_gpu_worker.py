@@ -19,6 +19,11 @@ def main():
     ap.add_argument("--scenes", type=int, default=4)
     ap.add_argument("--res", type=int, default=128)
     ap.add_argument("--slices", type=int, default=10)
+    ap.add_argument("--grid", type=int, default=5)
+    ap.add_argument("--spp", type=int, default=512)
+    ap.add_argument("--check-inproc", action="store_true",
+                    help="full-size runs: compare every gathered unit with the plain per-scene stack ON THE DEVICE in every rank "
+                         "and write only a summary (the full set is 2 GB at 16 scenes x 10 x 1024^2)")
     a = ap.parse_args()
     import torch.distributed as dist
     from aadff import dist as adist
@@ -30,7 +35,7 @@ def main():
     dev = torch.device("cuda", local)
     rank, world = adist.init_from_env(backend="nccl", device=dev)
     H = W = a.res
-    S, GRID, KS, SPP = a.slices, 5, 11, 512
+    S, GRID, KS, SPP = a.slices, a.grid, 11, a.spp
     lens = Lensgroup(os.path.join(REPO, "lenses", "rf50mm", "lens.json"), sensor_res=(H, W), device=dev)
     scenes = []
     for sc in range(a.scenes):
@@ -64,9 +69,20 @@ def main():
                 assert torch.equal(g0[:, 0, 0, 0, 0], want), (g0[:, 0, 0, 0, 0], want)
         ring.drain()
     rend.check_flags()
-    if rank == 0:
+    if a.check_inproc:
+        import json
+        worst, mean = 0.0, 0.0
+        for sc, (img, dbar, fds) in enumerate(scenes):
+            torch.manual_seed(sc)
+            st = render_focal_stack_m1(lens, img, dbar, fds, GRID, KS, SPP)[0].permute(1, 0, 2, 3)      # [S,3,H,W]
+            worst = max(worst, float((full[sc * S:(sc + 1) * S] - st).abs().max()))
+            mean += float(st.abs().mean()) / len(scenes)
+        json.dump({"world": world, "rank": rank, "units": int(full.shape[0]), "shape": list(full.shape), "worst_abs_diff": worst,
+                   "mean_abs_pixel": mean}, open(os.path.join(a.out, f"check_w{world}_r{rank}.json"), "w"))
+        assert worst <= 5e-6, f"rank {rank}: gathered units differ from the plain per-scene stacks by {worst}"
+    elif rank == 0:
         np.save(os.path.join(a.out, f"full_w{world}.npy"), full.cpu().numpy())
-    if world == 1:
+    if world == 1 and not a.check_inproc:
         stacks = []
         for sc, (img, dbar, fds) in enumerate(scenes):
             torch.manual_seed(sc)

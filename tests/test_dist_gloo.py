@@ -61,6 +61,32 @@ def test_sharded_render_equals_single_rank(tmp_path):
         assert torch.equal(got, want), f"rank {r}: gathered stack differs from the single-rank render"
 
 
+def _worker8(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    init_from_env(backend="gloo")
+    n, shape = 160, (3, 6, 8)
+    unit = lambda u: torch.full(shape, float(u)) + torch.arange(8, dtype=torch.float32)       # unit id in every pixel
+    full, mine = render_sharded(n, unit, shape, gather=True)
+    assert mine == list(range(rank, n, world)) and len(mine) == 20 and full.shape == (n,) + shape
+    assert torch.equal(full[:, 0, 0, 0], torch.arange(n, dtype=torch.float32)), "gathered set is not in unit order"
+    assert torch.equal(full[37], unit(37))
+    odd, _ = render_sharded(157, unit, shape, gather=True)                                     # not a multiple of 8: padded shares
+    assert odd.shape[0] == 157 and torch.equal(odd[:, 0, 0, 0], torch.arange(157, dtype=torch.float32))
+    if rank == 0:
+        open(os.path.join(out_dir, "ok8"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_config3_sharding_world_8_160_units(tmp_path):
+    """BASELINE.json config 3's partition at its real rank and unit counts: 16 scenes x 10 slices = 160 units over 8 ranks
+    (u = r mod 8, 20 each), gathered row by row into unit order; also a unit count that needs padding."""
+    mp.spawn(_worker8, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    assert os.path.exists(os.path.join(tmp_path, "ok8"))
+
+
 def test_single_process_path_needs_no_group():
     render, n, shape = _unit_renderer()
     full, mine = render_sharded(n, render, shape, gather=True)

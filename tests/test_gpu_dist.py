@@ -40,6 +40,23 @@ def test_sharded_units_two_emulated_ranks_equal_single_rank(tmp_path):
     assert float(np.abs(one).mean()) > 0.05                                                      # real pixels, not zeros
 
 
+@pytest.mark.timeout(1500)
+def test_config3_at_its_real_size_one_rank_and_two_emulated_ranks(tmp_path):
+    """BASELINE.json config 3 at the size it names - 16 scenes x 10 slices x 1024^2, 11x11 PSF grid, spp 2048 - through the
+    zero-copy sharded renderer (slices written by the convolution straight into the unit-order gather buffer, one in-place
+    all-gather per buffer row): every one of the 160 gathered units equals the plain per-scene stack (<= 5e-6: float atomics
+    of the PSF histogram), on one rank and on two ranks emulated on the one GPU, in every rank."""
+    worker = os.path.join(HERE, "dist_gpu_worker.py")
+    args = [worker, "--out", str(tmp_path), "--scenes", "16", "--res", "1024", "--slices", "10", "--grid", "11", "--spp", "2048", "--check-inproc"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    assert subprocess.call([sys.executable] + args, env=env, timeout=900) == 0
+    assert spawn_ranks(args, 2, emulate=True, env=env, timeout=1200) == 0
+    for name in ("check_w1_r0.json", "check_w2_r0.json", "check_w2_r1.json"):
+        rec = json.load(open(tmp_path / name))
+        assert rec["units"] == 160 and rec["shape"] == [160, 3, 1024, 1024] and rec["worst_abs_diff"] <= 5e-6 and rec["mean_abs_pixel"] > 0.05
+        print(f"\n{name}: 160 units, worst |gathered - plain| = {rec['worst_abs_diff']:.2e}")
+
+
 @pytest.mark.timeout(900)
 def test_bench_self_launches_two_emulated_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
@@ -52,3 +69,19 @@ def test_bench_self_launches_two_emulated_ranks():
         rec = json.loads(lines[0])
         assert rec["n_gpus"] == 2 and rec["config"]["ranks_emulated_on_one_gpu"] and rec["config"]["gather"] == bool(extra)
         assert rec["value"] > 0 and rec["flags"] & 3 == 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_c3_mode_one_rank_and_two_emulated_ranks():
+    """`bench.py --mode c3` (config 3: units sharded u = r mod N, gathered per buffer row) runs on one rank and on two
+    emulated ranks and reports the expected 8-GPU figures with and without the gather next to the measured line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["AADFF_C3_SCENES"] = "4"
+    for gpus in (1, 2):
+        extra = ["--gpus", "2", "--emulate-ranks"] if gpus == 2 else []
+        p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--mode", "c3", "--steps", "3", "--warmup", "1"] + extra,
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+        assert rec["n_gpus"] == gpus and rec["scaling"] == "strong" and rec["value"] > 0
+        assert rec["config"]["gathered_shape"] == [40, 3, 1024, 1024] and "expected_scaling" in rec
