@@ -454,6 +454,15 @@ __device__ __forceinline__ void lds_read16(uint2v& a, uint2v& b, unsigned byte_a
 }
 }  // namespace sb
 
+#ifdef AADFF_SB_TRACE
+// Timeline instrumentation (tools/conv_timeline.py, build libaadff_sbtrace.so): wave 0 of every workgroup stamps the 100 MHz
+// real-time counter at its start, after the band is staged, at the start of the matrix phase and at its end, plus HW_ID.
+__device__ unsigned long long* g_sb_trace = nullptr;
+#define AADFF_SB_STAMP(slot) do { if (g_sb_trace && threadIdx.x == 0) g_sb_trace[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AADFF_SB_STAMP(slot) do {} while (0)
+#endif
+
 // Workgroup = one band of RB output rows x 96 columns of one patch and channel plane; wave = one chunk of 4 slices
 // (NC waves).  The band is staged once for all slices (HBM reads the image once), every wave builds the T fragments
 // of its own chunk and walks the band's row pairs.
@@ -462,6 +471,7 @@ __global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
     const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
     int grid, int ntx, int nty, int npass, PatchBounds pb, int stagger) {
     using namespace sb;
+    AADFF_SB_STAMP(0);
     if (stagger) {
         // Workgroups that share a CU are dispatched ~256 linear ids apart and would all run the same phase at the same
         // time (stage -> build T -> matrix phase -> stores).  A start delay by residency slot spreads the phases so that
@@ -487,6 +497,16 @@ __global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
     const int x_hi = pb.wb[pj + 1], y_hi = pb.hb[pi + 1];
     const int x0 = pb.wb[pj] + tx * TCOLS, y0 = pb.hb[pi] + ty * RB;
     if (x0 >= x_hi || y0 >= y_hi) return;
+    AADFF_SB_STAMP(1);
+#ifdef AADFF_SB_TRACE
+    if (g_sb_trace && threadIdx.x == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_sb_trace[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + 6] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     const int G = grid * KS;
     const int s_base = pass * NSL;                       // first slice of this workgroup
     const int chunk = wave;
@@ -557,6 +577,7 @@ __global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
     }
     amax = wave_max(amax);
     if (lane == 0) red[wave] = amax;
+    AADFF_SB_STAMP(2);                                                        // global loads have arrived (wave 0)
     __syncthreads();
     float tmax = red[0];
 #pragma unroll
@@ -602,6 +623,7 @@ __global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
     }
     const float inv = isx * s_isw[chunk * 4 + kg];                            // D rows 4 kg + i belong to slice kg of the chunk
     __syncthreads();                                                          // the whole band is in LDS
+    AADFF_SB_STAMP(3);
 
     const int s_out = s_base + chunk * 4 + kg;
     const bool s_ok = s_out < S;
@@ -683,6 +705,11 @@ __global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
         step_fn(std::integral_constant<int, 12>{}); step_fn(std::integral_constant<int, 13>{}); step_fn(std::integral_constant<int, 14>{});
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the two prefetches issued by the last row pair
+    AADFF_SB_STAMP(4);
+#ifdef AADFF_SB_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stores retired
+    AADFF_SB_STAMP(5);
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -1228,6 +1255,13 @@ int aadff_render_psf_map_stack_strided(const float* img, const float* psf_maps, 
                     "render_psf_map_stack_strided: planes overlap (stride_bc %ld, stride_s %ld, B*C %d, S %d)", stride_bc, stride_s, B * C, S);
     return stack_launch(img, psf_maps, out, stride_bc, stride_s, B, C, S, H, W, grid, ks, (hipStream_t)stream);
 }
+
+#ifdef AADFF_SB_TRACE
+extern "C" int aadff_sb_trace_buffer(unsigned long long* dev_buf) {      // not part of the ABI: instrumentation builds only
+    AADFF_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(aadff::g_sb_trace), &dev_buf, sizeof(dev_buf)));
+    return 0;
+}
+#endif
 
 int aadff_time_next_launch(void* start_event, void* stop_event) {
     AADFF_CHECK_ARG((start_event == nullptr) == (stop_event == nullptr), "time_next_launch: give both events or neither");

@@ -3,8 +3,9 @@
 // The reference draws its pupil samples with torch.rand on the HOST generator
 // (deeplens/optics.py:480-481, deeplens/surfaces.py:192-193); sample-for-sample parity needs
 // exactly that stream.  torch.rand costs ~10 ns per float; this routine produces the same
-// floats from the same MT19937 state in ~1.5 ns each and hands the advanced state back, so
-// torch's global generator stays where the reference's call sequence would have left it.
+// floats from the same MT19937 state in ~1.5 ns each (scalar) / ~0.3 ns each (AVX2 / AVX-512 builds of the same loops, picked at run
+// time) and hands the advanced state back, so torch's global generator stays where the reference's call sequence would
+// have left it.
 //
 // State layout = at::CPUGeneratorImpl::get_state(): CPUGeneratorImplStateLegacy
 //   u64 seed | i32 left | i32 seeded | u64 next | u64 state[624] | f64 normal_x,y,rho | i32 normal_valid (+pad)
@@ -20,24 +21,58 @@ namespace {
 constexpr int N = 624, M = 397;
 constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
 
-inline uint32_t twist(uint32_t u, uint32_t v) {
-    return (((u & UPPER) | (v & LOWER)) >> 1) ^ ((v & 1u) ? MATRIX_A : 0u);
-}
+// The three loops below are written once and compiled twice (baseline x86-64 and AVX2): every iteration reads st[j],
+// st[j+1] (not yet updated) and an element >= 227 places away, so blocks of 8 iterations are independent and the
+// compiler vectorises them; the tempering + int->float conversion is element-wise.
+#define AADFF_MT_BODY(VW)                                                                                              \
+    static inline uint32_t twist(uint32_t u, uint32_t v) {                                                         \
+        return (((u & UPPER) | (v & LOWER)) >> 1) ^ ((0u - (v & 1u)) & MATRIX_A);                                   \
+    }                                                                                                              \
+    static void next_state(uint32_t* __restrict__ st) {                                                            \
+        int j = 0;                                                                                                 \
+        _Pragma(AADFF_STR(clang loop vectorize_width(VW)))                                                         \
+        for (; j < N - M; ++j) st[j] = st[j + M] ^ twist(st[j], st[j + 1]);                                         \
+        _Pragma(AADFF_STR(clang loop vectorize_width(VW)))                                                         \
+        for (; j < N - 1; ++j) st[j] = st[j + M - N] ^ twist(st[j], st[j + 1]);                                     \
+        st[N - 1] = st[M - 1] ^ twist(st[N - 1], st[0]);                                                           \
+    }                                                                                                              \
+    static void temper(const uint32_t* __restrict__ st, float* __restrict__ out, long n) {                         \
+        _Pragma(AADFF_STR(clang loop vectorize_width(VW)))                                                         \
+        for (long k = 0; k < n; ++k) {                                                                             \
+            uint32_t y = st[k];                                                                                    \
+            y ^= (y >> 11);                                                                                        \
+            y ^= (y << 7) & 0x9d2c5680u;                                                                           \
+            y ^= (y << 15) & 0xefc60000u;                                                                          \
+            y ^= (y >> 18);                                                                                        \
+            out[k] = (float)(int32_t)(y & 0xffffffu) * (1.0f / 16777216.0f);                                       \
+        }                                                                                                          \
+    }                                                                                                              \
+    static void fill(uint32_t* st, int& left, int& nxt, long n, float* out) {                                      \
+        long i = 0;                                                                                                \
+        while (i < n) {                                                                                            \
+            /* at::mt19937::operator(): if (--left == 0) next_state();  y = state[next++] */                       \
+            if (left == 1) {                                                                                       \
+                next_state(st);                                                                                    \
+                left = N + 1;                                                                                      \
+                nxt = 0;                                                                                           \
+            }                                                                                                      \
+            long run = left - 1; /* outputs available before the next regeneration */                              \
+            if (run > n - i) run = n - i;                                                                          \
+            temper(st + nxt, out + i, run);                                                                        \
+            i += run;                                                                                              \
+            nxt += (int)run;                                                                                       \
+            left -= (int)run;                                                                                      \
+        }                                                                                                          \
+    }
 
-void next_state(uint32_t* st) {
-    int j = 0;
-    for (; j < N - M; ++j) st[j] = st[j + M] ^ twist(st[j], st[j + 1]);
-    for (; j < N - 1; ++j) st[j] = st[j + M - N] ^ twist(st[j], st[j + 1]);
-    st[N - 1] = st[M - 1] ^ twist(st[N - 1], st[0]);
-}
-
-inline float to_uniform(uint32_t y) {
-    y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= (y >> 18);
-    return (float)(y & 0xffffffu) * (1.0f / 16777216.0f);
-}
+#define AADFF_STR(x) #x
+struct Base { AADFF_MT_BODY(4) };
+#pragma clang attribute push(__attribute__((target("avx2"))), apply_to = function)
+struct Avx2 { AADFF_MT_BODY(8) };
+#pragma clang attribute pop
+#pragma clang attribute push(__attribute__((target("avx512f,avx512bw,avx512vl"))), apply_to = function)
+struct Avx512 { AADFF_MT_BODY(16) };
+#pragma clang attribute pop
 }  // namespace
 
 extern "C" int aadff_host_mt19937_uniform_f32(unsigned char* torch_state, long state_bytes, long n, float* out) {
@@ -55,21 +90,11 @@ extern "C" int aadff_host_mt19937_uniform_f32(unsigned char* torch_state, long s
         st[i] = (uint32_t)v;
     }
     int nxt = (int)next64;
-    long i = 0;
-    while (i < n) {
-        // at::mt19937::operator(): if (--left == 0) next_state();  y = state[next++]
-        if (left == 1) {
-            next_state(st);
-            left = N + 1;
-            nxt = 0;
-        }
-        long run = left - 1;                 // outputs available before the next regeneration
-        if (run > n - i) run = n - i;
-        for (long k = 0; k < run; ++k) out[i + k] = to_uniform(st[nxt + k]);
-        i += run;
-        nxt += (int)run;
-        left -= (int)run;
-    }
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    static const bool avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl");
+    if (avx512) Avx512::fill(st, left, nxt, n, out);
+    else if (avx2) Avx2::fill(st, left, nxt, n, out);
+    else Base::fill(st, left, nxt, n, out);
     next64 = (uint64_t)nxt;
     std::memcpy(torch_state + 8, &left, 4);
     std::memcpy(torch_state + 16, &next64, 8);

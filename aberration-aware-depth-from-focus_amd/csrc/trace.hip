@@ -866,6 +866,9 @@ __global__ __launch_bounds__(kPsfThreads, 6) void psf_points_kernel(const float*
         }
     }
     const aadff_lens_state_t st = states[s];
+    // a focus state whose refocus found no valid ray has d_sensor = 0/0: the reference stops there with "sensor position is
+    // negative." (deeplens/optics.py:1176); in a pipelined stack the condition travels in the flags word (bit 2)
+    if (tid == 0 && !(st.d_sensor > 0.f) && flags) atomicOr(flags, 4);
     for (int e = tid; e < kk; e += kPsfThreads) hist[e] = 0.f;
 
     // object-space point: deeplens/optics.py:953-959 with calc_scale_pinhole (:1286-1290)

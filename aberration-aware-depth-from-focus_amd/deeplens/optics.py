@@ -44,10 +44,12 @@ from .utils import make_grid, save_image   # noqa: F401
 
 def raise_psf_flags(bits):
     """Flags word of aadff_psf_points -> the reference's errors (bit 0: NaN in a Newton residual, surfaces.py:555-558;
+    bit 2: a focus state without a positive sensor position, i.e. a refocus that found no valid ray, optics.py:1176;
     bit 1: no valid chief ray for some point, optics.py:901; bit 3: a staged upload was late and the kernel read the
     samples over PCIe instead — results are correct, only the overlap was lost, so this one is a warning)."""
     if bits & 1:
         raise FloatingPointError("found nan in ft in non-diff newton method.")
+    assert not bits & 4, "sensor position is negative."
     assert not bits & 2, "No sampled rays is valid."
     if bits & 8:
         import warnings

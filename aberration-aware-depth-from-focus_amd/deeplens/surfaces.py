@@ -44,7 +44,7 @@ class Aspheric(Surface):
 
     def __init__(self, r, d, c=0., k=0., ai=None, mat1=None, mat2=None, is_square=False, device=DEVICE,
                  diff=False, square=False):
-        Surface.__init__(self, r, d, mat1, mat2, is_square, device)
+        Surface.__init__(self, r, d, mat1, mat2, is_square or square, device)     # the reference's `square` overrides (:330)
         self.c = torch.Tensor([c]).to(device)
         self.k = torch.Tensor([k]).to(device)
         if ai is not None:
@@ -54,6 +54,10 @@ class Aspheric(Surface):
             self.ai_degree = len(ai)
             for i, a in enumerate(ai):
                 setattr(self, f"ai{2 * i + 2}", torch.Tensor([a]).to(device))
+            if self.ai_degree == 4:
+                # reference wart kept for parity (deeplens/surfaces.py:313): a 4-coefficient asphere evaluates its r^8 term
+                # with the r^6 coefficient (`self.ai8 = torch.Tensor([ai[2]])`); `self.ai` (what write_lens_json stores) is untouched
+                self.ai8 = torch.Tensor([ai[2]]).to(device)
         else:
             self.ai, self.ai_degree = None, 0
 
@@ -86,8 +90,9 @@ class Aspheric(Surface):
         s.refract_bwd = int(not (is_stop and eb == 1))
         s.n_ai = self.ai_degree
         for i in range(self.ai_degree):
-            s.ai[i] = float(self.ai[i].item())
-            s.dai[i] = float(f32(i + 1) * f32(self.ai[i].item()))
+            a = float(getattr(self, f"ai{2 * i + 2}").item())     # the coefficients the reference's sag reads (ai8 wart of degree 4)
+            s.ai[i] = a
+            s.dai[i] = float(f32(i + 1) * f32(a))
         s.newton_step_tol = self.newton_step_tol()
         return s
 
@@ -105,7 +110,7 @@ class Aspheric(Surface):
         curv = c / q ** 1.5                                   # second r-derivative of the conic sag
         for j in range(self.ai_degree):                       # + sum a_j (2j+2)(2j+1) r^(2j)
             n = 2 * (j + 1)
-            curv = curv + float(self.ai[j].item()) * n * (n - 1) * rr ** (n - 2)
+            curv = curv + float(getattr(self, f"ai{n}").item()) * n * (n - 1) * rr ** (n - 2)
         kappa = float(np.abs(curv).max()) if len(rr) else abs(c)
         return float(min(1e-2, np.sqrt(4e-6 / max(kappa, 1e-12))))
 

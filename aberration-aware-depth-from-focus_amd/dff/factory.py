@@ -1,11 +1,13 @@
 """dff/factory.py of the reference: build the train / test lens from the YAML dict (dff/factory.py:4-31) and pick a dataset
-(:33-55).  `get_lens` is the reference's logic on this package's PSFNet / ThinLens.  The reference's datasets read
-Matterport3D / FlyingThings3D / Middlebury files with cv2, skimage and torchvision (not part of the hot path, not installed
-here): `get_dataset` offers the seeded synthetic RGB-D set the benchmarks use and names what is missing otherwise."""
+(:33-55).  `get_lens` is the reference's logic on this package's PSFNet / ThinLens.  `get_dataset` keeps the reference's
+names and YAML keys for the file sets dff/dataset.py can read with PIL (Matterport3D, Middlebury2014 / 2021), adds the
+seeded synthetic RGB-D set the benchmarks use ('Synthetic'), and names what is missing otherwise (FlyingThings3D needs
+OpenEXR, RealWorld camera metadata)."""
 import torch
 
 from deeplens.psfnet import PSFNet, ThinLens
 from aadff.synth import synth_depth_mm, synth_rgb
+from .dataset import Matterport3D, Middlebury
 
 
 def _lens(spec, ks, sensor_res, device):
@@ -41,11 +43,19 @@ class SyntheticRGBD(torch.utils.data.Dataset):
 
 
 def get_dataset(args):
-    sets = []
-    for split in ("train", "test"):
-        name = args[split]["dataset"]
-        if name != "Synthetic":
-            raise NotImplementedError(f"dataset '{name}' reads files through cv2 / skimage / torchvision in the reference "
-                                      "(dff/dataset.py); only 'Synthetic' is provided here")
-        sets.append(SyntheticRGBD(args[split].get("n", 64), args["res"], seed=1000 if split == "train" else 2000))
-    return tuple(sets)
+    """(train_set, test_set) as dff/factory.py:33-55 selects them."""
+    name = args["train"]["dataset"]
+    if name == "Matterport3D":
+        train_set = Matterport3D(args["train_aif_dir"], args["train_depth_dir"], resize=args["res"])
+    elif name == "Synthetic":
+        train_set = SyntheticRGBD(args["train"].get("n", 64), args["res"], seed=1000)
+    else:
+        raise NotImplementedError(f"train dataset '{name}': only 'Matterport3D' and 'Synthetic' are provided (FlyingThings3D reads OpenEXR)")
+    name = args["test"]["dataset"]
+    if name in ("Middlebury2014", "Middlebury2021"):
+        test_set = Middlebury(args[f"{name}_val"], resize=args["res"], train=False)
+    elif name == "Synthetic":
+        test_set = SyntheticRGBD(args["test"].get("n", 64), args["res"], seed=2000)
+    else:
+        raise NotImplementedError(f"test dataset '{name}': only 'Middlebury2014', 'Middlebury2021' and 'Synthetic' are provided")
+    return train_set, test_set

@@ -220,19 +220,24 @@ def main():
             ring.drain()
         torch.cuda.synchronize(dev)
         lat.append(time.perf_counter() - t1)
-    # ---- untimed SOLO leg: one stack at a time, device idle before each; the PSF-grid and the convolution kernel each
-    # carry a HIP event pair on their own dispatch, and two stream events bracket the convolution launch (round-1 method)
-    solo = []
-    for i in range(max(4, args.solo_steps)):
-        torch.cuda.synchronize(dev)
-        cur = pipe.plans[pipe.turn % pipe.depth]
-        rec = {"psf": (hip_event(), hip_event()), "conv": (hip_event(), hip_event()),
-               "bracket": (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))}
-        torch.cuda.synchronize(dev)
-        cur.psf_kernel_events, cur.conv_kernel_events, cur.conv_events = rec["psf"], rec["conv"], rec["bracket"]
-        step(i)
-        cur.psf_kernel_events = cur.conv_kernel_events = cur.conv_events = None
-        solo.append(rec)
+    # ---- untimed SOLO leg: the same stacks on ONE stream, queued back to back (the device stays busy and clocked up, and the
+    # stream order keeps every kernel alone on the device - the condition rocprofv3 of `bench.py --streams 1` sees); on every
+    # 4th stack the PSF-grid and the convolution kernel carry a HIP event pair on their own dispatch, and two stream events
+    # bracket the convolution launch (round-1 method).  An attached pair costs ~10 us of queue time: this leg is not timed.
+    from aadff.focal_stack import render_focal_stack_m1
+    torch.cuda.synchronize(dev)
+    solo, splan = [], pipe.plans[0]
+    for i in range(4 * max(4, args.solo_steps)):
+        torch.manual_seed(i)
+        rec = None
+        if i % 4 == 3:
+            rec = {"psf": (hip_event(), hip_event()), "conv": (hip_event(), hip_event()),
+                   "bracket": (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))}
+            splan.psf_kernel_events, splan.conv_kernel_events, splan.conv_events = rec["psf"], rec["conv"], rec["bracket"]
+        render_focal_stack_m1(lens, img, dbar, fds, GRID, KS, SPP, plan=splan, update_lens=False)
+        splan.psf_kernel_events = splan.conv_kernel_events = splan.conv_events = None
+        if rec is not None:
+            solo.append(rec)
     torch.cuda.synchronize(dev)
     solo = solo[2:]                                                     # the first two re-warm the clocks after the latency leg
     psf_ms = float(np.median([hip_elapsed_ms(*r["psf"]) for r in solo]))
@@ -272,8 +277,9 @@ def main():
                        "gather": bool(ring is not None), "ranks_emulated_on_one_gpu": adist.emulated(),
                        "value_is": f"pipelined throughput: steps queued back to back, {n_streams} stack(s) in flight on {n_streams} HIP stream(s) "
                                    "of the GPU; latency_ms_p50 = one stack, host call to device idle",
-                       "kernel_times_from": f"untimed solo leg after the timed region: {len(solo)} stacks, one at a time with the device idle "
-                                            "before each (kernels of different stacks overlap in the timed region when streams > 1)",
+                       "kernel_times_from": f"untimed solo leg after the timed region: the same stacks back to back on ONE stream, {len(solo)} "
+                                            "of them with events on the kernels' dispatches (kernels of different stacks overlap in the "
+                                            "timed region when streams > 1)",
                        "arithmetic": "fp32 ray trace / PSF grid; convolution operands carried as fp16 hi+lo pairs "
                                      "(>= 21-bit significand) on MFMA with fp32 accumulation, <= 2e-6 abs from the reference's fp32 conv2d"},
             "roofline": {"kernel": {"v": "conv_psf_map_kernel<11,5> (packed fp32 FMA)",

@@ -196,6 +196,8 @@ int aadff_psf_splat(const float* o, const float* ra, const float* centre, int sp
  *   centre_mode 1: chief-ray centre (center=True); 0: ideal perspective centre (optics.py:970-975)
  *   map_layout  0: psf [S,N,L,ks,ks] ; 1: psf_map layout [S,L,g*ks,g*ks] with N = g*g (optics.py:1025)
  *   centre_out_or_null [S,L,N,2]
+ *   flags_or_null: see aadff_publish_flags.  A point whose rays all miss the ks x ks window gets a 0/0 = NaN PSF, as in
+ *   the reference (optics.py:978, monte_carlo.py:37).
  */
 int aadff_psf_points(const float* points, int S, int N, int L,
                      const aadff_surface_t* surf_main, const aadff_surface_t* surf_chief,
@@ -293,8 +295,9 @@ int aadff_post_computation(int S, const aadff_surface_t* surf_green, aadff_lens_
                            aadff_lens_state_t* states, aadff_stream_t stream);
 
 /* Copy the flags word the PSF / refocus kernels OR into (bit 0: NaN in a Newton residual — the reference exits,
- * deeplens/surfaces.py:555-558; bit 1: no valid chief ray, the assert of deeplens/optics.py:901; bit 3: a staged
- * upload arrived late and the samples were read over PCIe instead) to a PINNED host word from inside the stream:
+ * deeplens/surfaces.py:555-558; bit 1: no valid chief ray, the assert of deeplens/optics.py:901; bit 2: a focus state
+ * without a positive sensor position, i.e. a refocus that found no valid ray - "sensor position is negative.",
+ * deeplens/optics.py:1176; bit 3: a staged upload arrived late and the samples were read over PCIe instead) to a PINNED host word from inside the stream:
  * the host can then poll the reference's error conditions of pipelined stacks without a device synchronisation
  * (it reads the mirror after an event it waits on anyway).  One 64-thread launch. */
 int aadff_publish_flags(const int* flags_dev, int* mirror_host, aadff_stream_t stream);

@@ -14,9 +14,8 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # Watchdogs outside the per-test timeout (pytest.ini): a run of this suite takes 1-5 minutes; one that is still alive
-    # after 30 dumps every thread's stack and exits instead of hanging the caller (seen three times in this container
-    # with the output piped: no test was running, the process simply never ended).
+    # Watchdog outside the per-test timeout (pytest.ini): a run of this suite takes 1-5 minutes; one that is still alive
+    # after 30 dumps every thread's stack and exits non-zero instead of hanging the caller.
     import faulthandler
     faulthandler.enable()
     faulthandler.dump_traceback_later(1800, exit=True)
@@ -59,31 +58,79 @@ def margin():
     return record
 
 
-_STATUS = {"exit": 0}
+def _own_children():
+    """PIDs whose parent is this process (exact PIDs from /proc: nothing is matched by name)."""
+    me, out = os.getpid(), []
+    for p in os.listdir("/proc"):
+        if p.isdigit():
+            try:
+                if int(open(f"/proc/{p}/stat").read().rsplit(")", 1)[1].split()[1]) == me:
+                    out.append(int(p))
+            except (OSError, ValueError, IndexError):
+                pass
+    return out
 
 
-def pytest_sessionfinish(session, exitstatus):
-    _STATUS["exit"] = int(exitstatus)
+def _reap_children(grace=5.0):
+    """Leave no child behind.  What was found when 'pytest does not end after its last test' was chased (tools/exit_hang_probe.py,
+    8 clean exits of 8 here; the reader of a pipe is a different matter): the multi-rank tests start multiprocessing's resource
+    tracker, a helper process that INHERITS this session's stderr and lives until every process holding its pipe has gone - any
+    straggling rank keeps it, and with it the caller's `2>&1 |` pipe, open after pytest itself has exited, which reads as a hang;
+    and a tracker orphaned by an abrupt exit stays behind as a <defunct> child of PID 1.  So: stop the tracker the way
+    multiprocessing does at interpreter shutdown (close its pipe, wait for it), then terminate and reap whatever else is still
+    a child of this process - with a deadline, by exact PID."""
+    import signal
+    import time
+    try:
+        from multiprocessing import resource_tracker as rt
+        tr = rt._resource_tracker
+        if getattr(tr, "_fd", None) is not None:
+            os.close(tr._fd)                      # the tracker exits on EOF once nobody else holds the pipe
+            tr._fd = None
+    except Exception:
+        pass
+    deadline = time.monotonic() + grace
+    kids = _own_children()
+    while kids and time.monotonic() < deadline:
+        for pid in kids:
+            try:
+                os.waitpid(pid, os.WNOHANG)
+            except ChildProcessError:
+                pass
+        time.sleep(0.05)
+        kids = _own_children()
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        for pid in _own_children():
+            try:
+                os.kill(pid, sig)
+            except ProcessLookupError:
+                pass
+        t1 = time.monotonic() + 2.0
+        while _own_children() and time.monotonic() < t1:
+            for pid in _own_children():
+                try:
+                    os.waitpid(pid, os.WNOHANG)
+                except ChildProcessError:
+                    pass
+            time.sleep(0.05)
+    try:
+        tr._pid = None                            # multiprocessing's own shutdown hook must not wait for it again
+    except Exception:
+        pass
 
 
 @pytest.hookimpl(trylast=True)
 def pytest_unconfigure(config):
-    # Everything is reported and pytest's own clean-up (tmp_path, capture) has run.  Python-level exit handlers still run
-    # (whatever the caller registered with atexit included), then the process leaves WITHOUT the native finalisation
-    # (destructors of the OpenMP / HIP runtimes, thread pools): that is where a run whose tests had all passed has wedged.
-    # A C-level watchdog covers the exit handlers themselves.
-    import atexit
+    # Everything is reported.  The interpreter now exits the NORMAL way (exit handlers, module teardown, native
+    # destructors); the only thing added is that no child process outlives the session.  A watchdog covers the
+    # finalisation: if it is still running after two minutes every thread's stack is dumped and the process ends with a
+    # NON-ZERO status - a wedged exit is a failure to look at, not a pass (it does not restart or re-exec anything).
     import faulthandler
     faulthandler.cancel_dump_traceback_later()
-    if os.environ.get("AADFF_TEST_NORMAL_EXIT", "0") == "1":
-        return
+    _reap_children()
+    sys.stdout.flush()
+    sys.stderr.flush()
     faulthandler.dump_traceback_later(120, exit=True)
-    sys.stdout.flush()
-    sys.stderr.flush()
-    atexit._run_exitfuncs()
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(_STATUS["exit"])
 
 
 def pytest_terminal_summary(terminalreporter):

@@ -484,10 +484,54 @@ def g14_glass():
     pm = lens.psf_map(depth=-1200., grid=5, ks=11, spp=512)
     np.savez_compressed(f"{HERE}/g14_named_psf_map.npz", psf_map=pm.numpy(), d_sensor=np.float64(lens.d_sensor), hfov=np.float64(lens.hfov))
 
+
+def g15_ai_degree4():
+    """A 4-coefficient asphere: the reference evaluates its r^8 term with the r^6 coefficient (deeplens/surfaces.py:313,
+    `self.ai8 = torch.Tensor([ai[2]])`).  Emits lenses/rf50mm_ai4/lens.json (rf50mm with its two aspheres cut to four
+    coefficients, the fourth made different from the third so the wart is visible) and the fixture: load / refocus
+    scalars, per-surface states of a small ray bundle through the two aspheres, and a PSF map with its d_sensor."""
+    src = json.load(open(f"{REPO}/lenses/rf50mm/lens.json"))
+    for s in src["surfaces"]:
+        if s["type"] == "Aspheric":
+            s["ai"] = [s["ai"][0], s["ai"][1], s["ai"][2], s["ai"][3] * 3.0]
+    os.makedirs(f"{REPO}/lenses/rf50mm_ai4", exist_ok=True)
+    path = f"{REPO}/lenses/rf50mm_ai4/lens.json"
+    with open(path, "w") as f:
+        json.dump(src, f, indent=1)
+    res = (256, 256)
+    lens = Lensgroup(filename=path, sensor_res=res, device=CPU)
+    out = {"load": lens_scalars(lens), "refocus": {}}
+    for fd in (-800., -3000.):
+        lens = Lensgroup(filename=path, sensor_res=res, device=CPU)
+        torch.manual_seed(0)
+        lens.refocus(fd)
+        out["refocus"][str(int(fd))] = lens_scalars(lens)
+    with open(f"{HERE}/g15_ai4.json", "w") as f:
+        json.dump(out, f, indent=1)
+    lens = Lensgroup(filename=path, sensor_res=res, device=CPU)
+    torch.manual_seed(0)
+    lens.refocus(-1500.)
+    pts = lens.point_source_grid(depth=-1200., grid=3).reshape(-1, 3)
+    scale = lens.calc_scale_pinhole(pts[:, 2])
+    pobj = pts.clone()
+    pobj[..., 0] = pts[..., 0] * scale * lens.sensor_size[1] / 2
+    pobj[..., 1] = pts[..., 1] * scale * lens.sensor_size[0] / 2
+    torch.manual_seed(7)
+    ray = lens.sample_from_points(o=pobj, spp=16, wvln=0.589)
+    o0, d0 = ray.o.clone().numpy(), ray.d.clone().numpy()
+    so, sd, sra = [], [], []
+    for s in lens.surfaces:
+        ray = s.ray_reaction(ray)
+        so.append(ray.o.clone().numpy()); sd.append(ray.d.clone().numpy()); sra.append(ray.ra.clone().numpy())
+    torch.manual_seed(0)
+    pm = lens.psf_map(depth=-1200., grid=5, ks=11, spp=512)
+    np.savez_compressed(f"{HERE}/g15_ai4.npz", ray_o0=o0, ray_d0=d0, states_o=np.stack(so), states_d=np.stack(sd), states_ra=np.stack(sra),
+                        psf_map=pm.numpy(), d_sensor=np.float64(lens.d_sensor), hfov=np.float64(lens.hfov))
+
 ALL = [("G1", lambda: g1_scalars()), ("G2/G3", lambda: g2_g3_trace_and_splat()), ("G4", lambda: g4_psf_map()),
        ("G5", lambda: g5_conv()), ("G6/G7", lambda: g6_g7_psfnet()), ("G8", lambda: g8_focal_stack_m1()),
        ("G9", lambda: g9_stack_m1_full()), ("G10", lambda: g10_training_data()),
-       ("G11", lambda: g11_ckpt_activation_range()), ("G12", lambda: g12_select_focus_dist()), ("G14", lambda: g14_glass())]
+       ("G11", lambda: g11_ckpt_activation_range()), ("G12", lambda: g12_select_focus_dist()), ("G14", lambda: g14_glass()), ("G15", lambda: g15_ai_degree4())]
 
 if __name__ == "__main__":
     want = {a.upper() for a in sys.argv[1:]}            # e.g. `make_golden.py G9 G10`; no arguments = everything

@@ -17,7 +17,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from aadff import _abi                                   # noqa: E402
-from aadff.focal_stack import render_focal_stack_m1, render_focal_stack_m2   # noqa: E402
+from aadff.focal_stack import StackPlan, render_focal_stack_m1, render_focal_stack_m2   # noqa: E402
 from aadff.synth import mlp_state_dict, synth_depth_mm, synth_rgb           # noqa: E402
 from deeplens import monte_carlo as dl_mc                # noqa: E402
 import importlib                                          # noqa: E402
@@ -339,6 +339,99 @@ def test_named_glass_lens_end_to_end(golden_dir, repo_root):
     pm = lens.psf_map(depth=-1200.0, grid=5, ks=11, spp=512).cpu().numpy()
     assert lens.d_sensor == pytest.approx(float(gm["d_sensor"]), rel=1e-5)
     assert rel_l2(pm, gm["psf_map"]) <= 2e-3
+
+
+def test_four_coefficient_asphere_keeps_the_reference_wart(golden_dir, repo_root):
+    """G15: ai_degree == 4 evaluates r^8 with the r^6 coefficient in the reference (surfaces.py:313); reproduced through
+    the surface table (deeplens/surfaces.py: Aspheric.ai8 / pack): refocus scalars, per-surface states, PSF map."""
+    g = json.load(open(os.path.join(golden_dir, "g15_ai4.json")))
+    z = np.load(os.path.join(golden_dir, "g15_ai4.npz"))
+    path = lens_path(repo_root, "rf50mm_ai4")
+    lens = Lensgroup(path, sensor_res=(256, 256), device=DEV)
+    assert lens.surfaces[8].ai_degree == 4 and float(lens.surfaces[8].ai8) == float(lens.surfaces[8].ai6) != float(lens.surfaces[8].ai[3])
+    for f, want in g["refocus"].items():
+        torch.manual_seed(0)
+        lens.refocus(float(f))
+        for k in ("d_sensor", "hfov", "foclen", "fnum"):
+            assert getattr(lens, k) == pytest.approx(want[k], rel=1e-5), (f, k)
+    torch.manual_seed(0)
+    lens.refocus(-1500.0)
+    ray = Ray(tt(z["ray_o0"]).clone(), tt(z["ray_d0"]).clone(), wvln=0.589, device=DEV)
+    ray.d = tt(z["ray_d0"]).clone().to(DEV)                   # stored after Ray() normalised them: do not normalise twice
+    for i, s in enumerate(lens.surfaces):
+        ray = s.ray_reaction(ray)
+        ra = ray.ra.cpu().numpy()
+        assert np.array_equal(ra, z["states_ra"][i]), f"surface {i} validity"
+        alive = ra > 0
+        assert np.abs(ray.o.cpu().numpy() - z["states_o"][i])[alive].max() <= 2e-4, f"surface {i}"     # 1.5 m away: 1e-4 mm of fp32 noise
+        assert np.abs(ray.d.cpu().numpy() - z["states_d"][i])[alive].max() <= 1e-5, f"surface {i}"       # 1e-4 mm x curvature
+    torch.manual_seed(0)
+    pm = lens.psf_map(depth=-1200.0, grid=5, ks=11, spp=512).cpu().numpy()
+    assert lens.d_sensor == pytest.approx(float(z["d_sensor"]), rel=1e-5)
+    assert rel_l2(pm, z["psf_map"]) <= 2e-3
+
+
+def test_psf_with_no_ray_inside_the_window_is_nan_like_the_reference(repo_root):
+    """A point whose rays all fall outside the ks x ks window has psf.sum() == 0 and the reference returns 0/0 = NaN for
+    it (deeplens/optics.py:978, monte_carlo.py:37).  3x3 window at 1024^2 under heavy defocus, 64 rays: 21 of the 27
+    (point, wavelength) PSFs are NaN in the reference - the same ones here, the others match; a NaN patch of the map turns
+    exactly that patch of the rendered image into NaN (render_psf_map convolves patch by patch, render_psf.py:61-71)."""
+    from oracle.lens import OracleLens
+    ora = OracleLens(lens_path(repo_root), sensor_res=(1024, 1024))
+    torch.manual_seed(0)
+    ora.refocus(-500.0)
+    torch.manual_seed(2)
+    want = ora.psf_map(depth=-8000.0, grid=3, ks=3, spp=64).numpy()
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(1024, 1024), device=DEV)
+    torch.manual_seed(0)
+    lens.refocus(-500.0)
+    torch.manual_seed(2)
+    got_t = lens.psf_map(depth=-8000.0, grid=3, ks=3, spp=64)
+    got = got_t.cpu().numpy()
+    nan_w, nan_g = np.isnan(want), np.isnan(got)
+    assert nan_w.sum() == 21 * 9 and np.array_equal(nan_w, nan_g)
+    assert np.abs(got[~nan_g] - want[~nan_w]).max() <= 2e-2                 # a handful of rays per PSF: one ray = 1/5 of it
+    img = tt(synth_rgb(96, 96))[None].to(DEV)
+    out = rp.render_psf_map(img, got_t, 3).cpu().numpy()[0]                 # [3,96,96], patches of 32 x 32
+    for c in range(3):
+        for gi in range(3):
+            for gj in range(3):
+                patch = out[c, 32 * gi:32 * gi + 32, 32 * gj:32 * gj + 32]
+                assert np.isnan(patch).all() == bool(nan_g[c, 3 * gi, 3 * gj]) and np.isnan(patch).any() == bool(nan_g[c, 3 * gi, 3 * gj])
+
+
+def test_refocus_without_a_valid_ray_raises_like_the_reference(repo_root):
+    """refocus on an object 1 mm in front of the first surface: no ray gets through, np.mean([]) is NaN and the reference
+    stops with 'sensor position is negative.' (deeplens/optics.py:1176).  Same error from Lensgroup.refocus, and from a
+    pipelined stack through the flags word (bit 2) although only one of its focus states fails."""
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(64, 64), device=DEV)
+    good = lens.d_sensor
+    torch.manual_seed(0)
+    lens.refocus(-1.0)
+    with pytest.raises(AssertionError, match="sensor position is negative"):
+        lens.d_sensor
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(64, 64), device=DEV)
+    img = tt(synth_rgb(64, 64))[None].to(DEV)
+    plan = StackPlan(lens, 4, 64, 64, 1, 3, 3, 11, 256)
+    torch.manual_seed(0)
+    render_focal_stack_m1(lens, img, -1500.0, [-800.0, -1.0, -2000.0, -4000.0], 3, 11, 256, plan=plan, update_lens=False)
+    with pytest.raises(AssertionError, match="sensor position is negative"):
+        plan.check_flags()
+    torch.manual_seed(0)
+    render_focal_stack_m1(lens, img, -1500.0, [-800.0, -1200.0, -2000.0, -4000.0], 3, 11, 256, plan=plan, update_lens=False)
+    plan.check_flags()                                                      # the flag was consumed; a healthy stack raises nothing
+    assert good > 0
+
+
+def test_square_aperture_is_refused_cleanly():
+    """Square apertures (Surface(is_square=True) / Aspheric(square=True), deeplens/surfaces.py:17-20,330,416) are outside the
+    path; they cannot come from a lens file (read_lens_json never passes the flag) and the constructors say so."""
+    from deeplens.surfaces import Aspheric, Surface
+    for make in (lambda: Surface(5.0, 0.0, "air", "air", is_square=True, device="cpu"),
+                 lambda: Aspheric(5.0, 0.0, c=0.0, mat1="air", mat2="air", is_square=True, device="cpu"),
+                 lambda: Aspheric(5.0, 0.0, c=0.0, mat1="air", mat2="air", square=True, device="cpu")):
+        with pytest.raises(NotImplementedError, match="square apertures"):
+            make()
 
 
 # ================================================================= G2/G3: trace and splat

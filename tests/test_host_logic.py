@@ -248,10 +248,58 @@ def test_dff_factory_shims(repo_root):
     args = {"ks": 11, "res": (32, 48), "device": torch.device("cpu"), "train": thin, "test": dict(thin, dataset="Middlebury2014")}
     a, b = get_lens(args)
     assert isinstance(a, ThinLens) and isinstance(b, ThinLens) and a.ps == 24.0 / 32 and a.kernel_size == 11
-    with pytest.raises(NotImplementedError, match="Middlebury2014"):
+    args["test"]["dataset"] = "RealWorld"
+    with pytest.raises(NotImplementedError, match="RealWorld"):
         get_dataset(args)
     args["test"]["dataset"] = "Synthetic"
     tr, te = get_dataset(args)
     img, depth = tr[1]
     assert len(tr) == 3 and img.shape == (3, 32, 48) and depth.shape == (1, 32, 48) and 0.4 < float(depth.min()) and float(depth.max()) <= 5.0
     assert not torch.equal(tr[0][0], te[0][0])
+
+
+def test_middlebury_and_matterport_loaders_on_files_written_here(tmp_path):
+    """dff/dataset.py of the reference (:17-52, :170-200) restated with PIL: `im0.png` + 16-bit `depth.png` (mm) per scene ->
+    [RGB [3,H,W] in [0,1], depth [1,H,W] in metres], resized like the reference (image: antialiased bilinear; depth: plain
+    bilinear at pixel centres, cv.resize's default), selected through dff.factory.get_dataset by the reference's YAML keys."""
+    from PIL import Image
+    from dff.dataset import Matterport3D, Middlebury
+    from dff.factory import get_dataset
+    rng = np.random.Generator(np.random.PCG64(5))
+    root = tmp_path / "mb"
+    truth = {}
+    for name in ("Adirondack", "Jadeplant"):
+        (root / name).mkdir(parents=True)
+        rgb = rng.integers(0, 256, (40, 60, 3), dtype=np.uint8)
+        dep = rng.integers(500, 6000, (40, 60), dtype=np.uint16)
+        Image.fromarray(rgb).save(root / name / "im0.png")
+        Image.fromarray(dep).save(root / name / "depth.png")
+        truth[name] = (rgb, dep)
+    ds = Middlebury(str(root), resize=(40, 60))
+    assert len(ds) == 2 and ds.scenes == ["Adirondack", "Jadeplant"]
+    img, depth = ds[1]
+    rgb, dep = truth["Jadeplant"]
+    assert img.shape == (3, 40, 60) and img.dtype == torch.float32 and depth.shape == (1, 40, 60) and depth.dtype == torch.float32
+    assert torch.equal(img, torch.from_numpy((rgb / 255.0).astype("float32")).permute(2, 0, 1))
+    assert torch.equal(depth[0], torch.from_numpy((dep / 1000).astype("float32")))                 # uint16 mm -> m
+    small = Middlebury(str(root), resize=(20, 30))[0]
+    assert small[0].shape == (3, 20, 30) and small[1].shape == (1, 20, 30)
+    d64 = torch.from_numpy(truth["Adirondack"][1] / 1000)[None, None]
+    want = torch.nn.functional.interpolate(d64, size=(20, 30), mode="bilinear", align_corners=False)[0].float()
+    assert torch.equal(small[1], want)                                                             # exact 2x: mean of 2x2 blocks
+    assert torch.allclose(small[1][0, 3, 4], torch.from_numpy(truth["Adirondack"][1][6:8, 8:10] / 1000).mean().float(), atol=1e-6)
+    args = {"res": (20, 30), "train": {"dataset": "Synthetic", "n": 2}, "test": {"dataset": "Middlebury2014"}, "Middlebury2014_val": str(root)}
+    tr, te = get_dataset(args)
+    assert len(te) == 2 and te[0][0].shape == (3, 20, 30) and 0.5 <= float(te[0][1].min()) and float(te[0][1].max()) <= 6.0
+    mp3 = tmp_path / "mp"
+    (mp3 / "rgb" / "s0" / "undistorted_color_images").mkdir(parents=True)
+    (mp3 / "depth" / "s0" / "render_depth").mkdir(parents=True)
+    Image.fromarray(rgb).save(mp3 / "rgb" / "s0" / "undistorted_color_images" / "a.jpg", quality=95)
+    Image.fromarray((dep.astype(np.uint32) * 4).clip(0, 65535).astype(np.uint16)).save(mp3 / "depth" / "s0" / "render_depth" / "a.png")
+    m = Matterport3D(str(mp3 / "rgb"), str(mp3 / "depth"), resize=(40, 60), train=False)
+    i2, d2 = m[0]
+    assert len(m) == 1 and i2.shape == (3, 40, 60) and d2.shape == (1, 40, 60)
+    assert torch.allclose(d2[0], torch.from_numpy((dep / 1000).astype("float32")), atol=1e-6)      # 4000 units per metre
+    np.random.seed(0)
+    i3, d3 = Matterport3D(str(mp3 / "rgb"), str(mp3 / "depth"), resize=(40, 60), train=True)[0]   # augmentation path runs
+    assert i3.shape == (3, 40, 60) and d3.shape == (1, 40, 60) and float(d3.min()) >= 0

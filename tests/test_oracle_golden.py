@@ -91,6 +91,40 @@ def test_g14_named_glasses(golden_dir, repo_root):
     assert np.abs(pm.numpy() - gm["psf_map"]).max() <= ATOL
 
 
+def test_g15_four_coefficient_asphere_keeps_the_reference_wart(golden_dir, repo_root):
+    """G15: with four even-asphere coefficients the reference evaluates r^8 with the r^6 coefficient (surfaces.py:313);
+    the oracle must reproduce that (scalars, per-surface states, PSF map) - and must NOT match if the wart is 'fixed'."""
+    g = json.load(open(os.path.join(golden_dir, "g15_ai4.json")))
+    z = np.load(os.path.join(golden_dir, "g15_ai4.npz"))
+    path = lens_path(repo_root, "rf50mm_ai4")
+    lens = OracleLens(path, sensor_res=(256, 256))
+    for k in ("d_sensor", "hfov", "foclen", "fnum"):
+        assert getattr(lens, k) == pytest.approx(g["load"][k], rel=0, abs=1e-9), k
+    for f, want in g["refocus"].items():
+        lens = OracleLens(path, sensor_res=(256, 256))
+        torch.manual_seed(0)
+        lens.refocus(float(f))
+        for k in ("d_sensor", "hfov"):
+            assert getattr(lens, k) == pytest.approx(want[k], rel=0, abs=1e-9), (f, k)
+    lens = OracleLens(path, sensor_res=(256, 256))
+    torch.manual_seed(0)
+    lens.refocus(-1500.0)
+    rays = Rays(tt(z["ray_o0"]).clone(), tt(z["ray_d0"]).clone(), wvln=0.589, normalize=False)     # stored after Ray() normalised them
+    for i, s in enumerate(lens.surfaces):
+        rays = s.react(rays)
+        assert np.array_equal(rays.ra.numpy(), z["states_ra"][i]), f"surface {i} validity"
+        assert np.abs(rays.o.numpy() - z["states_o"][i]).max() <= ATOL and np.abs(rays.d.numpy() - z["states_d"][i]).max() <= ATOL, f"surface {i}"
+    torch.manual_seed(0)
+    pm = lens.psf_map(depth=-1200.0, grid=5, ks=11, spp=512)
+    assert np.abs(pm.numpy() - z["psf_map"]).max() <= ATOL
+    fixed = OracleLens(path, sensor_res=(256, 256))
+    rec = json.load(open(path))["surfaces"][8]
+    fixed.surfaces[8].ai[3] = torch.Tensor([rec["ai"][3]])          # what a 'corrected' implementation would use
+    torch.manual_seed(0)
+    fixed.refocus(-1500.0)
+    assert abs(fixed.d_sensor - float(z["d_sensor"])) > 1e-5
+
+
 def test_scalar_restatement_tracks_the_tensor_oracle(repo_root):
     """oracle/scalar_trace.py - the reference's surface arithmetic one float32 operation at a time - against the tensor
     oracle on the same batch: identical validity everywhere, the first surface's Newton root (10 batch-wide iterations

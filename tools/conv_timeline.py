@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Per-workgroup timeline of the stack convolution (instrumentation build csrc/libaadff_sbtrace.so, -DAADFF_SB_TRACE):
+every workgroup stamps the 100 MHz real-time counter at its start (0), after its early exit test (1), when its global
+loads have arrived (2), at the start of the matrix phase (3), after its last MFMA (4) and when its stores have retired (5),
+plus HW_ID / XCC_ID.  Prints the structure of the launch: when workgroups start (residency rounds), how long each phase
+takes inside the full kernel, how many workgroups share a CU over time.   python tools/conv_timeline.py [--json out]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "aberration-aware-depth-from-focus_amd")]
+import numpy as np
+import torch
+
+from aadff import _abi
+from aadff.synth import synth_rgb
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=os.path.join(os.path.dirname(_abi.LIB_PATH), "libaadff_sbtrace.so"))
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--runs", type=int, default=5)
+    a = ap.parse_args()
+    lib = _abi.load_library(a.lib)
+    dev = torch.device("cuda:0")
+    H = W = 1024
+    S, G, KS = 10, 11, 11
+    img = torch.from_numpy(synth_rgb(H, W))[None].to(dev)
+    rng = np.random.Generator(np.random.PCG64(3))
+    maps = torch.from_numpy(rng.random((S, 3, G * KS, G * KS), dtype=np.float32)).to(dev) / 121
+    out = torch.empty((1, 3, S, H, W), device=dev)
+    n_wg = 11 * 11 * 4 * 3                                # sntx*grid x snty*grid x B*C*npass for this workload
+    buf = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
+    lib.aadff_sb_trace_buffer.argtypes = [C.c_void_p]
+    st = _abi.stream_ptr(dev)
+    call = lambda: lib.aadff_render_psf_map_stack(C.c_void_p(img.data_ptr()), C.c_void_p(maps.data_ptr()), C.c_void_p(out.data_ptr()), 1, 3, S, H, W, G, KS, st)
+    assert lib.aadff_sb_trace_buffer(None) == 0
+    for _ in range(30):
+        assert call() == 0
+    torch.cuda.synchronize()
+    res = []
+    for r in range(a.runs):
+        buf.zero_()
+        assert lib.aadff_sb_trace_buffer(C.c_void_p(buf.data_ptr())) == 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            call()                                        # back to back: the traced launch is the last one
+        e0.record()
+        assert call() == 0
+        e1.record()
+        torch.cuda.synchronize()
+        t = buf.cpu().numpy().reshape(n_wg, 8).astype(np.int64)
+        live = t[:, 1] > 0
+        t = t[live]
+        t0 = t[:, 0].min()
+        us = lambda col: (t[:, col] - t0) / 100.0          # 100 MHz -> microseconds
+        hw = t[:, 6] & 0xFFFFFFFF
+        xcc = t[:, 6] >> 32
+        cu = ((xcc & 0xF) << 16) | (((hw >> 13) & 0x7) << 8) | (((hw >> 12) & 0x1) << 4) | ((hw >> 8) & 0xF)   # XCC | SE | SH | CU
+        start, loaded, main0, main1, end = us(0), us(2), us(3), us(4), us(5)
+        late = start > 10.0
+        per_cu = np.array([np.sum(cu == c) for c in np.unique(cu)])
+        rec = {"event_us": round(e0.elapsed_time(e1) * 1e3, 2), "workgroups": int(live.sum()), "cus_seen": int(len(np.unique(cu))),
+               "span_us": round(float(end.max()), 2),
+               "start_us": {"p50": round(float(np.median(start)), 2), "p90": round(float(np.percentile(start, 90)), 2), "max": round(float(start.max()), 2)},
+               "second_round_workgroups": int(late.sum()),
+               "second_round_first_start_us": round(float(start[late].min()), 2) if late.any() else None,
+               "prologue_us (start -> matrix phase)": {"p50": round(float(np.median(main0 - start)), 2), "p90": round(float(np.percentile(main0 - start, 90)), 2)},
+               "  of which until the global loads arrived": {"p50": round(float(np.median(loaded - start)), 2)},
+               "matrix_phase_us": {"p50": round(float(np.median(main1 - main0)), 2), "p90": round(float(np.percentile(main1 - main0, 90)), 2),
+                                   "second_round_p50": round(float(np.median((main1 - main0)[late])), 2) if late.any() else None},
+               "store_drain_us": {"p50": round(float(np.median(end - main1)), 2)},
+               "first_round_end_us": {"p50": round(float(np.median(end[~late])), 2), "max": round(float(end[~late].max()), 2)},
+               "workgroups_per_cu": {"min": int(per_cu.min()), "max": int(per_cu.max()), "mean": round(float(per_cu.mean()), 2)}}
+        res.append(rec)
+    res.sort(key=lambda r: r["event_us"])
+    pick = res[len(res) // 2]
+    print(json.dumps(pick, indent=1))
+    if a.json:
+        json.dump({"median_run": pick, "all_runs_event_us": [r["event_us"] for r in res]}, open(a.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Reproduce and diagnose the 'pytest does not exit after the last test' hang.
 
-Runs the CPU suite N times WITHOUT the conftest os._exit shortcut (AADFF_TEST_NORMAL_EXIT=1).  A run that is still alive
+Runs the CPU suite N times (the conftest no longer short-cuts the interpreter exit; round 2 did, with os._exit).  A run that is still alive
 `--grace` seconds after pytest printed its summary line is a reproduction: every thread of the process and of its
 children is listed with its kernel wait channel, state and kernel stack (/proc), then the exact PIDs are killed.
 Usage: python tools/exit_hang_probe.py [--runs 10] [--grace 60] [--out build/hang]"""
