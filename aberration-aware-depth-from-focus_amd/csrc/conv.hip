@@ -433,6 +433,8 @@ __global__ __launch_bounds__(64 * NW) void conv_psf_map_mfma_kernel(
 // zero-padded tap rows in LDS; a workgroup = NC slice chunks x 2 row groups sharing one staged band of a patch, so
 // the image is read from HBM once for all slices.  Same exact fp16 hi/lo operand split as above.
 // ------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) void* lp_gptr_t;
+typedef __attribute__((address_space(3))) void* lp_lptr_t;
 namespace sb {
 constexpr int KS = 11, PAD = 5;
 constexpr int TCOLS = 96;                 // output columns per workgroup tile (3 column blocks of 32)
@@ -447,10 +449,43 @@ typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(4))) f2u { float x, y; };       // 8-byte store at 4-byte alignment
 
 // 16 operand bytes as two ds_read_b64 (full-rate LDS reads; a ds_read2_b64 or an 8-byte-aligned b128 is half rate
-// or worse).  Not tracked by the compiler's waitcnt insertion: consume only after lds_wait().
+// or worse).  Not tracked by the compiler's waitcnt insertion: consume only after lds_wait().  The outputs are EARLY-CLOBBER:
+// the statement holds two instructions, and with plain "=v" the allocator may give the first read's destination the
+// address register - the second read then takes its address from a register the first one's returning data overwrites
+// whenever the wave is held between the two for longer than the LDS latency (seen in round 3 as one wrong 2x2 output
+// block per ~100 000, never the same one: `ds_read_b64 v[50:51], v50 ...; ds_read_b64 v[52:53], v50 ...`).
+// -DAADFF_SB_DPP=1 (experiment, round 3, rejected): the matrix phase is bound by the LDS operand reads (17 wave-bands x 720
+// reads x 4 cycles = 20 us per CU against 15 us of MFMA), and half of what it reads is read twice - lane cx's second 8
+// bytes (columns 2, 3 of its 2 x 4 block) are lane cx + 1's first 8.  In this form only the LAST lane of each 16-lane row
+// fetches its second half from LDS (a 4-lane ds_read_b64 under an exec mask: same instruction count, so the lgkmcnt
+// bookkeeping is unchanged) and lanes 0..14 take it from their right-hand neighbour with a DPP row shift once the data has
+// landed (lds_share16).  Bit-equal output, but SLOWER (matrix phase 18.6 -> 23.7 us): a ds_read_b64 occupies the LDS pipe
+// for its four passes whatever the exec mask, so the bytes saved buy nothing and the exec switches + 4 DPP moves are pure cost.
+#ifndef AADFF_SB_DPP
+#define AADFF_SB_DPP 0
+#endif
 template <int OFF>
 __device__ __forceinline__ void lds_read16(uint2v& a, uint2v& b, unsigned byte_addr) {
-    asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4" : "=v"(a), "=v"(b) : "v"(byte_addr), "n"(OFF), "n"(OFF + 8));
+#if AADFF_SB_DPP
+    unsigned long long keep;
+    // (s_mov, not s_and_saveexec: the statement must leave SCC alone - the compiler keeps loop conditions in it; every lane
+    // is active in the matrix phase, so the mask itself is the wanted EXEC)
+    asm volatile("ds_read_b64 %0, %3 offset:%5\n\t"
+                 "s_mov_b64 %2, exec\n\t"
+                 "s_mov_b64 exec, %4\n\t"
+                 "ds_read_b64 %1, %3 offset:%6\n\t"
+                 "s_mov_b64 exec, %2"
+                 : "=&v"(a), "=&v"(b), "=&s"(keep) : "v"(byte_addr), "s"(0x8000800080008000ull), "n"(OFF), "n"(OFF + 8));
+#else
+    asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4" : "=&v"(a), "=&v"(b) : "v"(byte_addr), "n"(OFF), "n"(OFF + 8));
+#endif
+}
+// after the wait that retires a lds_read16: second half of lanes 0..14 of every row = first half of the lane to the right
+__device__ __forceinline__ void lds_share16(const uint2v& a, uint2v& b) {
+#if AADFF_SB_DPP
+    b.x = (unsigned)__builtin_amdgcn_update_dpp((int)b.x, (int)a.x, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+    b.y = (unsigned)__builtin_amdgcn_update_dpp((int)b.y, (int)a.y, 0x101, 0xf, 0xf, false);
+#endif
 }
 }  // namespace sb
 
@@ -466,10 +501,16 @@ __device__ unsigned long long* g_sb_trace = nullptr;
 // Workgroup = one band of RB output rows x 96 columns of one patch and channel plane; wave = one chunk of 4 slices
 // (NC waves).  The band is staged once for all slices (HBM reads the image once), every wave builds the T fragments
 // of its own chunk and walks the band's row pairs.
-template <int RB, int NC>
-__global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
+#ifndef AADFF_SB_ILP
+#define AADFF_SB_ILP 0                  // 1: three accumulators per row pair, k-step outermost (158 VGPRs: 4 workgroups per CU)
+#endif
+#ifndef AADFF_CONV_PAIR_DEFAULT
+#define AADFF_CONV_PAIR_DEFAULT 0      // measured: every pairing is slower than one band per workgroup
+#endif
+template <int RB, int NC, bool PAIR, bool ILP = PAIR && AADFF_SB_ILP>
+__global__ __launch_bounds__(64 * NC, (PAIR && AADFF_SB_ILP ? 3 : 1)) void conv_psf_map_sbatch_kernel(
     const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
-    int grid, int ntx, int nty, int npass, PatchBounds pb, int stagger) {
+    int grid, int ntx, int nty, int npass, PatchBounds pb, int stagger, int pair_mod) {
     using namespace sb;
     AADFF_SB_STAMP(0);
     if (stagger) {
@@ -484,7 +525,11 @@ __global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
     static_assert(RB % 2 == 0 && THP % 2 == 0, "bands are whole row pairs");
     static_assert(WDW <= 64, "one lane per dword column");
     __shared__ __attribute__((aligned(16))) unsigned tile[(THP / 2) * RPP];
-    __shared__ __attribute__((aligned(16))) unsigned prow[2][NSL * PSL];            // [hi | lo] planes of the padded tap rows
+    // [hi | lo] planes of the padded tap rows; PAIR: once the T fragments are built the same memory (and a little more) is
+    // the landing zone of the second band's raw fp32 rows (LDS-DMA), THP rows x WCOLS floats
+    constexpr int PROW_DW = 2 * NSL * PSL, STAGE_DW = PAIR ? THP * WCOLS : 0, POOL_DW = PROW_DW > STAGE_DW ? PROW_DW : STAGE_DW;
+    __shared__ __attribute__((aligned(16))) unsigned pool[POOL_DW];
+    unsigned (*prow)[NSL * PSL] = reinterpret_cast<unsigned (*)[NSL * PSL]>(pool);
     __shared__ float red[NW];
     __shared__ float s_isw[NSL];
 
@@ -493,6 +538,14 @@ __global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
     const int pj = udiv_magic(blockIdx.x, ntx, pb.m_ntx), tx = blockIdx.x - pj * ntx;
     const int pi = udiv_magic(blockIdx.y, nty, pb.m_nty), ty = blockIdx.y - pi * nty;
     const int bc = udiv_magic(blockIdx.z, npass, pb.m_nchunk), pass = blockIdx.z - bc * npass;
+    // PAIR: every pair_mod-th (patch, plane) renders its bands two per workgroup - the even band's workgroup also takes the
+    // odd one, whose own workgroup leaves at once; pair_mod = 1 pairs everything (half the live workgroups), 4 pairs a
+    // quarter: just enough fewer workgroups for the whole launch to be resident in one round (1280 slots at 5 per CU)
+    bool paired = false;
+    if constexpr (PAIR) {
+        paired = (unsigned)((bc * grid + pi) * grid + pj) % (unsigned)pair_mod == 0u;
+        if (paired && (ty & 1)) return;
+    }
     const int c = bc - udiv_magic(bc, C, pb.m_c) * C;
     const int x_hi = pb.wb[pj + 1], y_hi = pb.hb[pi + 1];
     const int x0 = pb.wb[pj] + tx * TCOLS, y0 = pb.hb[pi] + ty * RB;
@@ -621,9 +674,32 @@ __global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
                               __builtin_amdgcn_alignbit(a1[2], a1[1], sh), __builtin_amdgcn_alignbit(a1[PRD + 2], a1[PRD + 1], sh)};
         }
     }
-    const float inv = isx * s_isw[chunk * 4 + kg];                            // D rows 4 kg + i belong to slice kg of the chunk
+    float inv = isx * s_isw[chunk * 4 + kg];                                  // D rows 4 kg + i belong to slice kg of the chunk
     __syncthreads();                                                          // the whole band is in LDS
     AADFF_SB_STAMP(3);
+
+    // PAIR: the second band of this patch (same PSFs -> same T fragments, already in registers) is fetched NOW, by LDS-DMA
+    // (no registers, nothing to wait for) into the memory the tap rows no longer need, while the first band is in its matrix
+    // phase: its load latency (8 us of 11 us of prologue, tools/conv_timeline.py) is hidden and the launch has half as many
+    // workgroups (all resident at once: no second residency round).
+    const int y0b = y0 + RB;
+    const bool second = PAIR && paired && y0b < y_hi;
+    if constexpr (PAIR) {
+        if (second) {
+            const float* plane = img + (size_t)bc * H * W;
+            const int xa = reflect_idx(x0 - PAD + lane, W), xb = reflect_idx(x0 - PAD + 64 + lane, W);
+#pragma unroll
+            for (int e = 0; e < NPT; ++e) {
+                const int r = wave + e * NW;
+                if (r < THP) {
+                    const float* row = plane + (size_t)reflect_idx(y0b - PAD + r, H) * W;
+                    // (the instruction offset would shift the global address too: the second piece gets its own LDS base)
+                    __builtin_amdgcn_global_load_lds((lp_gptr_t)(row + xa), (lp_lptr_t)(pool + r * WCOLS), 4, 0, 0);
+                    if (lane < WCOLS - 64) __builtin_amdgcn_global_load_lds((lp_gptr_t)(row + xb), (lp_lptr_t)(pool + r * WCOLS + 64), 4, 0, 0);
+                }
+            }
+        }
+    }
 
     const int s_out = s_base + chunk * 4 + kg;
     const bool s_ok = s_out < S;
@@ -649,63 +725,222 @@ __global__ __launch_bounds__(64 * NC) void conv_psf_map_sbatch_kernel(
         xaddr[st] = tile_base + 4u * (unsigned)(up * RPP + 2 * (lo4 + dd0));
     }
 
-    int npairs = (y_hi - y0 + 1) / 2;                   // row pairs of this band that hold valid rows
-    npairs = npairs > RB / 2 ? RB / 2 : npairs;
-    // 15 (cb, st) steps per row pair, operand reads two steps ahead (three 8-register buffers; 15 % 3 == 0 keeps the
-    // rotation across row pairs, so the last two steps prefetch the next row pair's first two).  Column block
-    // outermost: one accumulator live, its stores overlap the next block's MFMAs.
-    uint2v xq[3][4];                                    // [buffer][hi0, hi1, lo0, lo1]
-    auto issue = [&](auto stepc, unsigned rowb) {
-        constexpr int step = decltype(stepc)::value, cb = step / 5, st = step % 5, bf = step % 3;
-        const unsigned a = xaddr[st] + rowb;
-        lds_read16<cb * 128>(xq[bf][0], xq[bf][1], a);
-        lds_read16<LO * 4 + cb * 128>(xq[bf][2], xq[bf][3], a);
-    };
-    issue(std::integral_constant<int, 0>{}, 0u);
-    issue(std::integral_constant<int, 1>{}, 0u);
+    // ---- matrix phase of one band (rows yb .. yb + RB - 1 of the image, staged in `tile`) ----
+    auto run_band = [&](const int yb, const float inv) {
+        int npairs = (y_hi - yb + 1) / 2;                   // row pairs of this band that hold valid rows
+        npairs = npairs > RB / 2 ? RB / 2 : npairs;
+        if constexpr (ILP) {
+            // k-step outermost, the three column blocks of a row pair in three accumulators: the nine MFMAs of a k-step go out
+            // as hh(0) hh(1) hh(2) hl(0) hl(1) hl(2) lh(0) lh(1) lh(2), so an accumulator is touched every third issue slot
+            // (48 cycles: the latency of a dependent 16x16x32 MFMA) instead of 15 times in a row - with the 8-9 waves per CU of
+            // the paired launch a wave can no longer count on other waves to fill its dependency gaps.  Operands of the next
+            // k-step (3 fragments, 12 ds_read_b64) are fetched while the current one is in the matrix pipe; two sets of
+            // registers alternate, and since a row pair has five k-steps the roles swap from one row pair to the next (P).
+            uint2v xs[2][3][4];                             // [set][column block][hi0, hi1, lo0, lo1]
+            auto issue_set = [&](auto setc, auto stc, unsigned rowb) {
+                constexpr int set = decltype(setc)::value, st = decltype(stc)::value;
+                const unsigned a = xaddr[st] + rowb;
+                lds_read16<0>(xs[set][0][0], xs[set][0][1], a);
+                lds_read16<LO * 4>(xs[set][0][2], xs[set][0][3], a);
+                lds_read16<128>(xs[set][1][0], xs[set][1][1], a);
+                lds_read16<LO * 4 + 128>(xs[set][1][2], xs[set][1][3], a);
+                lds_read16<256>(xs[set][2][0], xs[set][2][1], a);
+                lds_read16<LO * 4 + 256>(xs[set][2][2], xs[set][2][3], a);
+            };
+            auto row_pair = [&](auto pc, const int rpi) {
+                constexpr int P = decltype(pc)::value;
+                const unsigned rowb = (unsigned)(rpi * RPP * 4);
+                const unsigned rowb_next = (unsigned)((rpi + 1 < npairs ? rpi + 1 : rpi) * RPP * 4);
+                const int yl = 2 * rpi;
+                const bool row1 = yb + yl + 1 < y_hi;
+                const unsigned loff = koff + (unsigned)(yb + yl) * w4 + (unsigned)(x0 + 2 * lo4) * 4u;
+                float4v acc[3];
+                auto kstep = [&](auto stc) {
+                    constexpr int st = decltype(stc)::value, cur = (P + st) & 1, nxt = cur ^ 1;
+#if defined(AADFF_SB_ABL) && AADFF_SB_ABL == 3      // ablation: operand reads only for the first k-step of a band
+                    if (rpi == 0 && st == 0) {
+#else
+                    {
+#endif
+                    if constexpr (st < 4) issue_set(std::integral_constant<int, nxt>{}, std::integral_constant<int, st + 1>{}, rowb);
+                    else issue_set(std::integral_constant<int, nxt>{}, std::integral_constant<int, 0>{}, rowb_next);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(12)"
+                                 : "+v"(xs[cur][0][0]), "+v"(xs[cur][0][1]), "+v"(xs[cur][0][2]), "+v"(xs[cur][0][3]),
+                                   "+v"(xs[cur][1][0]), "+v"(xs[cur][1][1]), "+v"(xs[cur][1][2]), "+v"(xs[cur][1][3]),
+                                   "+v"(xs[cur][2][0]), "+v"(xs[cur][2][1]), "+v"(xs[cur][2][2]), "+v"(xs[cur][2][3]));
+                    half8v bh[3], bl[3];
+#pragma unroll
+                    for (int cb = 0; cb < 3; ++cb) {
+                        lds_share16(xs[cur][cb][0], xs[cur][cb][1]);
+                        lds_share16(xs[cur][cb][2], xs[cur][cb][3]);
+                        const uint4v h4 = {xs[cur][cb][0].x, xs[cur][cb][0].y, xs[cur][cb][1].x, xs[cur][cb][1].y};
+                        const uint4v l4 = {xs[cur][cb][2].x, xs[cur][cb][2].y, xs[cur][cb][3].x, xs[cur][cb][3].y};
+                        bh[cb] = __builtin_bit_cast(half8v, h4);
+                        bl[cb] = __builtin_bit_cast(half8v, l4);
+                    }
+                    const half8v th = __builtin_bit_cast(half8v, Th[st]), tl = __builtin_bit_cast(half8v, Tl[st]);
+                    if constexpr (st == 0) {
+#pragma unroll
+                        for (int cb = 0; cb < 3; ++cb) acc[cb] = (float4v){0.f, 0.f, 0.f, 0.f};
+                    }
+#if defined(AADFF_SB_ABL) && AADFF_SB_ABL == 2      // ablation: no matrix work (one cheap VALU op keeps the operands live)
+#pragma unroll
+                    for (int cb = 0; cb < 3; ++cb) acc[cb][0] += __builtin_bit_cast(float, xs[cur][cb][0].x ^ xs[cur][cb][2].y ^ Th[st].x);
+#else
+#pragma unroll
+                    for (int cb = 0; cb < 3; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bh[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+                    for (int cb = 0; cb < 3; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bl[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+                    for (int cb = 0; cb < 3; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl, bh[cb], acc[cb], 0, 0, 0);
+#endif
+                };
+                kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{}); kstep(std::integral_constant<int, 2>{});
+                kstep(std::integral_constant<int, 3>{}); kstep(std::integral_constant<int, 4>{});
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) {
+                    // D[m = 4 kg + i][n = cx]: i = (du, j) -> out[slice kg][y + du][x0 + 32 cb + 2 cx + j]
+                    const float a0 = acc[cb][0] * inv, b0 = acc[cb][1] * inv, a1 = acc[cb][2] * inv, b1 = acc[cb][3] * inv;
+                    char* o0 = wbase + loff + cb * 128;
+                    char* o1 = wbase + (loff + w4) + cb * 128;
+#if defined(AADFF_SB_ABL) && AADFF_SB_ABL == 1      // ablation: no stores unless a value is NaN (never)
+                    if (a0 != a0 || b0 != b0 || a1 != a1 || b1 != b1)
+#endif
+                    if (pair_ok[cb]) {
+                        *reinterpret_cast<f2u*>(o0) = (f2u){a0, b0};
+                        if (row1) *reinterpret_cast<f2u*>(o1) = (f2u){a1, b1};
+                    } else if (one_ok[cb]) {
+                        *reinterpret_cast<float*>(o0) = a0;
+                        if (row1) *reinterpret_cast<float*>(o1) = a1;
+                    }
+                }
+            };
+            issue_set(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0u);
+            int rpi = 0;
 #pragma unroll 1
-    for (int rpi = 0; rpi < npairs; ++rpi) {
-        const unsigned rowb = (unsigned)(rpi * RPP * 4);
-        const unsigned rowb_next = (unsigned)((rpi + 1 < npairs ? rpi + 1 : rpi) * RPP * 4);
-        const int yl = 2 * rpi;
-        const bool row1 = y0 + yl + 1 < y_hi;           // row 0 of the pair is valid by construction of npairs
-        const unsigned loff = koff + (unsigned)(y0 + yl) * w4 + (unsigned)(x0 + 2 * lo4) * 4u;
-        float4v acc;
-        auto step_fn = [&](auto stepc) {
+            for (; rpi + 1 < npairs; rpi += 2) {
+                row_pair(std::integral_constant<int, 0>{}, rpi);
+                row_pair(std::integral_constant<int, 1>{}, rpi + 1);
+            }
+            if (rpi < npairs) row_pair(std::integral_constant<int, 0>{}, rpi);
+            // The set prefetched by the last k-step is never consumed: its destination registers must stay OWNED until the
+            // reads have landed (named here), or the allocator hands them to the next address computation and a late return
+            // overwrites it (seen as a write fault in the instrumented build).
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(xs[0][0][0]), "+v"(xs[0][0][1]), "+v"(xs[0][0][2]), "+v"(xs[0][0][3]), "+v"(xs[0][1][0]), "+v"(xs[0][1][1]),
+                           "+v"(xs[0][1][2]), "+v"(xs[0][1][3]), "+v"(xs[0][2][0]), "+v"(xs[0][2][1]), "+v"(xs[0][2][2]), "+v"(xs[0][2][3]),
+                           "+v"(xs[1][0][0]), "+v"(xs[1][0][1]), "+v"(xs[1][0][2]), "+v"(xs[1][0][3]), "+v"(xs[1][1][0]), "+v"(xs[1][1][1]),
+                           "+v"(xs[1][1][2]), "+v"(xs[1][1][3]), "+v"(xs[1][2][0]), "+v"(xs[1][2][1]), "+v"(xs[1][2][2]), "+v"(xs[1][2][3])
+                         :: "memory");
+            return;
+        }
+        // 15 (cb, st) steps per row pair, operand reads two steps ahead (three 8-register buffers; 15 % 3 == 0 keeps the
+        // rotation across row pairs, so the last two steps prefetch the next row pair's first two).  Column block
+        // outermost: one accumulator live, its stores overlap the next block's MFMAs.
+        uint2v xq[3][4];                                    // [buffer][hi0, hi1, lo0, lo1]
+        auto issue = [&](auto stepc, unsigned rowb) {
             constexpr int step = decltype(stepc)::value, cb = step / 5, st = step % 5, bf = step % 3;
-            if constexpr (step + 2 < 15) issue(std::integral_constant<int, step + 2>{}, rowb);
-            else issue(std::integral_constant<int, step + 2 - 15>{}, rowb_next);
-            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xq[bf][0]), "+v"(xq[bf][1]), "+v"(xq[bf][2]), "+v"(xq[bf][3]));
-            const uint4v h4 = {xq[bf][0].x, xq[bf][0].y, xq[bf][1].x, xq[bf][1].y};
-            const uint4v l4 = {xq[bf][2].x, xq[bf][2].y, xq[bf][3].x, xq[bf][3].y};
-            const half8v bh = __builtin_bit_cast(half8v, h4), bl = __builtin_bit_cast(half8v, l4);
-            const half8v th = __builtin_bit_cast(half8v, Th[st]), tl = __builtin_bit_cast(half8v, Tl[st]);
-            if constexpr (st == 0) acc = (float4v){0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl, bh, acc, 0, 0, 0);
-            if constexpr (st == 4) {
-                // D[m = 4 kg + i][n = cx]: i = (du, j) -> out[slice kg][y + du][x0 + 32 cb + 2 cx + j]
-                const float a0 = acc[0] * inv, b0 = acc[1] * inv, a1 = acc[2] * inv, b1 = acc[3] * inv;
-                char* o0 = wbase + loff + cb * 128;
-                char* o1 = wbase + (loff + w4) + cb * 128;
-                if (pair_ok[cb]) {
-                    *reinterpret_cast<f2u*>(o0) = (f2u){a0, b0};
-                    if (row1) *reinterpret_cast<f2u*>(o1) = (f2u){a1, b1};
-                } else if (one_ok[cb]) {
-                    *reinterpret_cast<float*>(o0) = a0;
-                    if (row1) *reinterpret_cast<float*>(o1) = a1;
+            const unsigned a = xaddr[st] + rowb;
+            lds_read16<cb * 128>(xq[bf][0], xq[bf][1], a);
+            lds_read16<LO * 4 + cb * 128>(xq[bf][2], xq[bf][3], a);
+        };
+        issue(std::integral_constant<int, 0>{}, 0u);
+        issue(std::integral_constant<int, 1>{}, 0u);
+    #pragma unroll 1
+        for (int rpi = 0; rpi < npairs; ++rpi) {
+            const unsigned rowb = (unsigned)(rpi * RPP * 4);
+            const unsigned rowb_next = (unsigned)((rpi + 1 < npairs ? rpi + 1 : rpi) * RPP * 4);
+            const int yl = 2 * rpi;
+            const bool row1 = yb + yl + 1 < y_hi;           // row 0 of the pair is valid by construction of npairs
+            const unsigned loff = koff + (unsigned)(yb + yl) * w4 + (unsigned)(x0 + 2 * lo4) * 4u;
+            float4v acc;
+            auto step_fn = [&](auto stepc) {
+                constexpr int step = decltype(stepc)::value, cb = step / 5, st = step % 5, bf = step % 3;
+                if constexpr (step + 2 < 15) issue(std::integral_constant<int, step + 2>{}, rowb);
+                else issue(std::integral_constant<int, step + 2 - 15>{}, rowb_next);
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xq[bf][0]), "+v"(xq[bf][1]), "+v"(xq[bf][2]), "+v"(xq[bf][3]));
+                lds_share16(xq[bf][0], xq[bf][1]);
+                lds_share16(xq[bf][2], xq[bf][3]);
+                const uint4v h4 = {xq[bf][0].x, xq[bf][0].y, xq[bf][1].x, xq[bf][1].y};
+                const uint4v l4 = {xq[bf][2].x, xq[bf][2].y, xq[bf][3].x, xq[bf][3].y};
+                const half8v bh = __builtin_bit_cast(half8v, h4), bl = __builtin_bit_cast(half8v, l4);
+                const half8v th = __builtin_bit_cast(half8v, Th[st]), tl = __builtin_bit_cast(half8v, Tl[st]);
+                if constexpr (st == 0) acc = (float4v){0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl, bh, acc, 0, 0, 0);
+                if constexpr (st == 4) {
+                    // D[m = 4 kg + i][n = cx]: i = (du, j) -> out[slice kg][y + du][x0 + 32 cb + 2 cx + j]
+                    const float a0 = acc[0] * inv, b0 = acc[1] * inv, a1 = acc[2] * inv, b1 = acc[3] * inv;
+                    char* o0 = wbase + loff + cb * 128;
+                    char* o1 = wbase + (loff + w4) + cb * 128;
+                    if (pair_ok[cb]) {
+                        *reinterpret_cast<f2u*>(o0) = (f2u){a0, b0};
+                        if (row1) *reinterpret_cast<f2u*>(o1) = (f2u){a1, b1};
+                    } else if (one_ok[cb]) {
+                        *reinterpret_cast<float*>(o0) = a0;
+                        if (row1) *reinterpret_cast<float*>(o1) = a1;
+                    }
+                }
+            };
+            step_fn(std::integral_constant<int, 0>{}); step_fn(std::integral_constant<int, 1>{}); step_fn(std::integral_constant<int, 2>{});
+            step_fn(std::integral_constant<int, 3>{}); step_fn(std::integral_constant<int, 4>{}); step_fn(std::integral_constant<int, 5>{});
+            step_fn(std::integral_constant<int, 6>{}); step_fn(std::integral_constant<int, 7>{}); step_fn(std::integral_constant<int, 8>{});
+            step_fn(std::integral_constant<int, 9>{}); step_fn(std::integral_constant<int, 10>{}); step_fn(std::integral_constant<int, 11>{});
+            step_fn(std::integral_constant<int, 12>{}); step_fn(std::integral_constant<int, 13>{}); step_fn(std::integral_constant<int, 14>{});
+        }
+        // the two prefetches issued by the last row pair are never consumed: their registers stay owned until they have landed
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(xq[0][0]), "+v"(xq[0][1]), "+v"(xq[0][2]), "+v"(xq[0][3]), "+v"(xq[1][0]), "+v"(xq[1][1]), "+v"(xq[1][2]), "+v"(xq[1][3]),
+                       "+v"(xq[2][0]), "+v"(xq[2][1]), "+v"(xq[2][2]), "+v"(xq[2][3])
+                     :: "memory");
+    };
+    run_band(y0, inv);
+    AADFF_SB_STAMP(4);
+    if constexpr (PAIR) {
+        if (second) {
+            // ---- second band: raw rows (DMA, landed during the first band's matrix phase) -> scaled fp16 hi/lo tile ----
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's DMA pieces (and its stores of the first band)
+            __syncthreads();                                      // every wave's pieces; nobody reads the old tile any more
+            {
+            const float* stg = reinterpret_cast<const float*>(pool);
+            float bmax = 0.f;
+#pragma unroll
+            for (int e = 0; e < NPT; ++e) {
+                const int r = wave + e * NW;
+                const bool in = lane < WDW && r < THP;
+                const float2 v = in ? *reinterpret_cast<const float2*>(stg + r * WCOLS + 2 * lane) : make_float2(0.f, 0.f);
+                v0[e] = v.x; v1[e] = v.y;
+                bmax = fmaxf(bmax, fmaxf(fabsf(v.x), fabsf(v.y)));
+            }
+            bmax = wave_max(bmax);
+            if (lane == 0) red[wave] = bmax;
+            __syncthreads();
+            float t2 = red[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) t2 = fmaxf(t2, red[w]);
+            float sx2, isx2;
+            pow2_scale(t2, sx2, isx2);
+#pragma unroll
+            for (int e = 0; e < NPT; ++e) {
+                const int r = wave + e * NW;
+                if (lane < WDW && r < THP) {
+                    const float a = v0[e] * sx2, b = v1[e] * sx2;
+                    const _Float16 ah = (_Float16)a, bh = (_Float16)b;
+                    const _Float16 al = (_Float16)(a - (float)ah), bl = (_Float16)(b - (float)bh);
+                    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                    const int d = (r >> 1) * RPP + 2 * lane + (r & 1);
+                    tile[d] = __builtin_bit_cast(unsigned, (half2v){ah, bh});
+                    tile[d + LO] = __builtin_bit_cast(unsigned, (half2v){al, bl});
                 }
             }
-        };
-        step_fn(std::integral_constant<int, 0>{}); step_fn(std::integral_constant<int, 1>{}); step_fn(std::integral_constant<int, 2>{});
-        step_fn(std::integral_constant<int, 3>{}); step_fn(std::integral_constant<int, 4>{}); step_fn(std::integral_constant<int, 5>{});
-        step_fn(std::integral_constant<int, 6>{}); step_fn(std::integral_constant<int, 7>{}); step_fn(std::integral_constant<int, 8>{});
-        step_fn(std::integral_constant<int, 9>{}); step_fn(std::integral_constant<int, 10>{}); step_fn(std::integral_constant<int, 11>{});
-        step_fn(std::integral_constant<int, 12>{}); step_fn(std::integral_constant<int, 13>{}); step_fn(std::integral_constant<int, 14>{});
+            inv = isx2 * s_isw[chunk * 4 + kg];
+            }
+            __syncthreads();
+            run_band(y0b, inv);
+        }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the two prefetches issued by the last row pair
-    AADFF_SB_STAMP(4);
 #ifdef AADFF_SB_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stores retired
     AADFF_SB_STAMP(5);
@@ -806,16 +1041,22 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
             AADFF_CHECK_ARG((size_t)B * C * npass <= 65535 && (size_t)snty * grid <= 65535, "render_psf_map: grid too large");
             AADFF_CHECK_ARG((size_t)H * W <= ((size_t)1 << 27) && 16 * (size_t)ss + 4 * (size_t)H * W < ((size_t)1 << 32),
                             "render_psf_map: image planes above 2^27 pixels / slice strides above 2^28 elements are not supported on the stack path");
+            // paired bands (default): a workgroup renders two consecutive bands of its patch, the second one prefetched by LDS-DMA
+            // AADFF_CONV_PAIR: 0 = one band per workgroup (round-2 form), N >= 1 = bands in pairs for every N-th (patch, plane)
+            const int pair_mod = [] { const char* e = getenv("AADFF_CONV_PAIR"); const int v = e ? atoi(e) : AADFF_CONV_PAIR_DEFAULT; return v < 0 ? 0 : v; }();   // read per launch: tests switch it
+            const bool pair = pair_mod > 0;
+            const int gny = snty;
             PatchBounds pbs = pb;
-            pbs.m_ntx = magic_of(sntx); pbs.m_nty = magic_of(snty); pbs.m_nchunk = magic_of(npass); pbs.m_c = magic_of(C);
-            dim3 gs(sntx * grid, snty * grid, B * C * npass);
+            pbs.m_ntx = magic_of(sntx); pbs.m_nty = magic_of(gny); pbs.m_nchunk = magic_of(npass); pbs.m_c = magic_of(C);
+            dim3 gs(sntx * grid, gny * grid, B * C * npass);
             static const int stagger = [] { const char* e = getenv("AADFF_CONV_STAGGER"); const int v = e ? atoi(e) : 1; return v < 0 ? 0 : (v > 64 ? 64 : v); }();   // default 1: -1 % in bench, -7 % back to back
             // aadff_time_next_launch: the two events ride ON this dispatch (kernel begin / end timestamps)
             hipEvent_t ev0 = g_time_start, ev1 = g_time_stop;
             g_time_start = g_time_stop = nullptr;
-#define AADFF_LAUNCH_S(NCV) do { \
-                if (ev0) hipExtLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV>), gs, dim3(64 * NCV), 0, st, ev0, ev1, 0, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, snty, npass, pbs, stagger); \
-                else hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV>), gs, dim3(64 * NCV), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, snty, npass, pbs, stagger); } while (0)
+#define AADFF_LAUNCH_S2(NCV, PR) do { \
+                if (ev0) hipExtLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR>), gs, dim3(64 * NCV), 0, st, ev0, ev1, 0, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); \
+                else hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR>), gs, dim3(64 * NCV), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); } while (0)
+#define AADFF_LAUNCH_S(NCV) do { if (pair) AADFF_LAUNCH_S2(NCV, true); else AADFF_LAUNCH_S2(NCV, false); } while (0)
             switch (nc) {
                 case 1: AADFF_LAUNCH_S(1); break;
                 case 2: AADFF_LAUNCH_S(2); break;
@@ -823,6 +1064,7 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
                 default: AADFF_LAUNCH_S(4);
             }
 #undef AADFF_LAUNCH_S
+#undef AADFF_LAUNCH_S2
             return 0;
         }
     }
@@ -1019,8 +1261,6 @@ __global__ __launch_bounds__(64) void local_psf_kernel(const float* __restrict__
 // per CU while other workgroups of the CU compute.  A workgroup is 2 or 4 waves that split the pieces, the window rows and the
 // tap rows of the run (partial sums meet through the freed tap buffer): the shorter a workgroup computes, the larger the
 // share of its life it spends with loads in flight.
-typedef const __attribute__((address_space(1))) void* lp_gptr_t;
-typedef __attribute__((address_space(3))) void* lp_lptr_t;
 #ifndef AADFF_LP_DMA_AUX
 #define AADFF_LP_DMA_AUX 0          // 2 = nt (streamed-once hint)
 #endif

@@ -446,12 +446,47 @@ class Lensgroup(DeepObj):
             return out
         return out[0].mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()
 
-    def analysis(self, save_name="./test", render=False, **kw):
-        """The reference draws the lens layout and spot diagrams (optics.py:1552-1572);
-        here the same call logs the first-order numbers so scripts keep running."""
-        logging.getLogger().info("lens %s: foclen %.4f mm, F/%.4f, hfov %.5f rad, d_sensor %.5f mm, pixel %.6f mm",
-                                 getattr(self, "lens_name", "?"), self.foclen, self.fnum, self.hfov, self.d_sensor,
-                                 self.pixel_size)
+    @torch.no_grad()
+    def draw_psf_map(self, grid=7, depth=DEPTH, ks=51, log_scale=False, quater=False, save_name=None):
+        """RGB PSF map at `depth`, every field normalised to its own peak, saved as an image (reference:
+        optics.py:1773-1803).  The map comes from the fused PSF-grid kernel; the picture is written with matplotlib like the
+        reference (scale ruler included) or, without matplotlib, as a plain PNG through `save_image`.  Returns the file name."""
+        psf_map = self.psf_map(depth=depth, grid=grid, ks=ks, spp=GEO_SPP, center=True).clone()
+        G = grid * ks
+        tiles = psf_map.reshape(3, grid, ks, grid, ks)
+        psf_map = (tiles / tiles.amax(dim=(0, 2, 4), keepdim=True)).reshape(3, G, G)
+        if log_scale:
+            psf_map = torch.log(psf_map + 1e-3)
+        save_name = f"./psf{-depth}mm.png" if save_name is None else f"{save_name}_psf{-depth}mm.png"
+        if plt is None:
+            save_image(psf_map.clamp(0, 1), save_name)
+            return save_name
+        plt.figure(figsize=(10, 10))
+        plt.imshow(psf_map.permute(1, 2, 0).cpu().numpy())
+        ruler_len = 100                                              # um
+        arrow_end = ruler_len / (self.pixel_size * 1e3)
+        plt.annotate("", xy=(0, G - 10), xytext=(arrow_end, G - 10), arrowprops=dict(arrowstyle="<->", color="white"))
+        plt.text(arrow_end + 10, G - 10, f"{ruler_len} um", color="white", fontsize=12, ha="left")
+        plt.axis("off")
+        plt.tight_layout(pad=0)
+        plt.savefig(save_name, dpi=300)
+        plt.close()
+        return save_name
+
+    @torch.no_grad()
+    def analysis(self, save_name="./test", render=False, multi_plot=False, plot_invalid=True, zmx_format=False, depth=DEPTH,
+                 render_unwarp=False, lens_title=None):
+        """Reference signature (optics.py:1552).  Of its four products this build makes the one that comes off the hot path -
+        the PSF map picture (`draw_psf_map`, ks 51) - and logs the first-order numbers; the 2-D layout drawing, the RMS
+        spot statistics (they need `sample_point_source`) and the rendered resolution chart are outside the path (DESIGN.md
+        section 8) and are skipped with a log line instead of failing, so scripts that call `lens.analysis(...)` keep running."""
+        log = logging.getLogger()
+        log.info("lens %s: foclen %.4f mm, F/%.4f, hfov %.5f rad, d_sensor %.5f mm, pixel %.6f mm",
+                 getattr(self, "lens_name", "?"), self.foclen, self.fnum, self.hfov, self.d_sensor, self.pixel_size)
+        out = self.draw_psf_map(save_name=save_name, ks=51, depth=depth)
+        log.info("PSF map written to %s; layout drawing, RMS spot analysis%s are not part of this build", out,
+                 " and chart rendering" if render else "")
+        return out
 
 
 Lens = Lensgroup      # `north_star` calls the class optics.Lens

@@ -63,11 +63,18 @@ def hip_render_stack(device, hw):
 
 
 if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--save", default=None, help="directory: every rank writes its consumer's parameters there (tests compare them)")
+    ap.add_argument("--steps", type=int, default=3)
+    a = ap.parse_args()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    rank, world, net, loss = train(hip_render_stack(dev, (64, 64)), dev, steps=3, hw=(64, 64))
+    rank, world, net, loss = train(hip_render_stack(dev, (64, 64)), dev, steps=a.steps, hw=(64, 64))
     print(f"rank {rank}/{world}: loss {loss:.4f}", flush=True)
+    if a.save:
+        torch.save({"loss": loss, "params": [p.detach().cpu() for p in net.parameters()]}, os.path.join(a.save, f"config5_rank{rank}.pt"))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

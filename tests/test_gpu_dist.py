@@ -85,3 +85,18 @@ def test_bench_c3_mode_one_rank_and_two_emulated_ranks():
         rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
         assert rec["n_gpus"] == gpus and rec["scaling"] == "strong" and rec["value"] > 0
         assert rec["config"]["gathered_shape"] == [40, 3, 1024, 1024] and "expected_scaling" in rec
+
+
+@pytest.mark.timeout(900)
+def test_config5_ddp_consumer_on_hip_rendered_stacks_two_emulated_ranks(tmp_path):
+    """BASELINE.json config 5's data flow on the GPU: two ranks (emulated on the one GPU: gloo instead of RCCL) each render
+    the focal stacks of their own mini-batch with the HIP renderer (PSFNet.render_stack, one fused launch per stack) and
+    train a DistributedDataParallel consumer; no data-path collective, and DDP leaves identical weights on both ranks although
+    they rendered different scenes (examples/config5_ddp_render.py)."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    script = os.path.join(REPO, "examples", "config5_ddp_render.py")
+    assert spawn_ranks([script, "--save", str(tmp_path), "--steps", "3"], 2, emulate=True, env=env, timeout=600) == 0
+    a, b = (torch.load(tmp_path / f"config5_rank{r}.pt") for r in range(2))
+    assert all(torch.equal(x, y) for x, y in zip(a["params"], b["params"])), "DDP ranks ended with different consumer weights"
+    assert np.isfinite(a["loss"]) and np.isfinite(b["loss"]) and a["loss"] != b["loss"]      # different scenes per rank

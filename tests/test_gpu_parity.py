@@ -1023,7 +1023,8 @@ def test_full_resolution_middlebury_size_properties():
 def test_train_psfnet_runs_and_checkpoints(repo_root, tmp_path):
     """1_fit_psfnet.py's calls: analysis, write_lens_json, train_psfnet (2 iterations), evaluate_psf, load_net."""
     net = PSFNet(lens_path(repo_root), sensor_res=(480, 640), kernel_size=11, device=DEV)
-    net.analysis(save_name=str(tmp_path / "lens"))
+    pic = net.analysis(save_name=str(tmp_path / "lens"))                # PSF-map picture (7 x 7 fields, ks 51) off the PSF-grid kernel
+    assert pic == str(tmp_path / "lens") + "_psf20000mm.png" and os.path.getsize(pic) > 10_000
     net.write_lens_json(str(tmp_path / "lens.json"))
     np.random.seed(0)
     torch.manual_seed(0)
@@ -1312,6 +1313,31 @@ def test_staged_upload_late_block_is_read_from_pinned_memory(repo_root, monkeypa
         from deeplens.optics import raise_psf_flags
         with pytest.warns(RuntimeWarning, match="arrived late"):
             raise_psf_flags(bits[True])
+
+
+def test_paired_band_convolution_is_bit_equal_to_one_band_per_workgroup(monkeypatch):
+    """AADFF_CONV_PAIR=N (round-3 experiment kept as an option: a workgroup renders two consecutive bands of every N-th
+    (patch, plane), the second band prefetched by LDS-DMA into the memory the tap rows no longer need) against the default
+    one-band-per-workgroup launch: bit-equal stacks on ragged shapes, every pixel written, repeatable.  (The race this
+    comparison exposed - an inline-asm operand read whose destination shared a register with its address - is fixed in
+    both forms: early-clobber outputs, prefetched registers owned until they have landed.)"""
+    st = _abi.stream_ptr(torch.device(DEV))
+    for (H, W, S, G, Cn) in ((1024, 1024, 10, 11, 3), (480, 640, 5, 7, 3), (333, 517, 3, 4, 2), (97, 131, 4, 1, 3)):
+        rng = np.random.Generator(np.random.PCG64(H + W))
+        img = tt(rng.random((1, Cn, H, W), dtype=np.float32)).to(DEV)
+        maps = tt(rng.random((S, Cn, G * 11, G * 11), dtype=np.float32)).to(DEV) / 121
+        outs = {}
+        for mode in ("0", "1", "3", "1"):
+            monkeypatch.setenv("AADFF_CONV_PAIR", mode)
+            out = torch.full((1, Cn, S, H, W), -7.0, device=DEV)
+            _abi.call("aadff_render_psf_map_stack", _abi.ptr(img), _abi.ptr(maps), _abi.ptr(out), 1, Cn, S, H, W, G, 11, st)
+            torch.cuda.synchronize()
+            assert int((out == -7.0).sum()) == 0
+            if mode in outs:
+                assert torch.equal(outs[mode], out), "paired launch is not repeatable"
+            outs[mode] = out
+        assert torch.equal(outs["0"], outs["1"]) and torch.equal(outs["0"], outs["3"]), (H, W, S, G, Cn)
+    monkeypatch.delenv("AADFF_CONV_PAIR")
 
 
 def test_time_next_launch_attaches_events_to_the_kernel():

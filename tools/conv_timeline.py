@@ -69,16 +69,28 @@ def main():
                "start_us": {"p50": round(float(np.median(start)), 2), "p90": round(float(np.percentile(start, 90)), 2), "max": round(float(start.max()), 2)},
                "second_round_workgroups": int(late.sum()),
                "second_round_first_start_us": round(float(start[late].min()), 2) if late.any() else None,
-               "prologue_us (start -> matrix phase)": {"p50": round(float(np.median(main0 - start)), 2), "p90": round(float(np.percentile(main0 - start, 90)), 2)},
-               "  of which until the global loads arrived": {"p50": round(float(np.median(loaded - start)), 2)},
+               "prologue_us (start -> matrix phase)": {"p50": round(float(np.median(main0 - start)), 2), "p90": round(float(np.percentile(main0 - start, 90)), 2),
+                                                       "first_round_p50": round(float(np.median((main0 - start)[~late])), 2),
+                                                       "second_round_p50": round(float(np.median((main0 - start)[late])), 2) if late.any() else None},
+               "  of which until the global loads arrived": {"p50": round(float(np.median(loaded - start)), 2),
+                                                             "first_round_p10_p50_p90": [round(float(np.percentile((loaded - start)[~late], q)), 2) for q in (10, 50, 90)],
+                                                             "second_round_p50": round(float(np.median((loaded - start)[late])), 2) if late.any() else None},
+               "  from loads arrived to matrix phase (convert, T build, 2 barriers)": {"first_round_p50": round(float(np.median((main0 - loaded)[~late])), 2),
+                                                                                       "second_round_p50": round(float(np.median((main0 - loaded)[late])), 2) if late.any() else None},
                "matrix_phase_us": {"p50": round(float(np.median(main1 - main0)), 2), "p90": round(float(np.percentile(main1 - main0, 90)), 2),
                                    "second_round_p50": round(float(np.median((main1 - main0)[late])), 2) if late.any() else None},
                "store_drain_us": {"p50": round(float(np.median(end - main1)), 2)},
                "first_round_end_us": {"p50": round(float(np.median(end[~late])), 2), "max": round(float(end[~late].max()), 2)},
                "workgroups_per_cu": {"min": int(per_cu.min()), "max": int(per_cu.max()), "mean": round(float(per_cu.mean()), 2)}}
+        rec["_raw"] = t
         res.append(rec)
     res.sort(key=lambda r: r["event_us"])
     pick = res[len(res) // 2]
+    raw = pick.pop("_raw")
+    for r in res:
+        r.pop("_raw", None)
+    if a.json:
+        np.save(a.json.replace(".json", "_raw.npy"), raw)
     print(json.dumps(pick, indent=1))
     if a.json:
         json.dump({"median_run": pick, "all_runs_event_us": [r["event_us"] for r in res]}, open(a.json, "w"), indent=1)
