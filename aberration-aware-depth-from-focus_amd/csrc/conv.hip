@@ -507,7 +507,10 @@ __device__ unsigned long long* g_sb_trace = nullptr;
 #ifndef AADFF_CONV_PAIR_DEFAULT
 #define AADFF_CONV_PAIR_DEFAULT 0      // measured: every pairing is slower than one band per workgroup
 #endif
-template <int RB, int NC, bool PAIR, bool ILP = PAIR && AADFF_SB_ILP>
+// TIMED: the same code under a second name - the launches that carry aadff_time_next_launch's events (bench.py's solo leg) then
+// have their own row in a rocprofv3 --stats summary of the very same command, separate from the launches of the timed region
+// that share the device with the next stack's PSF-grid kernel.
+template <int RB, int NC, bool PAIR, bool TIMED = false, bool ILP = PAIR && AADFF_SB_ILP>
 __global__ __launch_bounds__(64 * NC, (PAIR && AADFF_SB_ILP ? 3 : 1)) void conv_psf_map_sbatch_kernel(
     const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
     int grid, int ntx, int nty, int npass, PatchBounds pb, int stagger, int pair_mod) {
@@ -1029,7 +1032,10 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
     if constexpr (KS == 11) {
         // stacks: slice-batched GEMM (the image is the shared operand); "toeplitz" / "valu" force the older paths
         if (S >= 3 && !penv) {
-            constexpr int RB = 24;
+#ifndef AADFF_SB_RB
+#define AADFF_SB_RB 24
+#endif
+            constexpr int RB = AADFF_SB_RB;
             const int nc = S <= 4 ? 1 : (S <= 8 ? 2 : (S <= 12 ? 3 : 4));
             const int npass = (S + 4 * nc - 1) / (4 * nc);
             int mh = 0, mw = 0;
@@ -1054,7 +1060,7 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
             hipEvent_t ev0 = g_time_start, ev1 = g_time_stop;
             g_time_start = g_time_stop = nullptr;
 #define AADFF_LAUNCH_S2(NCV, PR) do { \
-                if (ev0) hipExtLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR>), gs, dim3(64 * NCV), 0, st, ev0, ev1, 0, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); \
+                if (ev0) hipExtLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR, true>), gs, dim3(64 * NCV), 0, st, ev0, ev1, 0, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); \
                 else hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR>), gs, dim3(64 * NCV), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); } while (0)
 #define AADFF_LAUNCH_S(NCV) do { if (pair) AADFF_LAUNCH_S2(NCV, true); else AADFF_LAUNCH_S2(NCV, false); } while (0)
             switch (nc) {

@@ -807,6 +807,8 @@ struct StageArgs {
 #endif
 constexpr int kPsfThreads = AADFF_PSF_THREADS, kPsfWaves = kPsfThreads / 64;
 constexpr int kCompactMax = 2048;         // rays per compaction chunk of the main pass (48 KB of LDS)
+// TIMED: the same code under a second name for the launches that carry aadff_time_next_launch's events (see conv.hip)
+template <bool TIMED>
 __global__ __launch_bounds__(kPsfThreads, 6) void psf_points_kernel(const float* __restrict__ points, int N, int L,
                                                           const aadff_surface_t* __restrict__ surf_main,
                                                           const aadff_surface_t* __restrict__ surf_chief,
@@ -1302,12 +1304,12 @@ static int psf_points_launch(const float* points, int S, int N, int L, const aad
     hipEvent_t ev0 = g_time_start, ev1 = g_time_stop;                    // aadff_time_next_launch
     g_time_start = g_time_stop = nullptr;
     if (ev0)
-        hipExtLaunchKernelGGL(psf_points_kernel, dim3(N, L, sa.src ? S + 1 : S), dim3(kPsfThreads), (size_t)ks * ks * sizeof(float), (hipStream_t)stream,
+        hipExtLaunchKernelGGL(psf_points_kernel<true>, dim3(N, L, sa.src ? S + 1 : S), dim3(kPsfThreads), (size_t)ks * ks * sizeof(float), (hipStream_t)stream,
                               ev0, ev1, 0, points, N, L, surf_main, surf_chief, lc, states, u_main, spp, main_stride_s, main_stride_l, u_chief,
                               spp_chief, chief_stride_s, chief_stride_l, make_splat_geom(lc.pixel_size, ks), centre_mode, map_grid, psf,
                               centre_out_or_null, flags_or_null, sa);
     else
-        hipLaunchKernelGGL(psf_points_kernel, dim3(N, L, sa.src ? S + 1 : S), dim3(kPsfThreads), (size_t)ks * ks * sizeof(float), (hipStream_t)stream, points, N, L, surf_main,
+        hipLaunchKernelGGL(psf_points_kernel<false>, dim3(N, L, sa.src ? S + 1 : S), dim3(kPsfThreads), (size_t)ks * ks * sizeof(float), (hipStream_t)stream, points, N, L, surf_main,
                            surf_chief, lc, states, u_main, spp, main_stride_s, main_stride_l, u_chief, spp_chief, chief_stride_s,
                            chief_stride_l, make_splat_geom(lc.pixel_size, ks),
                            centre_mode, map_grid, psf, centre_out_or_null, flags_or_null, sa);

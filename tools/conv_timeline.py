@@ -33,7 +33,7 @@ def main():
     rng = np.random.Generator(np.random.PCG64(3))
     maps = torch.from_numpy(rng.random((S, 3, G * KS, G * KS), dtype=np.float32)).to(dev) / 121
     out = torch.empty((1, 3, S, H, W), device=dev)
-    n_wg = 11 * 11 * 4 * 3                                # sntx*grid x snty*grid x B*C*npass for this workload
+    n_wg = 11 * 11 * 12 * 3                               # upper bound of sntx*grid x snty*grid x B*C*npass for this workload (bands >= 8 rows)
     buf = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
     lib.aadff_sb_trace_buffer.argtypes = [C.c_void_p]
     st = _abi.stream_ptr(dev)

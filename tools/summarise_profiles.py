@@ -41,11 +41,12 @@ def write_pmc(dst, sources, keep):
     return rows
 
 
-for name, sub in (("kernel_stats", "stats"), ("fit_kernel_stats", "fit_stats"), ("local_psf_kernel_stats", "lp_stats")):
+for name, sub in (("kernel_stats", "stats"), ("kernel_stats_1stream", "stats_s1"), ("fit_kernel_stats", "fit_stats"), ("local_psf_kernel_stats", "lp_stats")):
     src = one(f"{tag}_{sub}/**/*_kernel_stats.csv")
     if src:
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.csv"))
-for name in ("bench", "bench_fit", "bench_m2", "bench_2streams", "bench_refocus_overlap"):
+for name in ("bench", "bench_fit", "bench_m2", "bench_2streams", "bench_refocus_overlap", "bench_1stream", "bench_c3", "bench_under_rocprof",
+             "conv_timeline", "conv_timeline_paired", "parity_per_slice_shipped", "parity_per_slice_literal"):
     src = os.path.join(G, f"{tag}_{name}.json")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.json"))
@@ -54,7 +55,7 @@ rows = write_pmc(os.path.join(P, f"{tag}_psf_kernel_pmc.csv"),
                  [one(f"{tag}_psf_pmc1/**/*counter_collection.csv"), one(f"{tag}_psf_pmc2/**/*counter_collection.csv")], ("psf_points_kernel",))
 for k, (v, n, meta) in rows.items():
     if "SQ_INSTS_VALU" in v:
-        stats = one(f"{tag}_stats/**/*_kernel_stats.csv")
+        stats = one(f"{tag}_stats_s1/**/*_kernel_stats.csv") or one(f"{tag}_stats/**/*_kernel_stats.csv")
         us = None
         for r in csv.DictReader(open(stats)):
             if "psf_points_kernel" in r["Name"]:
@@ -73,12 +74,26 @@ if f and w:
     rows = write_pmc(os.path.join(P, f"{tag}_conv_traffic_pmc.csv"), [f, w], ("conv_psf_map_sbatch",))
     for k, (v, n, meta) in rows.items():
         fetch, write = v["FETCH_SIZE"] * 1024, v["WRITE_SIZE"] * 1024
+        requested = 1452 * (34 * 108 * 4) + 1452 * 12 * 121 * 4          # what the workgroups ask L2 for: staged rows (with halo) + taps
         json.dump({"kernel": "conv_psf_map_sbatch_kernel (S=10 stack, 1024x1024x3)",
-                   "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes on bench.py (tools/prof_r02.sh), profiles/{tag}_conv_traffic_pmc.csv",
+                   "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes on bench.py --streams 1 (tools/prof_r03.sh), profiles/{tag}_conv_traffic_pmc.csv",
                    "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"],
-                   "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read -> doubled; WRITE_SIZE as is. Both include Infinity-Cache hits.",
-                   "hbm_bytes_per_launch": int(2 * fetch + write), "unique_bytes_per_launch": 138412032, "algorithmic_bytes_per_launch": 251658240},
+                   "correction": "MI355X_MICROARCH.md (HBM): the x2 FETCH_SIZE rule is calibrated for 16 B/lane streaming reads only; this kernel stages its "
+                                 "band with 4 B/lane loads and stores 8 B/lane, both uncalibrated widths.  Calibration by bound: the counter tallies L2 "
+                                 f"misses, which cannot exceed what the workgroups request from L2 ({requested / 1e6:.1f} MB: 1452 bands x (34 rows x 108 "
+                                 "floats) + taps); x2 would read "
+                                 f"{2 * fetch / 1e6:.1f} MB > that, so FETCH_SIZE is taken AS COUNTED here (x1; round 2 doubled it).  WRITE_SIZE as counted "
+                                 "(output 125.8 MB -> 1.05x: consistent).  Both include Infinity-Cache hits.",
+                   "l2_requested_bytes_per_launch": requested, "fetch_bytes_x2_for_reference": int(2 * fetch),
+                   "hbm_bytes_per_launch": int(fetch + write), "unique_bytes_per_launch": 138412032, "algorithmic_bytes_per_launch": 251658240},
                   open(os.path.join(P, "conv_traffic.json"), "w"), indent=1)
+cp = one(f"{tag}_conv_pmc/**/*counter_collection.csv")
+if cp:
+    write_pmc(os.path.join(P, f"{tag}_conv_kernel_pmc.csv"), [cp], ("conv_psf_map_sbatch",))
+for txt in ("latency_breakdown.txt", "soak.txt"):
+    src = os.path.join(G, f"{tag}_{txt}")
+    if os.path.exists(src) and os.path.getsize(src):
+        shutil.copy(src, os.path.join(P, f"{tag}_{txt}"))
 lp = one(f"{tag}_lp_fetch/**/*counter_collection.csv")
 if lp:
     write_pmc(os.path.join(P, f"{tag}_local_psf_fetch_pmc.csv"), [lp], ("local_psf",))
