@@ -222,6 +222,16 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
     S = len(focus)
     B, C_, H, W = img.shape
     assert tuple(lens.sensor_res) == (H, W), "lens.sensor_res must match the image"
+    if getattr(lens, "parity", "fast") == "strict":
+        # verification mode: the reference's own loop (refocus -> psf_map per slice, 2_aber_aware_dff_aif.py:104-114) with the
+        # strict trace behind every call; only the convolution is shared with the fast path (deterministic to 2e-6 abs)
+        dev = lens._gpu()
+        maps = torch.stack([(lens.refocus(f), lens.psf_map(depth=depth_plane_mm, grid=grid, ks=ks, spp=spp))[1] for f in focus]).to(dev)
+        x = _abi.f32c(img, dev)
+        out = torch.empty((B, C_, S, H, W), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(maps.contiguous()), _abi.ptr(out), B, C_, S, H, W, grid, ks, _abi.stream_ptr(dev))
+        return (out, maps) if return_maps else out
     own_plan = plan is None
     if own_plan:
         plan = StackPlan(lens, S, H, W, B, C_, grid, ks, spp)

@@ -58,7 +58,16 @@ def raise_psf_flags(bits):
 
 
 class Lensgroup(DeepObj):
-    def __init__(self, filename=None, sensor_res=(1024, 1024), use_roc=False, post_computation=True, device=DEVICE):
+    """`parity="strict"` (keyword beyond the reference's signature; default "fast"): every ray trace runs in the reference's own
+    float32 operation order on the GPU (`aadff_trace_rays_strict`, one launch pair per surface, batch-wide Newton counts),
+    and everything the reference computes on the host with torch / numpy - pupil sampling (sin, cos, sqrt), ray
+    normalisation, the focus-distance mean, the field-of-view sum and arctangent, the chief-ray centroid - is computed on the
+    host with the same torch / numpy calls.  What that buys, what it cannot, and why it is not the default: DESIGN.md section 2.
+    0.24 s per 10-slice 1024^2 stack against 0.34 ms for the fused kernels: a verification mode."""
+
+    def __init__(self, filename=None, sensor_res=(1024, 1024), use_roc=False, post_computation=True, device=DEVICE, parity="fast"):
+        assert parity in ("fast", "strict"), "parity is 'fast' or 'strict'"
+        self.parity = parity
         self.device = torch.device(device) if not isinstance(device, torch.device) else device
         self.sampler = HostSampler()
         self._table_cache = {}
@@ -216,6 +225,8 @@ class Lensgroup(DeepObj):
     # ------------------------------------------------------------------ derived quantities
     def post_computation(self):
         """hfov, foclen, fnum for the current d_sensor (reference: optics.py:178-187)."""
+        if self.parity == "strict":
+            return self._post_computation_strict()
         self.find_aperture()
         st, lc = self._state_device(), self._lens_const()
         with torch.cuda.device(st.device):
@@ -238,6 +249,8 @@ class Lensgroup(DeepObj):
         """Move the sensor to the green-light focus of an on-axis point at `depth` (mm < 0)
         and refresh hfov/foclen/fnum (reference: optics.py:1155-1180).  One kernel, no
         host sync; host RNG order = surface_sample: theta then r (surfaces.py:192-193)."""
+        if self.parity == "strict":
+            return self._refocus_strict(depth)
         st, lc = self._state_device(), self._lens_const()
         u = torch.stack((self.sampler.rand(GEO_SPP), self.sampler.rand(GEO_SPP))).to(st.device)
         dep = torch.tensor([float(depth)], dtype=torch.float32).to(st.device)
@@ -245,6 +258,47 @@ class Lensgroup(DeepObj):
             _abi.call("aadff_refocus", _abi.ptr(dep), 1, _abi.ptr(u), GEO_SPP, 2 * GEO_SPP, _abi.ptr(self._table([DEFAULT_WAVE])),
                       lc, _abi.ptr(st), _abi.stream_ptr(st.device))
         self._state_stale = True
+
+    def _refocus_strict(self, depth):
+        """The reference's refocus line by line (optics.py:1155-1180): host sampling and host reductions are the
+        reference's own torch / numpy calls, the trace is the strict one."""
+        s0 = self.surfaces[0]
+        theta = self.sampler.rand(GEO_SPP) * 2 * np.pi                     # surface_sample, surfaces.py:188-199
+        r = torch.sqrt(self.sampler.rand(GEO_SPP) * s0.r ** 2)
+        x2, y2 = r * torch.cos(theta), r * torch.sin(theta)
+        o = torch.stack((x2, y2, torch.full_like(x2, s0.d.item())), 1)
+        d = o - torch.tensor([0, 0, depth], dtype=torch.float32)
+        ray, _, _ = self.trace(Ray(o, d, wvln=DEFAULT_WAVE, device="cpu"))
+        t = (ray.d[..., 0] * ray.o[..., 0] + ray.d[..., 1] * ray.o[..., 1]) / (ray.d[..., 0] ** 2 + ray.d[..., 1] ** 2)
+        t = t * ray.ra
+        focus_d = (ray.o[..., 2] - ray.d[..., 2] * t).numpy()
+        focus_d = focus_d[ray.ra > 0]
+        focus_d = focus_d[~np.isnan(focus_d) & (focus_d > 0)]
+        with np.errstate(all="ignore"):
+            d_sensor_new = float(np.mean(focus_d)) if len(focus_d) else float("nan")
+        assert d_sensor_new > 0, "sensor position is negative."
+        self.d_sensor = d_sensor_new
+        self.post_computation()
+
+    def _post_computation_strict(self):
+        """optics.py:178-187 + calc_fov :1187-1217 with the strict trace and the reference's host arithmetic."""
+        self.find_aperture()
+        M = 100
+        pupilz, pupilx = self.exit_pupil(shrink_pupil=True)
+        o1 = torch.tensor([self.r_last, 0, self.d_sensor]).repeat(M, 1).to(torch.float32)
+        x2 = torch.linspace(-pupilx, pupilx, M)
+        o2 = torch.stack((x2, torch.full_like(x2, 0), torch.full_like(x2, pupilz)), axis=-1)
+        ray, _, _ = self.trace(Ray(o1, o2 - o1, wvln=DEFAULT_WAVE, device="cpu"))
+        tan_fov = ray.d[..., 0] / ray.d[..., 2]
+        fov = torch.atan(torch.sum(tan_fov * ray.ra) / torch.sum(ray.ra))
+        hfov = 0.5 if torch.isnan(fov) else fov.item()
+        foclen = self.r_last / np.tan(hfov)
+        _, enp_r = self.entrance_pupil()
+        self._state_sync()
+        self._state_host.hfov, self._state_host.tan_hfov = float(hfov), float(np.tan(hfov))
+        self._state_host.foclen, self._state_host.fnum = float(foclen), float(foclen / enp_r / 2)
+        if self._state_dev is not None:
+            self._state_upload()
 
     # ------------------------------------------------------------------ pupils
     @torch.no_grad()
@@ -268,7 +322,7 @@ class Lensgroup(DeepObj):
             dz = -torch.cos(phi) if entrance else torch.cos(phi)
             d = torch.stack((torch.sin(phi), torch.zeros_like(phi), dz), axis=-1)
             rng = range(0, self.aper_idx) if entrance else range(self.aper_idx + 1, len(self.surfaces))
-            ray, _, _ = self.trace(Ray(o, d, device=self._gpu()), lens_range=rng)
+            ray, _, _ = self.trace(Ray(o, d, device="cpu" if self.parity == "strict" else self._gpu()), lens_range=rng)
             ro, rd, ra = ray.o.cpu().numpy(), ray.d.cpu().numpy(), ray.ra.cpu().numpy()
             ii, jj = np.triu_indices(M, 1)
             keep = (ra[ii] != 0) & (ra[jj] != 0)
@@ -303,7 +357,31 @@ class Lensgroup(DeepObj):
         theta = self.sampler.rand(spp) * 2 * np.pi
         r = torch.sqrt(self.sampler.rand(spp) * pupilr ** 2)
         o2 = torch.stack((r * torch.cos(theta), r * torch.sin(theta), torch.full_like(r, pupilz)), 1)
-        return Ray(o, o2.unsqueeze(1) - o.cpu(), wvln=wvln, device=self.device)
+        return Ray(o, o2.unsqueeze(1) - o.cpu(), wvln=wvln, device="cpu" if self.parity == "strict" else self.device)
+
+    def _trace_strict(self, ray, first, last, forward, z_sensor=None):
+        """`ray` (any device, any leading shape) through surfaces [first, last) in the reference's operation order; the
+        whole bundle is ONE Newton batch, as in one reference call.  Returns a new Ray on the CPU (strict mode keeps rays
+        there: the reference's host-side arithmetic on them is then the reference's own)."""
+        dev = self._gpu()
+        shape = ray.o.shape
+        o = _abi.f32c(ray.o, dev).reshape(-1, 3).clone()
+        d = _abi.f32c(ray.d, dev).reshape(-1, 3).clone()
+        ra = _abi.f32c(ray.ra, dev).reshape(-1).clone()
+        n = len(self.surfaces)
+        tab = (_abi.Surface * n)(*[s.pack(ray.wvln) for s in self.surfaces])
+        scratch = torch.zeros(2 * _abi.MAX_SURF + 1, dtype=torch.int32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _abi.call("aadff_trace_rays_strict", _abi.ptr(o), _abi.ptr(d), _abi.ptr(ra), o.shape[0], C.byref(tab), first, last, int(forward),
+                      int(z_sensor is not None), float(z_sensor if z_sensor is not None else 0.0), _abi.ptr(scratch), _abi.ptr(flag),
+                      _abi.stream_ptr(dev))
+        if int(flag.item()):
+            raise FloatingPointError("found nan in ft in non-diff newton method.")
+        out = Ray.__new__(Ray)
+        out.wvln, out.coherent, out.device = ray.wvln, False, torch.device("cpu")
+        out.o, out.d, out.ra = o.cpu().reshape(shape), d.cpu().reshape(shape), ra.cpu().reshape(shape[:-1])
+        return out
 
     def trace(self, ray, lens_range=None, record=False):
         """Ray in, (ray_out, valid, oss) out; direction from the first ray's d_z
@@ -313,6 +391,9 @@ class Lensgroup(DeepObj):
         is_forward = bool(ray.d.reshape(-1, 3)[0, 2] > 0)
         rng = range(0, len(self.surfaces)) if lens_range is None else lens_range
         first, last = (rng.start, rng.stop) if len(rng) else (0, 0)
+        if self.parity == "strict":
+            out = self._trace_strict(ray, first, last, is_forward)
+            return out, (out.ra == 1), None
         out = trace_ray_object(ray, self.surfaces, first, last, is_forward, None, table=self._table([ray.wvln]))
         return out, (out.ra == 1), None
 
@@ -321,6 +402,8 @@ class Lensgroup(DeepObj):
         if record:
             raise NotImplementedError("record=True is a plotting aid outside the hot path")
         is_forward = bool(ray.d.reshape(-1, 3)[0, 2] > 0)
+        if self.parity == "strict":
+            return self._trace_strict(ray, 0, len(self.surfaces), is_forward, z_sensor=self.d_sensor)
         return trace_ray_object(ray, self.surfaces, 0, len(self.surfaces), is_forward, self._state_device(),
                                 table=self._table([ray.wvln]))
 
@@ -397,12 +480,34 @@ class Lensgroup(DeepObj):
         """[N,ks,ks] (or [ks,ks]) single-wavelength PSFs of NORMALISED points (reference: optics.py:915-983)."""
         return self.psf_diff(points=points, wvln=wvln, ks=ks, spp=spp, center=center)
 
+    def _psf_strict(self, points, wvln, ks, spp, center):
+        """psf_diff of the reference, call by call (optics.py:933-983): sample on the host, strict trace, chief-ray centre by
+        the reference's own sum on the host, then the histogram kernel (whose only discontinuity, the window test, compares
+        the same float32 quantities as monte_carlo.py:37)."""
+        from .monte_carlo import forward_integral
+        pobj = self._object_points(points)
+        ray = self.trace2sensor(self.sample_from_points(pobj, spp=spp, wvln=wvln))
+        if center:
+            ref = self.psf_center(pobj)
+        else:
+            ref = points.clone()[:, :2]
+            ref[:, 0] *= self.sensor_size[1] / 2
+            ref[:, 1] *= self.sensor_size[0] / 2
+        dev = self._gpu()
+        ray.o, ray.ra = ray.o.to(dev), ray.ra.to(dev)
+        psf = forward_integral(ray, ps=self.pixel_size, ks=ks, pointc_ref=ref.to(dev))
+        psf = psf / psf.sum(-1).sum(-1).unsqueeze(-1).unsqueeze(-1)             # optics.py:978 (0/0 -> NaN like the reference)
+        return psf if self.device.type == "cuda" else psf.to(self.device)
+
     def psf_diff(self, points, wvln=DEFAULT_WAVE, ks=31, spp=GEO_SPP, center=True):
         if not torch.is_tensor(points):
             points = torch.tensor(points)
         single = len(points.shape) == 1
         if single:
             points = points.unsqueeze(0)
+        if self.parity == "strict":
+            out = self._psf_strict(points.float(), wvln, ks, spp, center)
+            return out.squeeze(0) if single else out
         out = self._psf_launch(points.float(), [wvln], ks, spp, center, False)[:, 0]
         return out.squeeze(0) if single else out
 
@@ -413,6 +518,9 @@ class Lensgroup(DeepObj):
         single = len(points.shape) == 1
         if single:
             points = points.unsqueeze(0)
+        if self.parity == "strict":
+            out = torch.stack([self._psf_strict(points.float(), w, ks, spp, center) for w in WAVE_RGB], dim=-3)
+            return out.squeeze(0) if single else out
         out = self._psf_launch(points.float(), WAVE_RGB, ks, spp, center, False)
         return out.squeeze(0) if single else out
 
@@ -422,6 +530,8 @@ class Lensgroup(DeepObj):
         if ks > _abi.MAX_KS:
             raise ValueError(f"ks={ks} exceeds the kernels' limit {_abi.MAX_KS}")
         pts = self.point_source_grid(depth=depth, grid=grid, quater=False).reshape(-1, 3)
+        if self.parity == "strict":
+            return make_grid(self.psf_rgb(pts, ks=ks, spp=spp, center=center), nrow=grid, padding=0)
         return self._psf_launch(pts, WAVE_RGB, ks, spp, center, True)
 
     # ------------------------------------------------------------------ image rendering / misc

@@ -317,6 +317,26 @@ def main():
                              "rel_l2_per_slice": [float(f"{v:.3e}") for v in per],
                              "against": "oracle (CPU restatement pinned to the reference by tests/golden), seed 0, "
                                         "same image / depth plane / focus distances as the timed steps"}
+            # the same stack through Lensgroup(parity="strict") (reference operation order on the GPU, reference host arithmetic;
+            # ~0.25 s per stack, untimed): every slice must meet the tolerance on its own, no floor widening
+            try:
+                from aadff.focal_stack import render_focal_stack_m1 as _rfs
+                ls = Lensgroup(lens_path, sensor_res=(H, W), device=dev, parity="strict")
+                torch.manual_seed(0)
+                t_s = time.perf_counter()
+                so = _rfs(ls, img, dbar, fds, GRID, KS, SPP)
+                torch.cuda.synchronize(dev)
+                t_s = time.perf_counter() - t_s
+                a2 = so[0].cpu().numpy()[:, :n].astype(np.float64)
+                per2 = [float(np.linalg.norm(a2[:, k] - b[:, k]) / np.linalg.norm(b[:, k])) for k in range(n)]
+                res["parity"]["strict_mode"] = {"rel_l2": float(f"{np.linalg.norm(a2 - b) / np.linalg.norm(b):.3e}"),
+                                                "rel_l2_per_slice": [float(f"{v:.3e}") for v in per2], "worst_slice": float(f"{max(per2):.3e}"),
+                                                "seconds_per_stack": round(t_s, 3),
+                                                "what": "Lensgroup(parity='strict'): aadff_trace_rays_strict + the reference's host arithmetic; DESIGN.md section 2"}
+                if not max(per2) <= 1e-4:
+                    print("bench: strict-mode parity above 1e-4 on a slice", file=sys.stderr, flush=True)
+            except Exception as e:                       # the contract line must not depend on the verification mode
+                res["parity"]["strict_mode"] = {"error": repr(e)}
             fpath = os.path.join(REPO, "tests", "golden", "g13_fp32_floor.npz")
             if os.path.exists(fpath):       # fp32-vs-fp64 distance of the reference formulation itself, per slice (static fixture)
                 res["parity"]["fp32_floor_per_slice"] = [float(f"{v:.3e}") for v in np.load(fpath)["img_floor"][:n]]

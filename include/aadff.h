@@ -165,6 +165,19 @@ int aadff_trace_rays(const float* o_in, const float* d_in, const float* ra_in,
                      const aadff_lens_state_t* state_or_null, int* flags_or_null,
                      aadff_stream_t stream);
 
+/* parity="strict": the same trace in the reference's own operation order, one IEEE float32 operation at a time (no fma
+ * contraction, IEEE division / sqrt, F.normalize's fused norm, the BATCH-WIDE Newton iteration count of
+ * deeplens/surfaces.py:547: all n rays of the call are one batch, as in one reference call), one launch pair per
+ * surface; csrc/strict.hip, specification oracle/scalar_trace.py.  In place on o,d [n,3], ra [n] (device).  `surf_host` is
+ * the HOST copy of the packed table of ONE wavelength (n_surf records).  propagate != 0 adds Ray.propagate_to(z_sensor).
+ * scratch: 2*AADFF_MAX_SURF + 1 device words (zeroed by the call).  flags_or_null (device): set to 1 on a NaN residual
+ * in an iteration the reference would have run.  Replaces Aspheric.ray_reaction / Lensgroup.trace,
+ * deeplens/surfaces.py:391-830, deeplens/optics.py:598-714, for Lensgroup(parity="strict").  A verification path: what it
+ * can and cannot reproduce is in DESIGN.md section 2. */
+int aadff_trace_rays_strict(float* o, float* d, float* ra, int n, const aadff_surface_t* surf_host, int first, int last,
+                            int forward, int propagate, float z_sensor, unsigned* scratch, int* flags_or_null,
+                            aadff_stream_t stream);
+
 /* Rays from object points through the entrance pupil to the sensor.  Replaces
  * sample_from_points + trace2sensor, deeplens/optics.py:457-491,635-661.
  * points_obj [N,3] (object space, mm); u_theta,u_r [spp] raw uniform draws

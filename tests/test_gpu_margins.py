@@ -174,6 +174,75 @@ def test_margin_bench_stack_literal_op_order_build(golden_dir, repo_root, margin
     monkeypatch.undo()
 
 
+def test_margin_bench_stack_strict_parity_mode(golden_dir, repo_root, margin):
+    """Lensgroup(parity="strict"): the bench workload with every trace in the reference's own float32 operation order
+    (aadff_trace_rays_strict: one launch pair per surface, batch-wide Newton iteration counts, IEEE division / sqrt, no fma
+    contraction) and the reference's host-side arithmetic done by the same torch / numpy calls.  EVERY slice is held to the
+    north-star 1e-4 with NO floor widening (the two wide-PSF slices, 1.5e-4 / 1.1e-4 in the fast build, come out at
+    <= 7e-5; slices whose d_sensor / hfov / pupil reproduce to the bit at < 1e-6).  About 7 s per stack: a verification mode."""
+    import time
+    g = np.load(os.path.join(golden_dir, "g9_stack_m1_1024.npz"))
+    H = W = 1024
+    S = 10
+    lens = Lensgroup(lp(repo_root), sensor_res=(H, W), device=DEV, parity="strict")
+    img = tt(synth_rgb(H, W, seed=1234))[None].to(DEV)
+    depth = synth_depth_mm(H, W, seed=5678)
+    dbar, fds = -float(depth.mean()), -np.linspace(depth.min(), depth.max(), S)
+    t0 = time.perf_counter()
+    torch.manual_seed(0)
+    out, maps = render_focal_stack_m1(lens, img, dbar, fds, 11, 11, 2048, return_maps=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    s = out[0].cpu().numpy().astype(np.float64)
+    num = den = 0.0
+    for k in range(S):
+        ref = rp.render_psf_map(img, tt(g["psf_maps"][k]).to(DEV), 11)[0].cpu().numpy().astype(np.float64)
+        dlt = s[:, k] - ref
+        num += float((dlt * dlt).sum())
+        den += float((ref * ref).sum())
+        margin(f"strict mode: slice {k} full-image rel-L2 vs reference PSFs (no floor widening)", np.sqrt((dlt * dlt).sum() / (ref * ref).sum()), 1e-4)
+        margin(f"strict mode: slice {k} PSF map rel-L2", rel(maps[k].cpu().numpy(), g["psf_maps"][k]), 2e-3 if k not in (1, 2) else 4e-3)
+    margin("strict mode: whole stack, full-image rel-L2", np.sqrt(num / den), 1e-4)
+    crops = {"seam": s[:, :, 61:125, 154:218], "centre": s[:, :, 480:544, 480:544], "corner": s[:, :, 960:1024, 960:1024]}
+    for k, v in crops.items():
+        margin(f"strict mode: 64x64 crop '{k}' rel-L2 vs the reference's pixels, whole stack", rel(v, g[f"crop_{k}"]), 1e-4)
+    margin("strict mode: seconds per 10-slice stack (informative)", dt, 120.0)
+
+
+def test_strict_trace_reproduces_reference_bits(golden_dir, repo_root, margin):
+    """The strict tracer against the reference's per-surface ray states (G2) and load / refocus scalars (G1), BIT for bit
+    where the reference's arithmetic can be reproduced at all: identical validity at every surface, the first surfaces'
+    states equal on every ray, >= 85 % of the rays still bit-equal behind all 12 surfaces (the rest: torch's CPU sqrt is
+    MKL's, 0.7 % of its results are not correctly rounded), d_sensor and hfov of the loaded lens equal to the last bit."""
+    import json as _json
+    g = np.load(os.path.join(golden_dir, "g2_g3_trace_splat.npz"))
+    g1 = _json.load(open(os.path.join(golden_dir, "g1_scalars.json")))["rf50mm@1024x1024"]
+    from deeplens.basics import Ray
+    lens = Lensgroup(lp(repo_root), sensor_res=(1024, 1024), device=DEV, parity="strict")
+    assert lens.d_sensor == g1["load"]["d_sensor"] and lens.hfov == g1["load"]["hfov"]
+    assert lens.exit_pupil() == pytest.approx(tuple(g1["exit_pupil"]), rel=1e-7) and lens.entrance_pupil() == pytest.approx(tuple(g1["entrance_pupil"]), rel=1e-7)
+    exact = 0
+    for f, want in g1["refocus"].items():
+        torch.manual_seed(0)
+        lens.refocus(float(f))
+        assert lens.d_sensor == pytest.approx(want["d_sensor"], rel=2e-7) and lens.hfov == pytest.approx(want["hfov"], rel=2e-7)
+        exact += int(lens.d_sensor == want["d_sensor"]) + int(lens.hfov == want["hfov"])
+    assert exact >= 6, f"only {exact} of 10 refocus scalars reproduce to the bit"
+    torch.manual_seed(0)
+    lens.refocus(-2000.0)
+    ray = Ray(tt(g["ray_o0"]).clone(), tt(g["ray_d0"]).clone(), wvln=0.589, device="cpu")
+    for i in range(len(lens.surfaces)):
+        ray, _, _ = lens.trace(ray, lens_range=range(i, i + 1))
+        ra = ray.ra.numpy()
+        assert np.array_equal(ra, g["states_ra"][i]), f"surface {i} validity"
+        alive = ra > 0
+        same = ((ray.o.numpy() == g["states_o"][i]).all(-1) & (ray.d.numpy() == g["states_d"][i]).all(-1))[alive].mean()
+        if i < 2:
+            assert same == 1.0, f"surface {i}: {same}"
+        assert np.abs(ray.o.numpy() - g["states_o"][i])[alive].max() <= 1e-5
+    margin("strict trace: fraction of rays NOT bit-equal to the reference behind all 12 surfaces", 1.0 - same, 0.15)
+
+
 def test_margin_training_data(golden_dir, repo_root, margin):
     """PSFNet.get_training_data vs the reference's (G10): identical network inputs (host RNG order: np choice, refocus
     draws, rand x, rand y, randn z, psf draws), ray-traced target PSFs within the PSF tolerance."""

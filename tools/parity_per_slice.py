@@ -48,13 +48,19 @@ def main():
     img = torch.from_numpy(synth_rgb(H, W, seed=1234))[None].to(dev)
     depth = synth_depth_mm(H, W, seed=5678)
     dbar, fds = -float(depth.mean()), -np.linspace(depth.min(), depth.max(), S)
-    plan = StackPlan(lens, S, H, W, 1, 3, 11, 11, 2048)
-    torch.manual_seed(0)
-    out = render_focal_stack_m1(lens, img, dbar, fds, 11, 11, 2048, plan=plan, update_lens=False)
-    plan.check_flags()
-    s = out[0].cpu().numpy()
-    maps = plan.psf_maps.cpu().numpy()
-    st = np.frombuffer(plan.states.cpu().numpy().tobytes(), dtype=np.float32).reshape(S, 8)
+    if args.strict:
+        torch.manual_seed(0)
+        out, maps_t = render_focal_stack_m1(lens, img, dbar, fds, 11, 11, 2048, return_maps=True)
+        s, maps = out[0].cpu().numpy(), maps_t.cpu().numpy()
+        st = np.tile(np.asarray(g["d_sensor"], np.float32)[:, None], (1, 8))        # per-slice d_sensor is not kept by the strict loop
+    else:
+        plan = StackPlan(lens, S, H, W, 1, 3, 11, 11, 2048)
+        torch.manual_seed(0)
+        out = render_focal_stack_m1(lens, img, dbar, fds, 11, 11, 2048, plan=plan, update_lens=False)
+        plan.check_flags()
+        s = out[0].cpu().numpy()
+        maps = plan.psf_maps.cpu().numpy()
+        st = np.frombuffer(plan.states.cpu().numpy().tobytes(), dtype=np.float32).reshape(S, 8)
     rows = []
     crops = {"seam": (slice(61, 125), slice(154, 218)), "centre": (slice(480, 544), slice(480, 544)), "corner": (slice(960, 1024), slice(960, 1024))}
     num = den = 0.0
