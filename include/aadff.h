@@ -104,7 +104,15 @@ int         aadff_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_le
 /* ------------------------------------------------------------------ image space */
 
 /* Spatially-varying blur with a g x g PSF grid.  Replaces render_psf_map,
- * deeplens/render_psf.py:31-73.  img [B,C,H,W], psf_map [C,g*ks,g*ks], out [B,C,H,W]. */
+ * deeplens/render_psf.py:31-73.  img [B,C,H,W], psf_map [C,g*ks,g*ks], out [B,C,H,W].
+ * Arithmetic contract of the three convolution entries (ks <= 11 on the matrix cores): every fp32 operand is carried as an
+ * fp16 hi + lo pair after a power-of-two pre-scale (per image tile / per PSF), products hi*hi + hi*lo + lo*hi accumulate in
+ * fp32: >= 21-22 significand bits per operand, <= 2e-6 abs from the reference's fp32 conv2d on every golden case (tested;
+ * seven decades of dynamic range inside one tile stay within 1e-6 of the tile maximum).  Non-finite input: an inf / NaN pixel
+ * makes the whole tile that staged it (<= 34 x 108 pixels with halo) NaN, where F.conv2d poisons only the ks x ks support;
+ * everything the reference poisons is non-finite here too and nothing farther than 128 pixels from the bad pixel is affected
+ * (tested).  A PSF patch that is NaN (no ray inside its window, optics.py:978) turns exactly its image patch into NaN, as in
+ * the reference. */
 int aadff_render_psf_map(const float* img, const float* psf_map, float* out,
                          int B, int C, int H, int W, int grid, int ks, aadff_stream_t stream);
 

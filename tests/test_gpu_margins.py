@@ -241,6 +241,13 @@ def test_strict_trace_reproduces_reference_bits(golden_dir, repo_root, margin):
             assert same == 1.0, f"surface {i}: {same}"
         assert np.abs(ray.o.numpy() - g["states_o"][i])[alive].max() <= 1e-5
     margin("strict trace: fraction of rays NOT bit-equal to the reference behind all 12 surfaces", 1.0 - same, 0.15)
+    # a whole PSF map through the strict path (G4: reference output, seed 0, refocus(-2000), depth -1500, spp 2048)
+    g4 = np.load(os.path.join(golden_dir, "g4_psf_map.npz"))
+    torch.manual_seed(0)
+    lens.refocus(-2000.0)
+    pm = lens.psf_map(depth=-1500.0, grid=11, ks=11, spp=2048)
+    assert lens.d_sensor == float(g4["rf50mm_d_sensor"])
+    margin("strict mode: psf_map rf50mm rel-L2 vs reference (fast path: 6e-4)", rel(pm.cpu().numpy(), g4["rf50mm_psf_map"]), 2e-4)
 
 
 def test_margin_training_data(golden_dir, repo_root, margin):

@@ -1340,6 +1340,33 @@ def test_paired_band_convolution_is_bit_equal_to_one_band_per_workgroup(monkeypa
     monkeypatch.delenv("AADFF_CONV_PAIR")
 
 
+def test_strided_stack_convolution_writes_unit_major_layouts():
+    """aadff_render_psf_map_stack_strided: plane (b, c, s) at out + (b*C + c)*stride_bc + s*stride_s.  With stride_bc = H*W,
+    stride_s = k*C*H*W the slices land as every k-th [C,H,W] unit of a caller's buffer (a rank's place in the unit-order
+    all-gather buffer) - bit-equal to the contiguous stack, nothing else touched; overlapping planes and
+    strides below one plane are refused."""
+    st = _abi.stream_ptr(torch.device(DEV))
+    rng = np.random.Generator(np.random.PCG64(77))
+    for (H, W, S, G, Cn, k) in ((256, 320, 10, 5, 3, 1), (97, 131, 4, 3, 3, 3), (128, 128, 2, 2, 1, 2)):
+        img = tt(rng.random((1, Cn, H, W), dtype=np.float32)).to(DEV)
+        maps = tt(rng.random((S, Cn, G * 11, G * 11), dtype=np.float32)).to(DEV) / 121
+        ref = torch.empty((1, Cn, S, H, W), device=DEV)
+        _abi.call("aadff_render_psf_map_stack", _abi.ptr(img), _abi.ptr(maps), _abi.ptr(ref), 1, Cn, S, H, W, G, 11, st)
+        units = torch.full((S * k + 2, Cn, H, W), -3.0, device=DEV)
+        _abi.call("aadff_render_psf_map_stack_strided", _abi.ptr(img), _abi.ptr(maps), C.c_void_p(units.data_ptr() + 4 * Cn * H * W),
+                  H * W, k * Cn * H * W, 1, Cn, S, H, W, G, 11, st)
+        torch.cuda.synchronize()
+        for sl in range(S):
+            assert torch.equal(units[1 + sl * k], ref[0, :, sl]), (H, W, sl)
+        mask = torch.ones(units.shape[0], dtype=torch.bool)
+        mask[1:1 + S * k:k] = False
+        assert bool((units[mask.to(DEV)] == -3.0).all())
+    with pytest.raises(RuntimeError, match="overlap"):
+        _abi.call("aadff_render_psf_map_stack_strided", _abi.ptr(img), _abi.ptr(maps), _abi.ptr(units), H * W, H * W, 1, 3, S, H, W, G, 11, st)
+    with pytest.raises(RuntimeError, match="below one plane"):
+        _abi.call("aadff_render_psf_map_stack_strided", _abi.ptr(img), _abi.ptr(maps), _abi.ptr(units), H * W - 1, S * H * W, 1, 1, S, H, W, G, 11, st)
+
+
 def test_time_next_launch_attaches_events_to_the_kernel():
     """aadff_time_next_launch (bench.py's roofline / trace blocks): the armed call produces identical results, the two HIP
     events attached to the dispatch give a positive kernel time no longer than the bracket of two stream events, the arming

@@ -303,3 +303,30 @@ def test_middlebury_and_matterport_loaders_on_files_written_here(tmp_path):
     np.random.seed(0)
     i3, d3 = Matterport3D(str(mp3 / "rgb"), str(mp3 / "depth"), resize=(40, 60), train=True)[0]   # augmentation path runs
     assert i3.shape == (3, 40, 60) and d3.shape == (1, 40, 60) and float(d3.min()) >= 0
+
+
+def test_per_surface_newton_step_tolerance_and_flag_bits(repo_root):
+    """Host logic of two round-3 changes: (1) the Newton step tolerance packed per surface keeps kappa * tol^2 <= 4e-6 (kappa =
+    largest |d^2 sag / d r^2| over the aperture) and never exceeds 10 um; spheres and stops carry 0 (they do not iterate);
+    (2) the flags word maps to the reference's errors: bit 2 = 'sensor position is negative.' (optics.py:1176)."""
+    from deeplens.optics import raise_psf_flags
+    lens = Lensgroup(lens_path(repo_root), post_computation=False, device="cpu")
+    tols = [s.newton_step_tol() for s in lens.surfaces]
+    assert [t > 0 for t in tols] == [k == 2 for k in (s.kind() for s in lens.surfaces)]
+    for s, t in zip(lens.surfaces, tols):
+        if t > 0:
+            assert t <= 1e-2 and s.pack(0.589).newton_step_tol == np.float32(t)
+            rr = np.linspace(0, s.r, 1001)
+            c, k = s.c.item(), s.k.item()
+            curv = c / (1 - (1 + k) * c * c * rr * rr) ** 1.5 + sum(float(a) * (2 * j + 2) * (2 * j + 1) * rr ** (2 * j) for j, a in enumerate(s.ai.tolist()))
+            assert np.abs(curv).max() * t * t <= 4.1e-6
+    assert 3e-3 < tols[8] < 6e-3 and 3e-3 < tols[9] < 6e-3            # rf50mm's aspheres: 4.9 and 3.7 um, not the 10 um round 2 assumed
+    raise_psf_flags(0)
+    with pytest.raises(AssertionError, match="sensor position is negative"):
+        raise_psf_flags(4)
+    with pytest.raises(AssertionError, match="No sampled rays is valid"):
+        raise_psf_flags(2)
+    with pytest.raises(FloatingPointError):
+        raise_psf_flags(1 | 4)
+    with pytest.warns(RuntimeWarning):
+        raise_psf_flags(8)
