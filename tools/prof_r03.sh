@@ -25,5 +25,6 @@ AADFF_CONV_PAIR=1 python tools/conv_timeline.py --json gpurun_out/${TAG}_conv_ti
 python tools/latency_breakdown.py > gpurun_out/${TAG}_latency_breakdown.txt 2>&1
 python tools/parity_per_slice.py --label shipped > gpurun_out/${TAG}_parity_per_slice_shipped.json 2>/dev/null
 AADFF_LIB=$R/aberration-aware-depth-from-focus_amd/csrc/libaadff_literal.so python tools/parity_per_slice.py --label literal > gpurun_out/${TAG}_parity_per_slice_literal.json 2>/dev/null
+python tools/parity_per_slice.py --strict --label strict > gpurun_out/${TAG}_parity_per_slice_strict.json 2>/dev/null
 python tools/soak.py > gpurun_out/${TAG}_soak.txt 2>&1
 find gpurun_out/${TAG}_* -name "*_kernel_stats.csv" | head; cut -c1-200 gpurun_out/${TAG}_bench.json

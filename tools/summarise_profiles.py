@@ -46,7 +46,7 @@ for name, sub in (("kernel_stats", "stats"), ("kernel_stats_1stream", "stats_s1"
     if src:
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.csv"))
 for name in ("bench", "bench_fit", "bench_m2", "bench_2streams", "bench_refocus_overlap", "bench_1stream", "bench_c3", "bench_under_rocprof",
-             "conv_timeline", "conv_timeline_paired", "parity_per_slice_shipped", "parity_per_slice_literal"):
+             "conv_timeline", "conv_timeline_paired", "parity_per_slice_shipped", "parity_per_slice_literal", "parity_per_slice_strict"):
     src = os.path.join(G, f"{tag}_{name}.json")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.json"))
