@@ -510,8 +510,17 @@ __device__ unsigned long long* g_sb_trace = nullptr;
 // TIMED: the same code under a second name - the launches that carry aadff_time_next_launch's events (bench.py's solo leg) then
 // have their own row in a rocprofv3 --stats summary of the very same command, separate from the launches of the timed region
 // that share the device with the next stack's PSF-grid kernel.
-template <int RB, int NC, bool PAIR, bool TIMED = false, bool ILP = PAIR && AADFF_SB_ILP>
-__global__ __launch_bounds__(64 * NC, (PAIR && AADFF_SB_ILP ? 3 : 1)) void conv_psf_map_sbatch_kernel(
+template <int RB, int NC, bool PAIR, bool TIMED = false, int RS = 1, bool ILP = PAIR && AADFF_SB_ILP>
+// Round 3: 5 waves per SIMD (96 VGPRs) = 6 workgroups per CU = 1536 slots: the 1452 workgroups of the bench launch are all
+// resident in ONE round (round 2: 104 VGPRs, 5 per CU, 172 workgroups in a second round that ended 12 us after the first).
+// What made 96 possible without spilling in the loop: two operand buffers instead of three (AADFF_SB_NBUF).
+#ifndef AADFF_SB_MINWAVES
+#define AADFF_SB_MINWAVES 5
+#endif
+#ifndef AADFF_SB_NBUF
+#define AADFF_SB_NBUF 2
+#endif
+__global__ __launch_bounds__(64 * NC * RS, (PAIR && AADFF_SB_ILP ? 3 : AADFF_SB_MINWAVES)) void conv_psf_map_sbatch_kernel(
     const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
     int grid, int ntx, int nty, int npass, PatchBounds pb, int stagger, int pair_mod) {
     using namespace sb;
@@ -521,10 +530,12 @@ __global__ __launch_bounds__(64 * NC, (PAIR && AADFF_SB_ILP ? 3 : 1)) void conv_
         // time (stage -> build T -> matrix phase -> stores).  A start delay by residency slot spreads the phases so that
         // one workgroup's HBM reads overlap another's MFMAs.
         const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int slot = (int)((lin >> 8) % 5u);
+        const int slot = (int)((lin >> 8) % 6u);
         for (int i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(32);
     }
-    constexpr int NW = NC, THP = RB + KS - 1, NSL = 4 * NC;
+    // RS > 1: RS row groups per chunk - wave = (row group, chunk); the waves of a chunk share its tap rows and T fragments
+    // source, and split the band's row pairs among themselves in the matrix phase
+    constexpr int NW = NC * RS, THP = RB + KS - 1, NSL = 4 * NC;
     static_assert(RB % 2 == 0 && THP % 2 == 0, "bands are whole row pairs");
     static_assert(WDW <= 64, "one lane per dword column");
     __shared__ __attribute__((aligned(16))) unsigned tile[(THP / 2) * RPP];
@@ -565,7 +576,7 @@ __global__ __launch_bounds__(64 * NC, (PAIR && AADFF_SB_ILP ? 3 : 1)) void conv_
 #endif
     const int G = grid * KS;
     const int s_base = pass * NSL;                       // first slice of this workgroup
-    const int chunk = wave;
+    const int chunk = RS == 1 ? wave : wave % NC, rgroup = RS == 1 ? 0 : wave / NC;
     const int kg = lane >> 4, lo4 = lane & 15;
 
     // ---- global loads up front: this wave's taps (4 slices, 2 per lane and slice), then its share of the image rows ----
@@ -600,8 +611,9 @@ __global__ __launch_bounds__(64 * NC, (PAIR && AADFF_SB_ILP ? 3 : 1)) void conv_
             amax = fmaxf(amax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
         }
     }
-    // ---- padded fp16 hi/lo tap rows of this wave's chunk ----
-    {
+    // ---- padded fp16 hi/lo tap rows of this wave's chunk (RS > 1: written by the chunk's first row group only; everybody
+    //      reads them after the barrier below) ----
+    if (rgroup == 0) {
         _Float16* ph = reinterpret_cast<_Float16*>(&prow[0][0]);
         _Float16* pl = reinterpret_cast<_Float16*>(&prow[1][0]);
         for (int e = lane; e < 4 * PSL; e += 64) { prow[0][4 * chunk * PSL + e] = 0u; prow[1][4 * chunk * PSL + e] = 0u; }
@@ -729,9 +741,16 @@ __global__ __launch_bounds__(64 * NC, (PAIR && AADFF_SB_ILP ? 3 : 1)) void conv_
     }
 
     // ---- matrix phase of one band (rows yb .. yb + RB - 1 of the image, staged in `tile`) ----
-    auto run_band = [&](const int yb, const float inv) {
-        int npairs = (y_hi - yb + 1) / 2;                   // row pairs of this band that hold valid rows
-        npairs = npairs > RB / 2 ? RB / 2 : npairs;
+    auto run_band = [&](const int yb0, const float inv) {
+        int npairs_all = (y_hi - yb0 + 1) / 2;              // row pairs of this band that hold valid rows
+        npairs_all = npairs_all > RB / 2 ? RB / 2 : npairs_all;
+        // this wave's share of the row pairs (row group): the code below sees a band that starts at its first row pair
+        constexpr int RPG = (RB / 2 + RS - 1) / RS;
+        const int rp0 = rgroup * RPG;
+        int npairs = npairs_all - rp0;
+        npairs = npairs > RPG ? RPG : (npairs < 0 ? 0 : npairs);
+        const int yb = yb0 + 2 * rp0;
+        const unsigned rowb0 = (unsigned)(rp0 * RPP * 4);
         if constexpr (ILP) {
             // k-step outermost, the three column blocks of a row pair in three accumulators: the nine MFMAs of a k-step go out
             // as hh(0) hh(1) hh(2) hl(0) hl(1) hl(2) lh(0) lh(1) lh(2), so an accumulator is touched every third issue slot
@@ -752,8 +771,8 @@ __global__ __launch_bounds__(64 * NC, (PAIR && AADFF_SB_ILP ? 3 : 1)) void conv_
             };
             auto row_pair = [&](auto pc, const int rpi) {
                 constexpr int P = decltype(pc)::value;
-                const unsigned rowb = (unsigned)(rpi * RPP * 4);
-                const unsigned rowb_next = (unsigned)((rpi + 1 < npairs ? rpi + 1 : rpi) * RPP * 4);
+                const unsigned rowb = rowb0 + (unsigned)(rpi * RPP * 4);
+                const unsigned rowb_next = rowb0 + (unsigned)((rpi + 1 < npairs ? rpi + 1 : rpi) * RPP * 4);
                 const int yl = 2 * rpi;
                 const bool row1 = yb + yl + 1 < y_hi;
                 const unsigned loff = koff + (unsigned)(yb + yl) * w4 + (unsigned)(x0 + 2 * lo4) * 4u;
@@ -819,7 +838,7 @@ __global__ __launch_bounds__(64 * NC, (PAIR && AADFF_SB_ILP ? 3 : 1)) void conv_
                     }
                 }
             };
-            issue_set(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0u);
+            issue_set(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, rowb0);
             int rpi = 0;
 #pragma unroll 1
             for (; rpi + 1 < npairs; rpi += 2) {
@@ -838,6 +857,73 @@ __global__ __launch_bounds__(64 * NC, (PAIR && AADFF_SB_ILP ? 3 : 1)) void conv_
                          :: "memory");
             return;
         }
+#if AADFF_SB_NBUF == 2
+        {
+            // Two operand buffers, reads ONE step ahead: 8 VGPRs fewer than the three-buffer form - what it takes to fit
+            // 96 VGPRs = 5 waves per SIMD = 6 workgroups (18 waves) per CU, i.e. all 1452 workgroups of the bench launch
+            // resident in ONE round (no 12 us tail of 172 late workgroups; tools/conv_timeline.py).  A row pair has 15 steps,
+            // so the buffer roles swap from one row pair to the next (P).
+            uint2v xq[2][4];
+            auto issue = [&](auto bfc, auto stepc, unsigned rowb) {
+                constexpr int bf = decltype(bfc)::value, step = decltype(stepc)::value, cb = step / 5, st = step % 5;
+                const unsigned a = xaddr[st] + rowb;
+                lds_read16<cb * 128>(xq[bf][0], xq[bf][1], a);
+                lds_read16<LO * 4 + cb * 128>(xq[bf][2], xq[bf][3], a);
+            };
+            auto row_pair = [&](auto pc, const int rpi) {
+                constexpr int P = decltype(pc)::value;
+                const unsigned rowb = rowb0 + (unsigned)(rpi * RPP * 4);
+                const unsigned rowb_next = rowb0 + (unsigned)((rpi + 1 < npairs ? rpi + 1 : rpi) * RPP * 4);
+                const int yl = 2 * rpi;
+                const bool row1 = yb + yl + 1 < y_hi;
+                const unsigned loff = koff + (unsigned)(yb + yl) * w4 + (unsigned)(x0 + 2 * lo4) * 4u;
+                float4v acc;
+                auto step_fn = [&](auto stepc) {
+                    constexpr int step = decltype(stepc)::value, cb = step / 5, st = step % 5, bf = (P + step) & 1, nx = bf ^ 1;
+                    if constexpr (step + 1 < 15) issue(std::integral_constant<int, nx>{}, std::integral_constant<int, step + 1>{}, rowb);
+                    else issue(std::integral_constant<int, nx>{}, std::integral_constant<int, 0>{}, rowb_next);
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xq[bf][0]), "+v"(xq[bf][1]), "+v"(xq[bf][2]), "+v"(xq[bf][3]));
+                    const uint4v h4 = {xq[bf][0].x, xq[bf][0].y, xq[bf][1].x, xq[bf][1].y};
+                    const uint4v l4 = {xq[bf][2].x, xq[bf][2].y, xq[bf][3].x, xq[bf][3].y};
+                    const half8v bh = __builtin_bit_cast(half8v, h4), bl = __builtin_bit_cast(half8v, l4);
+                    const half8v th = __builtin_bit_cast(half8v, Th[st]), tl = __builtin_bit_cast(half8v, Tl[st]);
+                    if constexpr (st == 0) acc = (float4v){0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl, bh, acc, 0, 0, 0);
+                    if constexpr (st == 4) {
+                        const float a0 = acc[0] * inv, b0 = acc[1] * inv, a1 = acc[2] * inv, b1 = acc[3] * inv;
+                        char* o0 = wbase + loff + cb * 128;
+                        char* o1 = wbase + (loff + w4) + cb * 128;
+                        if (pair_ok[cb]) {
+                            *reinterpret_cast<f2u*>(o0) = (f2u){a0, b0};
+                            if (row1) *reinterpret_cast<f2u*>(o1) = (f2u){a1, b1};
+                        } else if (one_ok[cb]) {
+                            *reinterpret_cast<float*>(o0) = a0;
+                            if (row1) *reinterpret_cast<float*>(o1) = a1;
+                        }
+                    }
+                };
+                step_fn(std::integral_constant<int, 0>{}); step_fn(std::integral_constant<int, 1>{}); step_fn(std::integral_constant<int, 2>{});
+                step_fn(std::integral_constant<int, 3>{}); step_fn(std::integral_constant<int, 4>{}); step_fn(std::integral_constant<int, 5>{});
+                step_fn(std::integral_constant<int, 6>{}); step_fn(std::integral_constant<int, 7>{}); step_fn(std::integral_constant<int, 8>{});
+                step_fn(std::integral_constant<int, 9>{}); step_fn(std::integral_constant<int, 10>{}); step_fn(std::integral_constant<int, 11>{});
+                step_fn(std::integral_constant<int, 12>{}); step_fn(std::integral_constant<int, 13>{}); step_fn(std::integral_constant<int, 14>{});
+            };
+            issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, rowb0);
+            int rpi = 0;
+#pragma unroll 1
+            for (; rpi + 1 < npairs; rpi += 2) {
+                row_pair(std::integral_constant<int, 0>{}, rpi);
+                row_pair(std::integral_constant<int, 1>{}, rpi + 1);
+            }
+            if (rpi < npairs) row_pair(std::integral_constant<int, 0>{}, rpi);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(xq[0][0]), "+v"(xq[0][1]), "+v"(xq[0][2]), "+v"(xq[0][3]), "+v"(xq[1][0]), "+v"(xq[1][1]), "+v"(xq[1][2]), "+v"(xq[1][3])
+                         :: "memory");
+            return;
+        }
+#endif
         // 15 (cb, st) steps per row pair, operand reads two steps ahead (three 8-register buffers; 15 % 3 == 0 keeps the
         // rotation across row pairs, so the last two steps prefetch the next row pair's first two).  Column block
         // outermost: one accumulator live, its stores overlap the next block's MFMAs.
@@ -848,12 +934,12 @@ __global__ __launch_bounds__(64 * NC, (PAIR && AADFF_SB_ILP ? 3 : 1)) void conv_
             lds_read16<cb * 128>(xq[bf][0], xq[bf][1], a);
             lds_read16<LO * 4 + cb * 128>(xq[bf][2], xq[bf][3], a);
         };
-        issue(std::integral_constant<int, 0>{}, 0u);
-        issue(std::integral_constant<int, 1>{}, 0u);
+        issue(std::integral_constant<int, 0>{}, rowb0);
+        issue(std::integral_constant<int, 1>{}, rowb0);
     #pragma unroll 1
         for (int rpi = 0; rpi < npairs; ++rpi) {
-            const unsigned rowb = (unsigned)(rpi * RPP * 4);
-            const unsigned rowb_next = (unsigned)((rpi + 1 < npairs ? rpi + 1 : rpi) * RPP * 4);
+            const unsigned rowb = rowb0 + (unsigned)(rpi * RPP * 4);
+            const unsigned rowb_next = rowb0 + (unsigned)((rpi + 1 < npairs ? rpi + 1 : rpi) * RPP * 4);
             const int yl = 2 * rpi;
             const bool row1 = yb + yl + 1 < y_hi;           // row 0 of the pair is valid by construction of npairs
             const unsigned loff = koff + (unsigned)(yb + yl) * w4 + (unsigned)(x0 + 2 * lo4) * 4u;
@@ -1051,6 +1137,8 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
             // AADFF_CONV_PAIR: 0 = one band per workgroup (round-2 form), N >= 1 = bands in pairs for every N-th (patch, plane)
             const int pair_mod = [] { const char* e = getenv("AADFF_CONV_PAIR"); const int v = e ? atoi(e) : AADFF_CONV_PAIR_DEFAULT; return v < 0 ? 0 : v; }();   // read per launch: tests switch it
             const bool pair = pair_mod > 0;
+            // (RS = 2 - two row groups per chunk, 6 waves per workgroup sharing one staged band - is implemented in the kernel and
+            // bit-equal, but with the paired form's 118 VGPRs it only fits 2 workgroups per CU or spills: 77 us; not instantiated)
             const int gny = snty;
             PatchBounds pbs = pb;
             pbs.m_ntx = magic_of(sntx); pbs.m_nty = magic_of(gny); pbs.m_nchunk = magic_of(npass); pbs.m_c = magic_of(C);
@@ -1059,10 +1147,10 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
             // aadff_time_next_launch: the two events ride ON this dispatch (kernel begin / end timestamps)
             hipEvent_t ev0 = g_time_start, ev1 = g_time_stop;
             g_time_start = g_time_stop = nullptr;
-#define AADFF_LAUNCH_S2(NCV, PR) do { \
-                if (ev0) hipExtLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR, true>), gs, dim3(64 * NCV), 0, st, ev0, ev1, 0, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); \
-                else hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR>), gs, dim3(64 * NCV), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); } while (0)
-#define AADFF_LAUNCH_S(NCV) do { if (pair) AADFF_LAUNCH_S2(NCV, true); else AADFF_LAUNCH_S2(NCV, false); } while (0)
+#define AADFF_LAUNCH_S3(NCV, PR, RSV) do { \
+                if (ev0) hipExtLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR, true, RSV>), gs, dim3(64 * NCV * RSV), 0, st, ev0, ev1, 0, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); \
+                else hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR, false, RSV>), gs, dim3(64 * NCV * RSV), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); } while (0)
+#define AADFF_LAUNCH_S(NCV) do { if (pair) AADFF_LAUNCH_S3(NCV, true, 1); else AADFF_LAUNCH_S3(NCV, false, 1); } while (0)
             switch (nc) {
                 case 1: AADFF_LAUNCH_S(1); break;
                 case 2: AADFF_LAUNCH_S(2); break;
@@ -1070,7 +1158,7 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
                 default: AADFF_LAUNCH_S(4);
             }
 #undef AADFF_LAUNCH_S
-#undef AADFF_LAUNCH_S2
+#undef AADFF_LAUNCH_S3
             return 0;
         }
     }
