@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AADFF_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libaadff.so")   # AADFF_LIB: A/B builds (tools/)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_GRID, MAX_KS, MAX_SURF, MAX_AI = 64, 51, 32, 8
 SURF_STOP, SURF_SPHERIC, SURF_ASPHERIC = 0, 1, 2
 
@@ -96,6 +96,7 @@ PROTOTYPES = {
     "aadff_fit_adamw": [_P, _P, _P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _P],
     "aadff_adamw_step": [_P, _P, _I, _P, _P, _P, _L, _P, _P, _F, _I, _F, _F, _F, _F, _P],
     "aadff_host_mt19937_uniform_f32": [_P, _L, _L, _P],
+    "aadff_host_mt19937_discard": [_P, _L, _L],
 }
 OTHER_SYMBOLS = ["aadff_abi_version", "aadff_last_error", "aadff_device_info"]
 

@@ -90,14 +90,30 @@ def init_from_env(backend=None, device=None):
     return rank, world
 
 
-def shard_units(n_units, rank, world):
-    """Round-robin ownership: rank r renders units u = r (mod world)."""
-    return list(range(rank, n_units, world))
+def shard_units(n_units, rank, world, block=1):
+    """Blocks of `block` consecutive units dealt round-robin: unit u belongs to rank (u // block) % world.  block = 1 is
+    SURVEY.md 8e's u = r (mod world); block = S hands out whole scenes (`scene_block`)."""
+    block = int(block)
+    nblocks = (n_units + block - 1) // block
+    return [u for b in range(rank, nblocks, world) for u in range(b * block, min(n_units, (b + 1) * block))]
 
 
-def padded_share(n_units, world):
-    """Units per rank after padding to equal shares (all_gather needs equal shapes)."""
-    return (n_units + world - 1) // world
+def padded_share(n_units, world, block=1):
+    """Units per rank after padding to equal shares of whole blocks (all_gather needs equal shapes)."""
+    nblocks = (n_units + block - 1) // block
+    return (nblocks + world - 1) // world * block
+
+
+def scene_block(n_units, S, world):
+    """Block size for (scene, slice) units: the largest divisor of S (blocks must not straddle scenes) that still gives
+    every rank a block.  A rank's launches, and the host draws it replicates per scene, go with the number of SCENES it
+    touches: with u = r (mod 8) a rank of config 3 touches all 16 scenes for 1-2 slices each and measures 3.3x slower than
+    its share of the work (tools/c3_share_probe.py); with block = S = 10 it renders 2 whole scenes at the one-GPU rate."""
+    best = 1
+    for d in range(1, S + 1):
+        if S % d == 0 and d * world <= max(n_units, world):
+            best = d
+    return best
 
 
 def _host_backend():
@@ -170,24 +186,25 @@ class GatherRing:
 
 
 def gather_row(row, rank):
-    """Complete one row `[world, *unit]` of the unit-order buffer: rank r's unit sits at row[r]; ONE all-gather fills the
-    others.  RCCL gathers in place (send buffer = receive buffer + rank x count); gloo gets a copy of the own unit."""
+    """Complete one row `[world, ...]` of the unit-order buffer: rank r's block sits at row[r]; ONE all-gather fills the
+    others.  RCCL gathers in place (send buffer = receive buffer + rank x count); gloo gets a copy of the own block."""
     all_gather_into(row, row[rank] if not _host_backend() else row[rank].clone())
 
 
-def render_sharded(n_units, render_unit, unit_shape, dtype=torch.float32, device="cpu", gather=True, stream=None):
+def render_sharded(n_units, render_unit, unit_shape, dtype=torch.float32, device="cpu", gather=True, stream=None, block=1):
     """Render this rank's units with `render_unit(u) -> tensor[unit_shape]` and, if `gather`,
     return the full `[n_units, *unit_shape]` tensor on every rank (the rank's own `[share, *unit_shape]` units otherwise:
-    the consumer is rank-local, e.g. DDP training).  The gather buffer is `[share, world, *unit_shape]` - row i holds units
-    i*world .. i*world + world - 1, i.e. unit order - and row i is completed by one all-gather as soon as this rank's unit
-    of that row is rendered (per-row chunks, no reorder).  With `stream` the gathers run on that side stream
+    the consumer is rank-local, e.g. DDP training).  The gather buffer is `[rows, world, block, *unit_shape]` - row i holds
+    the units (i*world)*block .. (i*world + world)*block - 1, i.e. unit order - and row i is completed by one all-gather
+    as soon as this rank's block of that row is rendered (per-row chunks, no reorder).  With `stream` the
+    gathers run on that side stream
     and the call ALWAYS returns three values `(out, mine, done)`: `done` is the event the consumer must wait
     on (the caller may render the next batch meanwhile), or None when nothing ran on the side stream (one rank, or
     `gather=False`).  Without `stream` it returns `(out, mine)` and the result is ready on the current stream."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    share = padded_share(n_units, world)
-    mine = shard_units(n_units, rank, world)
+    share = padded_share(n_units, world, block)
+    mine = shard_units(n_units, rank, world, block)
     if not gather or world == 1:
         local = torch.zeros((share,) + tuple(unit_shape), dtype=dtype, device=device)
         for i, u in enumerate(mine):
@@ -195,14 +212,17 @@ def render_sharded(n_units, render_unit, unit_shape, dtype=torch.float32, device
         out = local[:n_units] if (gather and world == 1) else local
         return (out, mine) if stream is None else (out, mine, None)
     full = torch.zeros((share * world,) + tuple(unit_shape), dtype=dtype, device=device)
-    rows = full.view((share, world) + tuple(unit_shape))
+    n_rows = share // block
+    rows = full.view((n_rows, world, block) + tuple(unit_shape))
     on_gpu = full.is_cuda
     cur = torch.cuda.current_stream(device) if on_gpu else None
     if stream is not None and on_gpu:
         full.record_stream(stream)
-    for i in range(share):
-        if i < len(mine):
-            rows[i, rank].copy_(render_unit(mine[i]))
+    for i in range(n_rows):
+        for j in range(block):
+            u = (i * world + rank) * block + j
+            if u < n_units:
+                full[u].copy_(render_unit(u))
         if stream is not None and on_gpu:
             ev = torch.cuda.Event()
             ev.record(cur)

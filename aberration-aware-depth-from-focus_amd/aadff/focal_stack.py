@@ -7,6 +7,7 @@ ONE fused PSF launch over S x 3 wavelengths x g^2 field points and ONE stack-fus
 convolution; the S lens states stay on the device in between.
 Mode M2: the per-pixel-PSF path the training scripts call (PSFNet.render per slice).
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -444,9 +445,53 @@ def render_focal_stack_m2(lens, img, depth_m, n_stack):
     return torch.stack([lens.render(img, -depth_m * 1e3, -fds[:, i] * 1e3) for i in range(n_stack)], dim=2), fds
 
 
-def shard_units(n_units, rank, world):
-    """Round-robin unit ownership u = rank (mod world)."""
-    return list(range(rank, n_units, world))
+def shard_units(n_units, rank, world, block=1):
+    """Unit ownership (u // block) = rank (mod world); block = 1 is SURVEY.md §8e's round robin (aadff.dist.shard_units)."""
+    from .dist import shard_units as f
+    return f(n_units, rank, world, block)
+
+
+class RowSampler:
+    """The rows `rows` (ascending) of the `[n_rows, per]` block of draws that starts at the generator's current position,
+    taken straight from the host generator: the rows in between are SKIPPED (aadff_host_mt19937_discard: the generator's
+    regenerations only), not produced and dropped.  A rank of a sharded job owns some slices of a scene's stack and must
+    consume exactly the draws the whole-stack render would give those slices.  The generator is left
+    behind the last owned row, not behind the block (every scene is re-seeded)."""
+    on_device = False
+
+    def __init__(self, base, rows, per):
+        self.base, self.rows, self.per = base, list(rows), int(per)
+        assert all(b > a for a, b in zip(self.rows, self.rows[1:])), "rows must ascend"
+        self.preset = None
+
+    def rand_into(self, out):
+        per, rows = self.per, self.rows
+        if self.preset is not None or out.numel() != len(rows) * per or not out.is_contiguous() or out.dim() != 1:
+            return self._fallback().rand_into(out)
+        pos = i = 0
+        while i < len(rows):
+            j = i
+            while j + 1 < len(rows) and rows[j + 1] == rows[j] + 1:
+                j += 1                                           # a run of consecutive rows is one draw
+            self.base.skip((rows[i] - pos) * per)
+            self.base.rand_into(out[i * per:(j + 1) * per])
+            pos, i = rows[j] + 1, j + 1
+        self.preset = False
+        return out
+
+    def _fallback(self):
+        if not self.preset:
+            assert self.preset is None, "RowSampler: the rows were already consumed"
+            block = torch.empty(len(self.rows) * self.per)
+            self.rand_into(block)
+            self.preset = PresetSampler(block)
+        return self.preset
+
+    def rand(self, n):
+        return self._fallback().rand(n)
+
+    def rand_block(self, sizes):
+        return self._fallback().rand_block(sizes)
 
 
 class PresetSampler:
@@ -502,11 +547,17 @@ class SceneUnitRenderer:
     draw: 0.1 ms on the host) and consumes only the rows of the slices it owns.  The slices a rank owns within one
     scene go through ONE refocus / PSF-grid / convolution launch triple."""
 
-    def __init__(self, lens, scenes, S, grid=11, ks=11, spp=GEO_SPP, seed_scene=None):
+    def __init__(self, lens, scenes, S, grid=11, ks=11, spp=GEO_SPP, seed_scene=None, streams=1):
+        """`seed_scene(scene)` seeds torch's CPU generator for a scene (default: the CPU half of `torch.manual_seed(scene)`,
+        2 us instead of 26-125).  `streams` > 1: consecutive scene groups go to that many HIP streams in turn, each with
+        plans of its own, so the small launches of one group (a rank of an 8-rank job owns 1-2 slices of a scene in the
+        round-robin partition) run beside those of the next and the PSF-grid kernel of one scene beside the convolution
+        of another (StackPipeline's effect: +10 % on whole stacks)."""
         self.lens, self.scenes, self.S, self.grid, self.ks, self.spp = lens, scenes, S, grid, ks, spp
-        self.seed_scene = seed_scene or (lambda scene: torch.manual_seed(scene))
+        self.seed_scene = seed_scene or (lambda scene: torch.default_generator.manual_seed(int(scene)))
         self.per = stack_uniform_layout(spp)[0]
         self.plans = {}
+        self.n_streams, self.streams, self.turn = max(1, int(streams)), None, 0
 
     def n_units(self):
         return len(self.scenes) * self.S
@@ -516,8 +567,9 @@ class SceneUnitRenderer:
         out_index[k] = k).  The slices of one scene whose destinations form an arithmetic progression - always the case for
         a rank's share in ascending order, in the local layout and in the all-gather buffer alike - are written by the
         convolution itself (aadff_render_psf_map_stack_strided); anything else is rendered into the plan's stack and copied.
-        `after_group(positions)` is called after the launches of each scene group (its destinations are then queued on the
-        current stream): the sharded renderer starts the group's all-gather chunks from it."""
+        `after_group(positions)` is called after the launches of each scene group, with the stream they were queued on as
+        the current stream: the sharded renderer starts the group's all-gather chunks from it.  On return the caller's
+        current stream waits for every group."""
         lens, S = self.lens, self.S
         by_scene = {}
         for pos, u in enumerate(units):
@@ -527,33 +579,51 @@ class SceneUnitRenderer:
         dev = lens._gpu()
         if out is None:
             out = torch.empty((len(units), C_, H, W), dtype=torch.float32, device=dev)
+        cur = torch.cuda.current_stream(dev)
+        multi = self.n_streams > 1 and len(by_scene) > 1
+        if multi:
+            if self.streams is None:
+                self.streams = [torch.cuda.Stream(dev) for _ in range(self.n_streams)]
+            for st in self.streams:
+                st.wait_stream(cur)                       # inputs and `out` are ready on the caller's stream
         saved = lens.sampler
+        host_rows = not saved.on_device and hasattr(saved, "skip")
         try:
             for scene, items in by_scene.items():
                 img, depth_plane_mm, focus = self.scenes[scene]
                 focus = [float(f) for f in np.asarray(focus, dtype=np.float64).reshape(-1)]
                 assert len(focus) == S
+                items = sorted(items)
                 sl = [k for k, _ in items]
                 dst = [q for _, q in items]
                 self.seed_scene(scene)
-                block = saved.rand_block([S * self.per]).reshape(S, self.per)        # the whole stack's draws
-                lens.sampler = PresetSampler(block, rows=sl)
+                if host_rows:
+                    lens.sampler = RowSampler(saved, sl, self.per)               # only the owned slices' draws, rest skipped
+                else:
+                    block = saved.rand_block([S * self.per]).reshape(S, self.per)        # the whole stack's draws
+                    lens.sampler = PresetSampler(block, rows=sl)
                 n = len(sl)
-                plan = self.plans.get(n)
+                slot = self.turn % self.n_streams if multi else 0
+                self.turn += 1
+                plan = self.plans.get((n, slot))
                 if plan is None:
-                    plan = self.plans[n] = StackPlan(lens, n, H, W, 1, C_, self.grid, self.ks, self.spp)
+                    plan = self.plans[(n, slot)] = StackPlan(lens, n, H, W, 1, C_, self.grid, self.ks, self.spp)
                 step = dst[1] - dst[0] if n > 1 else 1
                 direct = (B == 1 and step >= 1 and all(dst[i] == dst[0] + i * step for i in range(n)) and out.is_cuda
                           and out.is_contiguous() and out.dtype == torch.float32 and step * C_ * H * W < (1 << 28))
-                st = render_focal_stack_m1(lens, img, depth_plane_mm, [focus[k] for k in sl], self.grid, self.ks, self.spp,
-                                           plan=plan, update_lens=False, dest=(out, dst[0], step) if direct else None)
-                if not direct:
-                    for i, q in enumerate(dst):
-                        out[q].copy_(st[0, :, i])
-                if after_group is not None:
-                    after_group(dst)
+                with (torch.cuda.stream(self.streams[slot]) if multi else contextlib.nullcontext()):
+                    st = render_focal_stack_m1(lens, img, depth_plane_mm, [focus[k] for k in sl], self.grid, self.ks, self.spp,
+                                               plan=plan, update_lens=False, dest=(out, dst[0], step) if direct else None)
+                    if not direct:
+                        for i, q in enumerate(dst):
+                            out[q].copy_(st[0, :, i])
+                    if after_group is not None:
+                        after_group(dst)
         finally:
             lens.sampler = saved
+            if multi:
+                for st in self.streams:
+                    cur.wait_stream(st)
         return out
 
     def check_flags(self):
@@ -561,24 +631,30 @@ class SceneUnitRenderer:
             plan.check_flags()
 
 
-def render_scenes_sharded(renderer, gather=True, stream=None):
+def render_scenes_sharded(renderer, gather=True, stream=None, block=None):
     """This rank's share of all (scene, slice) units through the HIP renderer and, with `gather`, the full
     `[n_scenes*S, C, H, W]` set in unit order on every rank.  Returns `(out, mine)`, or with `stream`
     always `(out, mine, done_or_None)` (aadff.dist.render_sharded semantics).
 
-    No copy and no reorder anywhere: the buffer is laid out `[share, world, C, H, W]`, whose row i holds the units
-    i*world .. i*world + world - 1 - rank r's i-th unit is unit i*world + r, so this IS unit order.  The convolution
-    writes each of this rank's slices straight to its place (`aadff_render_psf_map_stack_strided`, slice stride =
-    world units), and row i is completed by ONE in-place all-gather of that row (12.6 MB per rank at 1024^2) as soon as
-    the scene group that produced it has been launched: with `stream` the gathers run on that side stream, overlapped
-    with the rendering of the following scenes, per-row chunks instead of one monolithic collective at the end."""
+    `block`: units are dealt to the ranks in blocks of that many consecutive units (aadff.dist.shard_units); default
+    `scene_block` = whole scenes when there are enough of them (config 3 on 8 ranks: 2 scenes per rank, 2 launch triples
+    and 2 scenes' draws per step instead of 16), 1 = SURVEY's u = r (mod world).
+
+    No copy and no reorder anywhere: the buffer is laid out `[rows, world, block, C, H, W]`, whose row i holds the units
+    (i*world)*block .. (i*world + world)*block - 1 - rank r's i-th block is block i*world + r, so this IS unit order.
+    The convolution writes each of this rank's slices straight to its place (`aadff_render_psf_map_stack_strided`), and
+    row i is completed by ONE in-place all-gather of that row (block x 12.6 MB per rank at 1024^2) as soon as the scene
+    groups that produce this rank's block of it have been launched: with `stream` the gathers run on that side stream,
+    overlapped with the rendering of the following scenes, per-row chunks instead of one monolithic collective at the end."""
     import torch.distributed as dist
     from . import dist as adist
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     n = renderer.n_units()
-    mine = adist.shard_units(n, rank, world)
-    share = adist.padded_share(n, world)
+    if block is None:
+        block = adist.scene_block(n, renderer.S, world)
+    mine = adist.shard_units(n, rank, world, block)
+    share = adist.padded_share(n, world, block)
     img0 = renderer.scenes[0][0]
     dev = renderer.lens._gpu()
     unit_shape = tuple(img0.shape[1:])
@@ -587,29 +663,40 @@ def render_scenes_sharded(renderer, gather=True, stream=None):
         renderer.render(mine, out=local[:len(mine)])
         return (local[:len(mine)] if world == 1 else local, mine) if stream is None else (local[:len(mine)] if world == 1 else local, mine, None)
     full = torch.empty((share * world,) + unit_shape, dtype=torch.float32, device=dev)
-    rows = full.view((share, world) + unit_shape)
-    if len(mine) < share:
-        rows[len(mine):, rank].zero_()                # padding units of the equal-share gather (n not a multiple of world)
+    n_rows = share // block
+    rows = full.view((n_rows, world, block) + unit_shape)
+    owned = [0] * n_rows                                # units of this rank per row still to be queued
+    for u in mine:
+        owned[u // (world * block)] += 1
+    for i in range(n_rows):                             # padding units of the equal-share gather (own slots past n)
+        if owned[i] < block:
+            rows[i, rank, owned[i]:].zero_()
     cur = torch.cuda.current_stream(dev)
     side = stream if stream is not None else cur
     if stream is not None:
         full.record_stream(stream)
+    state = {"next": 0}
 
-    def gather_rows(idx):
-        if side is not cur:
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            side.wait_event(ev)
-        with torch.cuda.stream(side):
-            for i in idx:
-                adist.gather_row(rows[i], rank)
+    def gather_ready():
+        """Rows are gathered in ascending order on every rank (collectives must be issued in the same order everywhere)."""
+        while state["next"] < n_rows and owned[state["next"]] == 0:
+            with torch.cuda.stream(side):
+                adist.gather_row(rows[state["next"]], rank)
+            state["next"] += 1
 
     def after_group(dst):
-        gather_rows([q // world for q in dst])        # destinations of this rank are full[i*world + rank]
+        here = torch.cuda.current_stream(dev)           # the stream the group's launches were queued on
+        if side is not here:
+            ev = torch.cuda.Event()
+            ev.record(here)
+            side.wait_event(ev)
+        for q in dst:                                   # destinations are unit ids: the buffer is in unit order
+            owned[q // (world * block)] -= 1
+        gather_ready()
 
-    renderer.render(mine, out=full, out_index=[i * world + rank for i in range(len(mine))], after_group=after_group)
-    if len(mine) < share:
-        gather_rows(range(len(mine), share))
+    renderer.render(mine, out=full, out_index=mine, after_group=after_group)
+    gather_ready()                                      # rows in which this rank owns nothing
+    assert state["next"] == n_rows
     if stream is None:
         return full[:n], mine
     done = torch.cuda.Event()

@@ -46,8 +46,25 @@ def _fast_host_rand_into(out):
     return True
 
 
+def _fast_host_discard(n):
+    """Advance torch's global CPU generator past n float32 draws without producing them (aadff_host_mt19937_discard)."""
+    if _FAST is not True:
+        return False
+    from . import _abi
+    st = torch.get_rng_state()
+    if _abi.load_library().aadff_host_mt19937_discard(C.c_void_p(st.data_ptr()), st.numel(), int(n)) != 0:
+        return False
+    torch.set_rng_state(st)
+    return True
+
+
 class HostSampler:
     on_device = False
+
+    def skip(self, n):
+        """Leave the generator where `torch.rand(n)` would, without the draws (a sharded rank skipping slices it does not own)."""
+        if n > 0 and not _fast_host_discard(n):
+            torch.rand(int(n))
 
     def rand(self, n):
         return torch.rand(n)

@@ -58,7 +58,7 @@ constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0
             }                                                                                                      \
             long run = left - 1; /* outputs available before the next regeneration */                              \
             if (run > n - i) run = n - i;                                                                          \
-            temper(st + nxt, out + i, run);                                                                        \
+            if (out) temper(st + nxt, out + i, run); /* out == NULL: discard (aadff_host_mt19937_discard) */        \
             i += run;                                                                                              \
             nxt += (int)run;                                                                                       \
             left -= (int)run;                                                                                      \
@@ -75,8 +75,7 @@ struct Avx512 { AADFF_MT_BODY(16) };
 #pragma clang attribute pop
 }  // namespace
 
-extern "C" int aadff_host_mt19937_uniform_f32(unsigned char* torch_state, long state_bytes, long n, float* out) {
-    AADFF_CHECK_ARG(torch_state && out && n >= 0, "host_mt19937: NULL pointer or negative count");
+static int advance(unsigned char* torch_state, long state_bytes, long n, float* out) {
     AADFF_CHECK_ARG(state_bytes == 5056, "host_mt19937: unexpected torch CPU generator state size %ld (want 5056)", state_bytes);
     int32_t left;
     uint64_t next64;
@@ -103,4 +102,16 @@ extern "C" int aadff_host_mt19937_uniform_f32(unsigned char* torch_state, long s
         std::memcpy(torch_state + 24 + 8 * k, &v, 8);
     }
     return 0;
+}
+
+extern "C" int aadff_host_mt19937_uniform_f32(unsigned char* torch_state, long state_bytes, long n, float* out) {
+    AADFF_CHECK_ARG(torch_state && out && n >= 0, "host_mt19937: NULL pointer or negative count");
+    return advance(torch_state, state_bytes, n, out);
+}
+
+// The state after `n` further float32 draws, without producing them (regenerations only, no tempering / conversion / stores):
+// a rank of a sharded job that owns some slices of a scene's stack skips the draws of the others.
+extern "C" int aadff_host_mt19937_discard(unsigned char* torch_state, long state_bytes, long n) {
+    AADFF_CHECK_ARG(torch_state && n >= 0, "host_mt19937_discard: NULL pointer or negative count");
+    return advance(torch_state, state_bytes, n, nullptr);
 }

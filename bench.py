@@ -351,8 +351,9 @@ def main():
 
 
 def main_c3(args):
-    """BASELINE.json config 3: 16 scenes x 10 slices = 160 (scene, slice) units, rank r renders u = r (mod N), ONE
-    all-gather reassembles [160,3,1024,1024] on every rank.  Total work is fixed: strong scaling."""
+    """BASELINE.json config 3: 16 scenes x 10 slices = 160 (scene, slice) units dealt to the ranks in whole-scene blocks
+    (AADFF_C3_BLOCK=1: SURVEY.md 8e's u = r (mod N)), per-row in-place all-gathers reassemble [160,3,1024,1024] on every
+    rank.  Total work is fixed: strong scaling."""
     import torch.distributed as dist
     from aadff import dist as adist
     from aadff.focal_stack import SceneUnitRenderer, render_scenes_sharded
@@ -371,12 +372,15 @@ def main_c3(args):
         depth = synth_depth_mm(H, W, seed=5678 + sc)
         scenes.append((torch.from_numpy(synth_rgb(H, W, seed=1234 + sc))[None].to(dev), -float(depth.mean()),
                        -np.linspace(depth.min(), depth.max(), S)))
-    rend = SceneUnitRenderer(lens, scenes, S, GRID, KS, SPP)
+    c3_streams = int(os.environ.get("AADFF_C3_STREAMS", "2"))
+    rend = SceneUnitRenderer(lens, scenes, S, GRID, KS, SPP, streams=c3_streams)
+    n_units = n_scenes * S
+    block = int(os.environ.get("AADFF_C3_BLOCK", "0")) or adist.scene_block(n_units, S, world)
     steps, warm = (min(args.steps, 10) if args.steps == 200 else args.steps), min(args.warmup, 2)
     side = torch.cuda.Stream(dev) if world > 1 else None
 
     def step():
-        full, _, done = render_scenes_sharded(rend, gather=True, stream=side or torch.cuda.current_stream(dev))
+        full, _, done = render_scenes_sharded(rend, gather=True, stream=side or torch.cuda.current_stream(dev), block=block)
         if done is not None:
             torch.cuda.current_stream(dev).wait_event(done)
         return full
@@ -394,6 +398,25 @@ def main_c3(args):
         dist.barrier()
     dt = adist.all_reduce_max(time.perf_counter() - t0)
     rend.check_flags()
+    share8 = None
+    if world == 1:
+        # What ONE rank of an 8-rank job has to do, measured here (untimed leg): rank 0's share of the 8-way partition
+        # rendered on this GPU without peers - its launches, and the host draws it replicates, go with the number of scenes
+        # it touches, so this is NOT t1 / 8 by construction (tools/c3_share_probe.py sweeps partitions and rank counts).
+        share8 = {}
+        for name, blk in (("block", adist.scene_block(n_units, S, 8)), ("half_scene", max(1, S // 2)), ("round_robin", 1)):
+            mine8 = adist.shard_units(n_units, 0, 8, blk)
+            loc = torch.empty((len(mine8), 3, H, W), dtype=torch.float32, device=dev)
+            rend.render(mine8, out=loc)
+            torch.cuda.synchronize(dev)
+            t8 = time.perf_counter()
+            for _ in range(steps):
+                rend.render(mine8, out=loc)
+            torch.cuda.synchronize(dev)
+            share8[name] = {"units_per_block": blk, "units": len(mine8), "scenes_touched": len({u // S for u in mine8}),
+                            "ms": round((time.perf_counter() - t8) / steps * 1e3, 3)}
+            del loc
+        rend.check_flags()
     if rank == 0:
         # What the first real 8-GPU run should be read against (no multi-GPU box in the build loop): every rank
         # must RECEIVE (N-1)/N of the gathered set per step over its 7 xGMI links (~153 GB/s each, point to point).
@@ -402,26 +425,41 @@ def main_c3(args):
         link_in = 7 * 153e9
         exp = {"xgmi_inbound_GBps_per_rank": round(link_in / 1e9, 1), "gathered_bytes": total_bytes,
                "gather_floor_ms_at_8": round(total_bytes * 7 / 8 / link_in * 1e3, 3),
-               "note": "8 ranks: render time = 1-rank time / 8 (units are independent, host draws replicate per scene); with the "
-                       "gather a step cannot be shorter than gather_floor_ms_at_8 (each rank receives 7/8 of the set), so the gathered "
+               "note": "render_ms_at_8 is MEASURED: rank 0's share of the 8-way partition rendered on this GPU (whole-scene blocks; "
+                       "the round-robin partition u = r mod 8 is listed beside it). With the gather a step cannot be shorter than "
+                       "gather_floor_ms_at_8 (each rank receives 7/8 of the set) plus the last row's exposed part, so the gathered "
                        "configuration is link-bound and the >= 6x target of north_star is a no-gather target"}
         if world == 1:
             t1 = dt / steps * 1e3
-            exp.update({"render_ms_at_1": round(t1, 3), "render_ms_at_8": round(t1 / 8, 3),
-                        "speedup_at_8_no_gather": 8.0,
-                        "speedup_at_8_with_gather": round(t1 / max(t1 / 8, exp["gather_floor_ms_at_8"]), 2),
-                        "MPs_at_8_no_gather": round(n_scenes * S * H * W / 1e6 / (t1 / 8 * 1e-3), 0),
-                        "MPs_at_8_with_gather": round(n_scenes * S * H * W / 1e6 / (max(t1 / 8, exp["gather_floor_ms_at_8"]) * 1e-3), 0)})
+            t8 = share8["block"]["ms"]
+            rows8 = adist.padded_share(n_units, 8, share8["block"]["units_per_block"]) // share8["block"]["units_per_block"]
+            # rows are gathered as they complete, one after the other on the links: row i can start when this rank's block
+            # of it is rendered ((i+1)/rows of the render time) and row i-1 has arrived
+            def gathered(t_render, rows):
+                g = 0.0
+                for i in range(rows):
+                    g = max((i + 1) * t_render / rows, g) + exp["gather_floor_ms_at_8"] / rows
+                return g
+            with_gather = gathered(t8, rows8)
+            for v in share8.values():
+                v["step_ms_with_gather_model"] = round(gathered(v["ms"], adist.padded_share(n_units, 8, v["units_per_block"]) // v["units_per_block"]), 3)
+            exp.update({"render_ms_at_1": round(t1, 3), "render_ms_at_8": t8, "share_of_8_measured": share8,
+                        "speedup_at_8_no_gather": round(t1 / t8, 2),
+                        "speedup_at_8_with_gather": round(t1 / with_gather, 2),
+                        "MPs_at_8_no_gather": round(n_scenes * S * H * W / 1e6 / (t8 * 1e-3), 0),
+                        "MPs_at_8_with_gather": round(n_scenes * S * H * W / 1e6 / (with_gather * 1e-3), 0)})
         print(json.dumps({
-            "metric": "focal-stack MP/s (config 3: 16 scenes x 10 slices sharded u = r mod N, all-gathered)",
+            "metric": "focal-stack MP/s (config 3: 16 scenes x 10 slices sharded over N ranks in whole-scene blocks, all-gathered)",
             "value": round(n_scenes * S * H * W / 1e6 * steps / dt, 2), "unit": "MP/s", "n_gpus": world, "steps": steps, "warmup": warm,
             "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"rf50mm, {n_scenes} scenes x {S} slices, 1024x1024, 11x11 PSF grid, ks 11, spp 2048, mode M1",
                        "gather": world > 1, "ranks_emulated_on_one_gpu": adist.emulated(),
-                       "gather_form": "slices written by the convolution straight into the unit-order buffer [share, world, C, H, W]; one in-place "
-                                      "all-gather per buffer row (12.6 MB per rank) on a side stream, started as soon as the scene group that "
-                                      "produced the row has been launched",
+                       "partition": f"blocks of {block} consecutive units dealt round-robin (unit u -> rank (u // {block}) % N)",
+                       "streams_per_rank": c3_streams,
+                       "gather_form": "slices written by the convolution straight into the unit-order buffer [rows, world, block, C, H, W]; one "
+                                      f"in-place all-gather per buffer row ({block} x 12.6 MB per rank) on a side stream, started as soon as the "
+                                      "scene groups that produce this rank's block of the row have been launched",
                        "gathered_shape": list(full.shape)},
             "expected_scaling": exp}), flush=True)
     if world > 1:

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AADFF_ABI_VERSION 4
+#define AADFF_ABI_VERSION 5
 
 #define AADFF_EINVAL      (-1)   /* bad shape / size / NULL pointer                  */
 #define AADFF_EUNSUPPORTED (-2)  /* parameter outside what the kernels were built for */
@@ -412,6 +412,12 @@ int aadff_fit_adamw(float* param, float* grad, float* exp_avg, float* exp_avg_sq
  * deeplens/surfaces.py:192-193 at ~7x the speed while leaving torch's generator exactly where the
  * reference's call sequence would.  out_host may be pinned memory. */
 int aadff_host_mt19937_uniform_f32(unsigned char* torch_state_host, long state_bytes, long n, float* out_host);
+
+/* HOST routine: advance the same byte state past n float32 draws without producing them (the generator's regenerations
+ * only) - the state torch.rand(n) would leave behind.  A rank of the sharded configuration that owns some
+ * slices of a scene skips the other slices' draws of the reference's per-scene stream (deeplens/optics.py:480-481 in the
+ * call order of a stack) instead of producing and dropping them. */
+int aadff_host_mt19937_discard(unsigned char* torch_state_host, long state_bytes, long n);
 
 #ifdef __cplusplus
 }

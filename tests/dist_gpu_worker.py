@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Rank process of tests/test_gpu_dist.py (not collected by pytest): (scene, slice) units of a small M1 workload through
-the HIP renderer, sharded u = r (mod world) and all-gathered (gloo when the ranks are emulated on one GPU, RCCL otherwise).
+the HIP renderer, sharded in blocks of units dealt round-robin (block 1: u = r (mod world)) and all-gathered (gloo when the ranks are emulated on one GPU, RCCL otherwise).
 Run without WORLD_SIZE it renders everything on one rank and also writes the plain per-scene stacks."""
 import argparse
 import os
@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--slices", type=int, default=10)
     ap.add_argument("--grid", type=int, default=5)
     ap.add_argument("--spp", type=int, default=512)
+    ap.add_argument("--block", type=int, default=None, help="units per block of the partition (default: aadff.dist.scene_block; 1 = u = r mod world)")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the scene groups of a rank alternate over")
+    ap.add_argument("--tag", default="")
     ap.add_argument("--check-inproc", action="store_true",
                     help="full-size runs: compare every gathered unit with the plain per-scene stack ON THE DEVICE in every rank "
                          "and write only a summary (the full set is 2 GB at 16 scenes x 10 x 1024^2)")
@@ -42,13 +45,14 @@ def main():
         depth = synth_depth_mm(H, W, seed=900 + sc)
         scenes.append((torch.from_numpy(synth_rgb(H, W, seed=800 + sc))[None].to(dev), -float(depth.mean()),
                        -np.linspace(depth.min(), depth.max(), S)))
-    rend = SceneUnitRenderer(lens, scenes, S, GRID, KS, SPP)
-    full, mine = render_scenes_sharded(rend, gather=True)
-    assert mine == adist.shard_units(a.scenes * S, rank, world)
+    rend = SceneUnitRenderer(lens, scenes, S, GRID, KS, SPP, streams=a.streams)
+    full, mine = render_scenes_sharded(rend, gather=True, block=a.block)
+    block = a.block or adist.scene_block(a.scenes * S, S, world)
+    assert mine == adist.shard_units(a.scenes * S, rank, world, block) and all((u // block) % world == rank for u in mine)
     torch.cuda.synchronize(dev)
     if world > 1:                                      # the overlapped form (side stream + event) must deliver the same bytes
         side = torch.cuda.Stream(dev)
-        full2, mine2, done = render_scenes_sharded(rend, gather=True, stream=side)
+        full2, mine2, done = render_scenes_sharded(rend, gather=True, stream=side, block=a.block)
         torch.cuda.current_stream(dev).wait_event(done)
         torch.cuda.synchronize(dev)
         assert mine2 == mine and full2.shape == full.shape
@@ -81,7 +85,7 @@ def main():
                    "mean_abs_pixel": mean}, open(os.path.join(a.out, f"check_w{world}_r{rank}.json"), "w"))
         assert worst <= 5e-6, f"rank {rank}: gathered units differ from the plain per-scene stacks by {worst}"
     elif rank == 0:
-        np.save(os.path.join(a.out, f"full_w{world}.npy"), full.cpu().numpy())
+        np.save(os.path.join(a.out, f"full_w{world}{a.tag}.npy"), full.cpu().numpy())
     if world == 1 and not a.check_inproc:
         stacks = []
         for sc, (img, dbar, fds) in enumerate(scenes):

@@ -73,6 +73,16 @@ def _worker8(rank, world, port, out_dir):
     assert torch.equal(full[37], unit(37))
     odd, _ = render_sharded(157, unit, shape, gather=True)                                     # not a multiple of 8: padded shares
     assert odd.shape[0] == 157 and torch.equal(odd[:, 0, 0, 0], torch.arange(157, dtype=torch.float32))
+    # whole-scene blocks (config 3's default, aadff.dist.scene_block): rank r renders scenes r and r + 8, two row gathers
+    from aadff.dist import scene_block
+    assert scene_block(160, 10, 8) == 10
+    blk, mine_b = render_sharded(n, unit, shape, gather=True, block=10)
+    assert mine_b == list(range(rank * 10, rank * 10 + 10)) + list(range(80 + rank * 10, 90 + rank * 10))
+    assert torch.equal(blk, full), "blocked partition: gathered set differs from the round-robin one"
+    for b, cnt in ((5, 157), (4, 150), (10, 95)):                                              # ragged last block / missing blocks
+        got, mine_c = render_sharded(cnt, unit, shape, gather=True, block=b)
+        assert got.shape[0] == cnt and torch.equal(got[:, 0, 0, 0], torch.arange(cnt, dtype=torch.float32)), (b, cnt)
+        assert mine_c == shard_units(cnt, rank, world, b)
     if rank == 0:
         open(os.path.join(out_dir, "ok8"), "w").write("ok")
     dist.barrier()
@@ -96,6 +106,16 @@ def test_single_process_path_needs_no_group():
 def test_uneven_unit_counts_are_padded():
     assert padded_share(15, 2) == 8 and padded_share(160, 8) == 20 and padded_share(7, 8) == 1
     assert sorted(shard_units(15, 0, 2) + shard_units(15, 1, 2)) == list(range(15))
+    from aadff.dist import scene_block
+    assert padded_share(160, 8, 10) == 20 and padded_share(157, 8, 5) == 20 and padded_share(95, 8, 10) == 20 and padded_share(10, 8, 1) == 2
+    for n, world, block in ((160, 8, 10), (157, 8, 5), (95, 8, 10), (15, 2, 5), (7, 8, 1), (40, 8, 5)):
+        parts = [shard_units(n, r, world, block) for r in range(world)]
+        assert sorted(u for p in parts for u in p) == list(range(n))
+        assert all(len(p) <= padded_share(n, world, block) for p in parts)
+        assert all((u // block) % world == r for r, p in enumerate(parts) for u in p)
+    # whole scenes when every rank can have one, the largest divisor of S otherwise, round robin for a single stack
+    assert [scene_block(160, 10, w) for w in (1, 2, 4, 8)] == [10, 10, 10, 10]
+    assert scene_block(40, 10, 8) == 5 and scene_block(10, 10, 8) == 1 and scene_block(20, 10, 8) == 2 and scene_block(30, 5, 8) == 1
 
 
 _RANK_SCRIPT = '''

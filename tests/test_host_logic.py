@@ -173,6 +173,41 @@ def test_fast_host_rng_continues_torch_generator_bit_exactly():
     assert lib.aadff_host_mt19937_uniform_f32(C.c_void_p(bad.data_ptr()), 100, 4, C.c_void_p(torch.empty(4).data_ptr())) == -1
 
 
+def test_host_rng_discard_and_row_sampler():
+    """aadff_host_mt19937_discard leaves the generator where torch.rand(n) would; RowSampler hands a sharded rank exactly
+    the rows of the whole-stack block that belong to its slices without producing the others."""
+    import aadff.sampling as sm
+    from aadff.focal_stack import PresetSampler, RowSampler
+    s = HostSampler()
+    s.rand_block([8])                       # arms the fast path (self-check)
+    assert sm._FAST is True
+    for n in (0, 1, 623, 624, 625, 20480, 100000):
+        torch.manual_seed(77)
+        torch.rand(5)
+        if n:
+            torch.rand(n)
+        want_state, want_next = torch.get_rng_state(), torch.rand(4)
+        torch.manual_seed(77)
+        torch.rand(5)
+        s.skip(n)
+        assert torch.equal(torch.get_rng_state(), want_state), n
+        assert torch.equal(torch.rand(4), want_next)
+    per, S = 2051, 10
+    torch.manual_seed(3)
+    block = torch.rand(S * per).reshape(S, per)
+    for rows in ([0], [9], [3, 4, 5], [1, 9], [0, 2, 4, 6, 8], list(range(10))):
+        torch.manual_seed(3)
+        out = torch.empty(len(rows) * per)
+        RowSampler(s, rows, per).rand_into(out)
+        assert torch.equal(out.reshape(len(rows), per), block[rows]), rows
+        torch.manual_seed(3)                # consumers that draw call by call get the same rows
+        r = RowSampler(s, rows, per)
+        got = torch.cat([r.rand(per // 2), r.rand_block([per - per // 2] + [per] * (len(rows) - 1))])
+        assert torch.equal(got.reshape(len(rows), per), block[rows])
+    with pytest.raises(AssertionError, match="ascend"):
+        RowSampler(s, [3, 1], per)
+
+
 def test_select_focus_dist_matches_reference_goldens(golden_dir):
     """dff/utils.py:4-50: 'linear' on a batch with invalid pixels, 'importance' in the reference's np.random call order
     (and with its num - 2 quirk)."""
