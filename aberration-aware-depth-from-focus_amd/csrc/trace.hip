@@ -575,6 +575,35 @@ __device__ __forceinline__ void sphere_step2(const SphereP& s, Ray2& r, f2& vm) 
     r.dy = s.eta * r.dy + gc * r.oy;
     r.dz = s.eta * r.dz + (gc * dzt - g);
 }
+#ifdef AADFF_SPHERE_FROM_POINT
+// The same sphere met from where the ray IS (a point of the previous surface, a few mm away) instead of from the vertex
+// plane: with p = o - (0,0,d) the quadratic  c t^2 + 2 t (c p.d - dz) + (c |p|^2 - 2 pz) = 0  has the same near root
+// t = C / -(B + sign(B) sqrt(B^2 - c C)); no division by dz to reach the plane first - one transcendental and two packed
+// instructions fewer per ray pair.  Not for a ray that starts metres away (the object point): c |p|^2 and B^2 then cancel
+// catastrophically in fp32, so the first surface of a trace keeps the vertex-plane form.
+__device__ __forceinline__ void sphere_step2_from_point(const SphereP& s, Ray2& r, f2& vm) {
+    const f2 pz = r.oz - s.d;
+    const f2 p2 = r.ox * r.ox + r.oy * r.oy + pz * pz;
+    const f2 beta = s.c * (r.ox * r.dx + r.oy * r.dy + pz * r.dz) - r.dz;
+    const f2 cc = s.c * p2 - 2.f * pz;
+    const f2 disc = beta * beta - s.c * cc;
+    const f2 root = vsqrt(vmax0(disc));
+    const f2 sroot = (f2){__builtin_copysignf(root.x, beta.x), __builtin_copysignf(root.y, beta.y)};
+    const f2 tau = cc * vrcp(-(beta + sroot));
+    const f2 zt = pz + r.dz * tau;                                      // height above the vertex at the hit
+    r.ox += r.dx * tau; r.oy += r.dy * tau; r.oz = s.d + zt;
+    vm = vmin3(vm, disc, tau);
+    const f2 dn = beta + s.c * tau;
+    const f2 cos2 = dn * dn;
+    vm = vmin3(vm, s.r2 - (r.ox * r.ox + r.oy * r.oy), cos2 - s.thr);
+    const f2 sq = vsqrt(vmax0(s.eta2 * cos2 + (1.f - s.eta2)));
+    const f2 g = -(sq + s.eta * dn);
+    const f2 gc = g * s.c;
+    r.dx = s.eta * r.dx + gc * r.ox;
+    r.dy = s.eta * r.dy + gc * r.oy;
+    r.dz = s.eta * r.dz + (gc * zt - g);
+}
+#endif
 // stop / asphere, forward (the general code of react2 with the margin form of validity)
 __device__ __forceinline__ void other_step2(const aadff_surface_t& s, Ray2& r, f2& vm, int& nan_flag) {
     const f2 t0 = (s.d - r.oz) * vrcp(r.dz);
@@ -631,7 +660,12 @@ __device__ __forceinline__ void trace_part2(const aadff_surface_t* __restrict__ 
                 SphereP cur;
                 cur.d = cs[i].d; cur.c = cs[i].c; cur.r2 = cs[i].r2; cur.eta = cs[i].eta_fwd; cur.eta2 = cs[i].eta_fwd2;
                 cur.thr = __builtin_bit_cast(float, __builtin_bit_cast(int, cs[i].cos2_min_fwd) + 1);
+#ifdef AADFF_SPHERE_FROM_POINT
+                if (i == 0) sphere_step2(cur, r, vm);
+                else sphere_step2_from_point(cur, r, vm);
+#else
                 sphere_step2(cur, r, vm);
+#endif
                 ++i;
             } while (i < last && cs[i].kind == AADFF_SURF_SPHERIC);
         } else {

@@ -166,7 +166,9 @@ def main():
         ring = adist.GatherRing(lambda: torch.empty_like(plan.out), world, slots=2, device=dev)
 
     def step(i, timed=False):
-        torch.manual_seed(i)
+        # every stack is seeded: the CPU generator is the only one the path draws from (the reference's torch.rand calls), and
+        # seeding it alone costs 2 us where torch.manual_seed - which also walks the device generators - costs 26
+        torch.default_generator.manual_seed(i)
         cur = pipe.plans[pipe.turn % pipe.depth]
         if ring is not None:
             k, cur.out = ring.acquire()

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--scenes", type=int, default=16)
     ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--profile", action="store_true", help="cProfile of the timed loop (stderr): where the host spends a step")
     args = ap.parse_args()
     from aadff import dist as adist
     from aadff.focal_stack import SceneUnitRenderer
@@ -61,6 +62,10 @@ def main():
             rend.render(mine, out=local)
         torch.cuda.synchronize(dev)
         host = 0.0
+        if args.profile:
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             h0 = time.perf_counter()
@@ -68,6 +73,10 @@ def main():
             host += time.perf_counter() - h0
         torch.cuda.synchronize(dev)
         wall = (time.perf_counter() - t0) / args.steps * 1e3
+        if args.profile:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(14)
         rend.check_flags()
         if world == 1:
             t1 = wall
