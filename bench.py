@@ -166,9 +166,7 @@ def main():
         ring = adist.GatherRing(lambda: torch.empty_like(plan.out), world, slots=2, device=dev)
 
     def step(i, timed=False):
-        # every stack is seeded: the CPU generator is the only one the path draws from (the reference's torch.rand calls), and
-        # seeding it alone costs 2 us where torch.manual_seed - which also walks the device generators - costs 26
-        torch.default_generator.manual_seed(i)
+        torch.manual_seed(i)                # every stack is seeded (26 us of host time, hidden in the pipeline)
         cur = pipe.plans[pipe.turn % pipe.depth]
         if ring is not None:
             k, cur.out = ring.acquire()
@@ -213,7 +211,7 @@ def main():
         raise SystemExit(3)
 
     # ---- untimed: per-stack latency as SURVEY.md 8(d) defines it (first host call -> device idle), median of 20
-    lat = []
+    lat, lat_render = [], []
     for i in range(20):
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
@@ -222,6 +220,13 @@ def main():
             ring.drain()
         torch.cuda.synchronize(dev)
         lat.append(time.perf_counter() - t1)
+    for i in range(20 if ring is None else 0):   # the same with the seed outside the window (torch.manual_seed walks the device generators too)
+        torch.cuda.synchronize(dev)
+        torch.manual_seed(i)
+        t1 = time.perf_counter()
+        pipe.render(lens, img, dbar, fds, inputs_ready=True)
+        torch.cuda.synchronize(dev)
+        lat_render.append(time.perf_counter() - t1)
     # ---- untimed SOLO leg: the same stacks on ONE stream, queued back to back (the device stays busy and clocked up, and the
     # stream order keeps every kernel alone on the device - the condition rocprofv3 of `bench.py --streams 1` sees); on every
     # 4th stack the PSF-grid and the convolution kernel carry a HIP event pair on their own dispatch, and two stream events
@@ -272,6 +277,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "latency_ms_p50": round(float(np.median(lat)) * 1e3, 4),
+            "latency_ms_p50_render_call_only": round(float(np.median(lat_render)) * 1e3, 4) if lat_render else None,
             "streams": n_streams,
             "config": {"workload": "rf50mm, 1024x1024 synthetic RGB + depth plane, 10 focus distances, 11x11 PSF grid, "
                                    "ks 11, spp 2048 (+2048 chief), mode M1 (refocus -> psf_map -> render_psf_map)",

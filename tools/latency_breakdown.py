@@ -46,7 +46,7 @@ def main():
     sampling.HostSampler.rand_into = wrap("draws (MT19937 -> pinned block)", sampling.HostSampler.rand_into)
     plan.staged = wrap("guard event / flag mirror", plan.staged)
     for i in range(30):
-        torch.default_generator.manual_seed(i)
+        torch.manual_seed(i)
         fs.render_focal_stack_m1(lens, img, dbar, fds, plan=plan, update_lens=False)
     torch.cuda.synchronize()
     seg.clear()
@@ -54,7 +54,7 @@ def main():
     for i in range(a.n):
         torch.cuda.synchronize()
         t0 = now()
-        torch.default_generator.manual_seed(i)
+        torch.manual_seed(i)
         t1 = now()
         fs.render_focal_stack_m1(lens, img, dbar, fds, plan=plan, update_lens=False)
         t2 = now()
@@ -63,7 +63,7 @@ def main():
         tot.append(t3 - t0); seed.append(t1 - t0); body.append(t2 - t1); sync.append(t3 - t2)
     med = lambda v: float(np.median(v)) * 1e6
     print(f"latency (seed + host call + wait for the device), median of {a.n}: {med(tot):7.1f} us")
-    print(f"  default_generator.manual_seed                            {med(seed):7.1f} us")
+    print(f"  torch.manual_seed                                        {med(seed):7.1f} us")
     print(f"  render_focal_stack_m1 (host, returns after enqueue) {med(body):7.1f} us")
     for k, v in seg.items():
         per = len(v) / a.n
