@@ -1,11 +1,11 @@
-"""One process per GPU: shard (scene, slice) units across ranks and, when a single consumer needs
-the whole result, reassemble it with ONE all-gather (RCCL over xGMI on the GPU box, gloo in the CPU
-tests and in the one-GPU rank emulation).  The path has no other exchange step: units are
+"""One process per GPU: shard (scene, slice) units across ranks (blocks of consecutive units dealt round-robin) and,
+when a single consumer needs the whole result, reassemble it with one in-place all-gather per buffer row (RCCL over
+xGMI on the GPU box, gloo in the CPU tests and in the one-GPU rank emulation).  The path has no other exchange step: units are
 independent.
 
 Launching: `spawn_ranks` starts N copies of a script BEFORE anything has touched the GPU (the parent
 never makes a HIP call; a child owns its device).  `--emulate-ranks` puts all N ranks on GPU 0 with
-the gloo backend, because RCCL refuses two ranks on one device: the launcher, the `u = r (mod N)`
+the gloo backend, because RCCL refuses two ranks on one device: the launcher, the
 sharding and the gather order are then exercised on a one-GPU box; xGMI is not.
 """
 import os

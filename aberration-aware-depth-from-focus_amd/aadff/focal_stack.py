@@ -540,7 +540,7 @@ class PresetSampler:
 
 class SceneUnitRenderer:
     """M1 rendering of (scene, slice) units for the sharded configuration (BASELINE.json config 3: 16 scenes x 10
-    slices over 8 GPUs, rank r owns units u = scene*S + slice with u = r (mod world)).
+    slices over 8 GPUs, units u = scene*S + slice dealt to the ranks by aadff.dist.shard_units).
 
     A unit's pixels must not depend on which rank renders it or on what else that rank renders, so every rank
     draws the uniforms of the WHOLE stack of a scene in the reference's order (`seed_scene(scene)` then one flat

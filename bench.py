@@ -105,7 +105,7 @@ def main():
                     help="m1 (default, BASELINE.json metric): ray-traced PSF grid + patch convolution; "
                          "m2: RGB-D stack through the PSF surrogate network (PSFNet.render, SURVEY.md 8f-1); "
                          "fit: 1_fit_psfnet.py training iterations (ray-traced targets + MLP step, BASELINE config 3); "
-                         "c3: 16 scenes x 10 slices sharded u = r (mod N) with one all-gather (BASELINE config 3, strong scaling)")
+                         "c3: 16 scenes x 10 slices sharded in whole-scene blocks, all-gathered row by row (BASELINE config 3, strong scaling)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
