@@ -686,7 +686,7 @@ def render_scenes_sharded(renderer, gather=True, stream=None, block=None):
 
     def after_group(dst):
         here = torch.cuda.current_stream(dev)           # the stream the group's launches were queued on
-        if side is not here:
+        if side != here:
             ev = torch.cuda.Event()
             ev.record(here)
             side.wait_event(ev)

@@ -1,13 +1,12 @@
 """dff/factory.py of the reference: build the train / test lens from the YAML dict (dff/factory.py:4-31) and pick a dataset
 (:33-55).  `get_lens` is the reference's logic on this package's PSFNet / ThinLens.  `get_dataset` keeps the reference's
-names and YAML keys for the file sets dff/dataset.py can read with PIL (Matterport3D, Middlebury2014 / 2021), adds the
-seeded synthetic RGB-D set the benchmarks use ('Synthetic'), and names what is missing otherwise (FlyingThings3D needs
-OpenEXR, RealWorld camera metadata)."""
+names and YAML keys (Matterport3D / FlyingThings3D for training, Middlebury2014 / 2021 / RealWorld for testing; files are read
+with PIL and dff/exr.py) and adds the seeded synthetic RGB-D set the benchmarks use ('Synthetic')."""
 import torch
 
 from deeplens.psfnet import PSFNet, ThinLens
 from aadff.synth import synth_depth_mm, synth_rgb
-from .dataset import Matterport3D, Middlebury
+from .dataset import FlyingThings3D, Matterport3D, Middlebury, RealWorld
 
 
 def _lens(spec, ks, sensor_res, device):
@@ -47,15 +46,19 @@ def get_dataset(args):
     name = args["train"]["dataset"]
     if name == "Matterport3D":
         train_set = Matterport3D(args["train_aif_dir"], args["train_depth_dir"], resize=args["res"])
+    elif name == "FlyingThings3D":
+        train_set = FlyingThings3D(args["FlyingThings3D_train"], resize=args["res"])
     elif name == "Synthetic":
         train_set = SyntheticRGBD(args["train"].get("n", 64), args["res"], seed=1000)
     else:
-        raise NotImplementedError(f"train dataset '{name}': only 'Matterport3D' and 'Synthetic' are provided (FlyingThings3D reads OpenEXR)")
+        raise NotImplementedError(f"train dataset '{name}': 'Matterport3D', 'FlyingThings3D' and 'Synthetic' are provided")
     name = args["test"]["dataset"]
     if name in ("Middlebury2014", "Middlebury2021"):
         test_set = Middlebury(args[f"{name}_val"], resize=args["res"], train=False)
+    elif name == "RealWorld":
+        test_set = RealWorld(args["RealWorld_val"], resize=args["res"], depth=False)
     elif name == "Synthetic":
         test_set = SyntheticRGBD(args["test"].get("n", 64), args["res"], seed=2000)
     else:
-        raise NotImplementedError(f"test dataset '{name}': only 'Middlebury2014', 'Middlebury2021' and 'Synthetic' are provided")
+        raise NotImplementedError(f"test dataset '{name}': 'Middlebury2014', 'Middlebury2021', 'RealWorld' and 'Synthetic' are provided")
     return train_set, test_set

@@ -283,8 +283,8 @@ def test_dff_factory_shims(repo_root):
     args = {"ks": 11, "res": (32, 48), "device": torch.device("cpu"), "train": thin, "test": dict(thin, dataset="Middlebury2014")}
     a, b = get_lens(args)
     assert isinstance(a, ThinLens) and isinstance(b, ThinLens) and a.ps == 24.0 / 32 and a.kernel_size == 11
-    args["test"]["dataset"] = "RealWorld"
-    with pytest.raises(NotImplementedError, match="RealWorld"):
+    args["test"]["dataset"] = "NoSuchSet"
+    with pytest.raises(NotImplementedError, match="NoSuchSet"):
         get_dataset(args)
     args["test"]["dataset"] = "Synthetic"
     tr, te = get_dataset(args)
@@ -365,3 +365,143 @@ def test_per_surface_newton_step_tolerance_and_flag_bits(repo_root):
         raise_psf_flags(1 | 4)
     with pytest.warns(RuntimeWarning):
         raise_psf_flags(8)
+
+
+def _write_exr(path, planes, compression, lines):
+    """Scan-line OpenEXR writer for the tests (OpenEXR file layout: magic, version 2, attributes, offset table, chunks of
+    `lines` rows stored channel by channel; ZIP/ZIPS/RLE chunks byte-split and delta-predicted like ImfZip.cpp)."""
+    import struct
+    import zlib
+    names = sorted(planes)
+    H, W = planes[names[0]].shape
+    ptype = {np.dtype("uint32"): 0, np.dtype("float16"): 1, np.dtype("float32"): 2}
+
+    def attr(name, typ, payload):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(payload)) + payload
+
+    chl = b"".join(n.encode() + b"\0" + struct.pack("<iB3xii", ptype[planes[n].dtype], 0, 1, 1) for n in names) + b"\0"
+    box = struct.pack("<4i", 0, 0, W - 1, H - 1)
+    head = struct.pack("<ii", 20000630, 2) + attr("channels", "chlist", chl) + attr("compression", "compression", bytes([compression])) \
+        + attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") \
+        + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) \
+        + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+
+    def rle(b):
+        out, i = bytearray(), 0
+        while i < len(b):
+            j = i
+            while j + 1 < len(b) and b[j + 1] == b[i] and j - i < 126:
+                j += 1
+            if j > i + 1:
+                out += struct.pack("b", j - i) + b[i:i + 1]
+                i = j + 1
+            else:
+                k = i
+                while k < len(b) and k - i < 127 and not (k + 2 < len(b) and b[k] == b[k + 1] == b[k + 2]):
+                    k += 1
+                out += struct.pack("b", -(k - i)) + b[i:k]
+                i = k
+        return bytes(out)
+
+    chunks = []
+    for y0 in range(0, H, lines):
+        raw = b"".join(planes[n][y].astype(planes[n].dtype.newbyteorder("<")).tobytes() for y in range(y0, min(H, y0 + lines)) for n in names)
+        data = raw
+        if compression in (1, 2, 3):
+            t = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([t[0::2], t[1::2]]).astype(np.int64)
+            t[1:] = (t[1:] - t[:-1] + 128) & 0xFF
+            enc = t.astype(np.uint8).tobytes()
+            data = zlib.compress(enc) if compression in (2, 3) else rle(enc)
+            if len(data) >= len(raw):
+                data = raw
+        chunks.append((y0, data))
+    table_at = len(head)
+    pos = table_at + 8 * len(chunks)
+    offs = []
+    for _, data in chunks:
+        offs.append(pos)
+        pos += 8 + len(data)
+    with open(path, "wb") as f:
+        f.write(head + struct.pack(f"<{len(offs)}Q", *offs) + b"".join(struct.pack("<ii", y, len(d)) + d for y, d in chunks))
+
+
+def test_exr_reader_and_flyingthings_realworld_loaders(tmp_path):
+    """dff/exr.py (scan-line OpenEXR: NONE / RLE / ZIPS / ZIP, HALF / FLOAT / UINT) on files written here, then the two
+    remaining dataset classes of the reference (dff/dataset.py:55-110 FlyingThings3D, :207-246 RealWorld) on top of it and
+    through dff.factory.get_dataset with the reference's YAML keys."""
+    import random
+    from PIL import Image
+    from dff.dataset import FlyingThings3D, RealWorld
+    from dff.exr import read_exr
+    from dff.factory import get_dataset
+    rng = np.random.Generator(np.random.PCG64(9))
+    H, W = 37, 50                                   # 37 rows: a ragged last ZIP chunk (16 rows per chunk)
+    disp = (rng.random((H, W), dtype=np.float32) * 30 + 5).astype(np.float32)
+    smooth = np.repeat(np.repeat(rng.random((5, 5), dtype=np.float32), 10, 1), 8, 0)[:H, :W].copy()   # runs: RLE / ZIP really compress
+    for comp, lines in ((0, 1), (1, 1), (2, 1), (3, 16)):
+        for arr in (disp, smooth):
+            p = tmp_path / f"c{comp}.exr"
+            _write_exr(p, {"Y": arr}, comp, lines)
+            assert np.array_equal(read_exr(p), arr), comp
+    rgbh = {"R": disp.astype(np.float16), "G": (disp * 2).astype(np.float16), "B": smooth.astype(np.float16), "A": np.ones((H, W), np.float16)}
+    _write_exr(tmp_path / "rgba.exr", rgbh, 3, 16)
+    got = read_exr(tmp_path / "rgba.exr")
+    assert got.shape == (H, W, 4) and got.dtype == np.float32                                        # OpenCV order: B G R A
+    assert np.array_equal(got[..., 0], rgbh["B"].astype(np.float32)) and np.array_equal(got[..., 2], rgbh["R"].astype(np.float32))
+    _write_exr(tmp_path / "zu.exr", {"Z": disp, "id": rng.integers(0, 1 << 30, (H, W)).astype(np.uint32)}, 2, 1)
+    assert read_exr(tmp_path / "zu.exr").shape == (H, W, 2)
+    bad = bytearray((tmp_path / "c3.exr").read_bytes())
+    bad[bad.index(b"compression\0compression\0") + 28] = 4                                          # PIZ
+    (tmp_path / "piz.exr").write_bytes(bytes(bad))
+    with pytest.raises(NotImplementedError, match="PIZ"):
+        read_exr(tmp_path / "piz.exr")
+    with pytest.raises(ValueError, match="not an OpenEXR"):
+        (tmp_path / "x.exr").write_bytes(b"12345678")
+        read_exr(tmp_path / "x.exr")
+
+    ft = tmp_path / "ft"
+    imgs = {}
+    for scene in ("a", "b"):
+        (ft / scene).mkdir(parents=True)
+        _write_exr(ft / scene / "disp.exr", {"Y": disp}, 3, 16)
+        for name in ("10.5", "20", "40", "AiF"):
+            imgs[scene, name] = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+            Image.fromarray(imgs[scene, name]).save(ft / scene / f"{name}.png")
+    ds = FlyingThings3D(str(ft), resize=(H, W), train=False)
+    aif, depth = ds[0]
+    assert len(ds) == 2 and aif.shape == (3, H, W) and depth.shape == (1, H, W)
+    assert torch.equal(aif, torch.from_numpy((imgs[ds.scenes[0], "AiF"] / 255.0).astype("float32")).permute(2, 0, 1))     # RGB
+    assert torch.equal(depth[0], torch.from_numpy(disp / 20))
+    random.seed(1)
+    stack, depth2, dists = FlyingThings3D(str(ft), resize=(20, 30), train=False, fs_num=2)[1]
+    random.seed(1)
+    picked = random.sample(["10.5", "20", "40"], 2)
+    assert stack.shape == (2, 3, 20, 30) and depth2.shape == (1, 20, 30) and dists.tolist() == [float(n) / 20 for n in picked]
+    want0 = torch.nn.functional.interpolate(torch.from_numpy(imgs[ds.scenes[1], picked[0]][..., ::-1].astype(np.float32) / np.float32(255)).permute(2, 0, 1)[None],
+                                            size=(20, 30), mode="bilinear", align_corners=False)[0]
+    assert torch.equal(stack[0], want0)                                                               # B G R, plain bilinear
+    np.random.seed(3)
+    random.seed(2)
+    s3, d3, f3 = FlyingThings3D(str(ft), resize=(20, 30), train=True, fs_num=3)[0]                    # augmentation on a stack
+    assert s3.shape == (3, 3, 20, 30) and d3.shape == (1, 20, 30) and len(f3) == 3
+
+    rw = tmp_path / "rw" / "scene0"
+    (rw / "align").mkdir(parents=True)
+    (rw / "depth").mkdir()
+    shots = {}
+    for i, mm in enumerate((600, 1200, 2500)):
+        shots[mm] = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        Image.fromarray(shots[mm]).save(rw / "align" / f"{i:02d}_dist{mm}_f2.png")
+    d16 = rng.integers(0, 65536, (H, W)).astype(np.uint16)
+    Image.fromarray(d16).save(rw / "depth" / "depth.png")
+    stack, depth, dists = RealWorld(str(tmp_path / "rw"), resize=(H, W), depth=True)[0]
+    assert stack.shape == (3, 3, H, W) and dists.tolist() == [0.6, 1.2, 2.5]
+    assert torch.equal(stack[1], torch.from_numpy(shots[1200][..., ::-1].astype(np.float32) / np.float32(255)).permute(2, 0, 1))
+    assert torch.equal(depth[0], torch.from_numpy(((d16 / 65535 * 3000 + 500) / 1000).astype("float32")))
+    assert float(RealWorld(str(tmp_path / "rw"), resize=(H, W))[0][1].abs().max()) == 0.0            # depth=False: zeros
+    args = {"res": (20, 30), "train": {"dataset": "FlyingThings3D"}, "test": {"dataset": "RealWorld"}, "FlyingThings3D_train": str(ft),
+            "RealWorld_val": str(tmp_path / "rw")}
+    np.random.seed(0)
+    tr, te = get_dataset(args)
+    assert len(tr) == 2 and tr[0][0].shape == (3, 20, 30) and tr[0][1].shape == (1, 20, 30) and te[0][0].shape == (3, 3, 20, 30)
