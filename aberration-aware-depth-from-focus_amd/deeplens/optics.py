@@ -82,7 +82,7 @@ class Lensgroup(DeepObj):
             self.load_file(filename, use_roc, sensor_res, post_computation)
 
     # ------------------------------------------------------------------ loading
-    def load_file(self, filename, use_roc=False, sensor_res=(1024, 1024), post_computation=True):
+    def load_file(self, filename, use_roc, sensor_res, post_computation=True):
         if filename[-5:] == ".json":
             self.read_lens_json(filename)
         else:
@@ -537,10 +537,13 @@ class Lensgroup(DeepObj):
     # ------------------------------------------------------------------ image rendering / misc
     @torch.no_grad()
     def render_single_img(self, img_org, depth=DEPTH, spp=64, unwarp=False, save_name=None, return_tensor=False,
-                          noise=0, method="psf"):
-        """`method='psf'` branch of the reference (optics.py:779-783): 7x7 PSF grid, ks 21."""
+                          noise=0, method="raytracing"):
+        """Reference signature (optics.py:722).  `method='psf'` is the branch on the focal-stack hot path (:779-783: 7x7 PSF
+        grid, ks 21); the default 'raytracing' branch calls `calc_scale_ray`, `render_sample_ray` and `render_compute_image`,
+        which the reference snapshot does not define (AttributeError there) - refused here with the way out named."""
         if method != "psf":
-            raise NotImplementedError("only method='psf' is on the focal-stack hot path")
+            raise NotImplementedError(f"render_single_img(method='{method}'): only method='psf' exists (the reference's 'raytracing' "
+                                      "branch calls methods its snapshot lacks); pass method='psf'")
         if not isinstance(img_org, np.ndarray):
             raise Exception("This function only supports ndarray input. If you want to render an image batch, use `render` function.")
         H, W, Cn = img_org.shape

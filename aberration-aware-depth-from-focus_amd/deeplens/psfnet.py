@@ -444,6 +444,60 @@ class PSFNet(Lensgroup):
             plan.check_flags()
         torch.save(psfnet.state_dict(), f"{result_dir}/PSFNet_{self.model_name}.pkl")
 
+    def _grid_points(self, psf_grid):
+        """Centres of a psf_grid[0] x psf_grid[1] tiling of the normalised field, row-major from the top left
+        (reference: psfnet.py:227-233, 320-325)."""
+        x, y = torch.meshgrid(torch.linspace(-1 + 1 / (2 * psf_grid[1]), 1 - 1 / (2 * psf_grid[1]), psf_grid[1]),
+                              torch.linspace(1 - 1 / (2 * psf_grid[0]), -1 + 1 / (2 * psf_grid[0]), psf_grid[0]), indexing="xy")
+        return x.reshape(-1), y.reshape(-1)
+
+    @torch.no_grad()
+    def calc_psf_map(self, foc_dist, depth, psf_grid=(11, 11)):
+        """Ray-traced PSF grid [3, psf_grid[0]*ks, psf_grid[1]*ks] (green PSF tiled, repeated over the channels by make_grid)
+        of the lens focused to `foc_dist` for points at `depth` (reference: psfnet.py:215-243; its `self.psf(...,
+        kernel_size=ks)` call names a keyword Lensgroup.psf does not have - `ks` is meant)."""
+        self.refocus(depth=foc_dist)
+        x, y = self._grid_points(psf_grid)
+        o = torch.stack((x, y, torch.full_like(x, depth)), dim=-1)
+        psf = self.psf(points=o, ks=self.kernel_size, spp=self.spp, center=True)            # [psf_grid^2, ks, ks]
+        return make_grid(psf.unsqueeze(1), nrow=psf_grid[1], padding=0)
+
+    @torch.no_grad()
+    def evaluate_psf_score(self, vis=False, evaluate_model=None, result_dir="./"):
+        """Mean L1 / L2 distance between ray-traced and predicted PSFs over every focus distance of `foc_z_arr`, 40 depths
+        and the `psf_grid` field points (reference: psfnet.py:305-366, with its `self.psf(o=..., kernel_size=...)` call
+        spelled as Lensgroup.psf takes it).  Prints the reference's line and also returns (avg_l1, avg_l2)."""
+        psf_grid, ks, spp = self.psf_grid, self.kernel_size, self.spp
+        psfnet = self.psfnet
+        psfnet.eval()
+        evaluate_model = getattr(self, "evaluate_model", "mlp") if evaluate_model is None else evaluate_model
+        if evaluate_model != "mlp":
+            raise Exception("Unimplemented")
+        dev = next(psfnet.parameters()).device
+        x, y = self._grid_points(psf_grid)
+        l1_error, l2_error = [], []
+        for foc_z in tqdm(self.foc_z_arr):
+            foc_dist = foc_z * (self.d_max - self.d_min) + self.d_min
+            self.refocus(depth=foc_dist)
+            for z in np.linspace(0, 1, 40, endpoint=True):
+                depth = z * (self.d_max - self.d_min) + self.d_min
+                o = torch.stack((x, y, torch.full_like(x, depth)), dim=-1)
+                psf_gt = self.psf(points=o, ks=ks, spp=spp, center=True).to(dev)             # [psf_grid^2, ks, ks]
+                inp = torch.stack((x, y, torch.full_like(x, z), torch.full_like(x, foc_z)), dim=-1).to(dev)
+                psf_pred = psfnet(inp).view(-1, ks, ks)
+                l2_error.append(torch.sum((psf_gt - psf_pred) ** 2) / psf_gt.numel())
+                l1_error.append(torch.sum((psf_gt - psf_pred).abs()) / psf_gt.numel())
+                if vis:
+                    gt_map = make_grid(psf_gt.unsqueeze(1), nrow=psf_grid[1], padding=0)
+                    pred_map = make_grid(psf_pred.unsqueeze(1), nrow=psf_grid[1], padding=0)
+                    scale = 1 / max(gt_map.max(), pred_map.max())
+                    save_image(gt_map * scale, f"{result_dir}/psf_foc{-foc_dist}_depth{-depth}_gt.png")
+                    save_image(pred_map * scale, f"{result_dir}/psf_foc{-foc_dist}_depth{-depth}_pred.png")
+        avg_l2_error = sum(l2_error) / len(l2_error)
+        avg_l1_error = sum(l1_error) / len(l1_error)
+        print(f"avg l1 error: {avg_l1_error}, avg l2 error: {avg_l2_error}.")
+        return float(avg_l1_error), float(avg_l2_error)
+
     @torch.no_grad()
     def evaluate_psf(self, result_dir="./"):
         """Ray-traced vs predicted PSFs at three field points, focus 1.5 m, depths

@@ -1031,6 +1031,19 @@ def test_train_psfnet_runs_and_checkpoints(repo_root, tmp_path):
     net.train_psfnet(iters=1, bs=16, lr=1e-4, spp=256, evaluate_every=1, result_dir=str(tmp_path))
     assert (tmp_path / "PSFNet_mlp.pkl").exists() and (tmp_path / "iter1.png").exists()
     net.evaluate_psf(result_dir=str(tmp_path))
+    # calc_psf_map / evaluate_psf_score (psfnet.py:215-243, 305-366; both call Lensgroup.psf with a keyword it lacks in the
+    # reference snapshot - built as they are meant): the ray-traced grid equals psf() on the same points and seed
+    torch.manual_seed(3)
+    pm = net.calc_psf_map(-1500.0, -1200.0, psf_grid=(3, 4))
+    assert pm.shape == (3, 3 * 11, 4 * 11) and torch.equal(pm[0], pm[2])
+    torch.manual_seed(3)
+    net.refocus(depth=-1500.0)
+    xs, ys = net._grid_points((3, 4))
+    want = net.psf(points=torch.stack((xs, ys, torch.full_like(xs, -1200.0)), -1), ks=11, spp=net.spp, center=True)
+    assert torch.equal(pm[0, 11:22, 22:33].cpu(), want[1 * 4 + 2].cpu()) and float(xs[0]) == pytest.approx(-0.75) and float(ys[0]) == pytest.approx(2 / 3)
+    net.foc_z_arr, net.psf_grid, net.spp = net.foc_z_arr[:2], [2, 3], 256
+    l1, l2 = net.evaluate_psf_score(vis=True, result_dir=str(tmp_path))
+    assert 0 < l2 < l1 < 0.05 and len([f for f in os.listdir(tmp_path) if f.endswith("_gt.png")]) == 2 * 40
     sd = torch.load(tmp_path / "PSFNet_mlp.pkl", map_location="cpu")
     assert sorted(sd)[:2] == ["net.0.bias", "net.0.weight"] and sd["net.20.weight"].shape == (121, 256)
     net2 = PSFNet(str(tmp_path / "lens.json"), sensor_res=(480, 640), kernel_size=11, device=DEV)

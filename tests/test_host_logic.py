@@ -505,3 +505,82 @@ def test_exr_reader_and_flyingthings_realworld_loaders(tmp_path):
     np.random.seed(0)
     tr, te = get_dataset(args)
     assert len(tr) == 2 and tr[0][0].shape == (3, 20, 30) and tr[0][1].shape == (1, 20, 30) and te[0][0].shape == (3, 3, 20, 30)
+
+
+def test_public_signatures_match_the_reference(golden_dir):
+    """Fixture G16 (tests/golden/make_signatures.py: names and defaults of the reference's functions and methods, read from
+    its source by ast): every one this package also defines takes the reference's parameters in the reference's order with
+    the reference's defaults; extra parameters are allowed only AFTER them and only with defaults (opt-in switches)."""
+    import ast
+    import importlib
+    import inspect
+    import json
+    ref = json.load(open(os.path.join(golden_dir, "g16_signatures.json")))
+
+    def norm(src):
+        try:
+            v = ast.literal_eval(src)
+            return round(v, 12) if isinstance(v, float) else (list(v) if isinstance(v, tuple) else v)
+        except Exception:
+            return src                                            # a name (DEPTH, GEO_SPP, DEFAULT_WAVE ...): compared as text
+
+    consts = {}
+    import deeplens.basics as basics
+    for k in dir(basics):
+        if k.isupper():
+            consts[k] = getattr(basics, k)
+    checked, extras, missing, bad = 0, [], [], []
+
+    def check(cond, msg):
+        if not cond:
+            bad.append(msg)
+        return cond
+
+    for modname, entries in ref.items():
+        mod = importlib.import_module(modname)
+        for qual, want in entries.items():
+            obj = mod
+            for part in qual.split("."):
+                obj = getattr(obj, part, None)
+                if obj is None:
+                    break
+            if obj is None or not callable(obj):
+                missing.append(f"{modname}.{qual}")
+                continue
+            try:
+                got = list(inspect.signature(obj).parameters.values())
+            except (TypeError, ValueError):
+                continue
+            if "." in qual and not isinstance(inspect.getattr_static(getattr(mod, qual.split(".")[0]), qual.split(".")[1]), (staticmethod,)) \
+                    and got and got[0].name != "self" and want and want[0][0] == "self":
+                want = want[1:]                                   # bound through the class: inspect drops nothing, but be lenient
+            names = [p.name if p.kind not in (p.VAR_POSITIONAL, p.VAR_KEYWORD) else ("*" if p.kind == p.VAR_POSITIONAL else "**") + p.name for p in got]
+            wn = [w[0] for w in want]
+            if not check(names[:len(wn)] == wn, f"{modname}.{qual}: parameters {names} do not start with the reference's {wn}"):
+                continue
+            for p, (_, dflt) in zip(got, want):
+                if dflt is None:
+                    check(p.default is inspect.Parameter.empty or p.kind in (p.VAR_POSITIONAL, p.VAR_KEYWORD), f"{modname}.{qual}: '{p.name}' has a default the reference lacks")
+                    continue
+                if not check(p.default is not inspect.Parameter.empty, f"{modname}.{qual}: '{p.name}' lost its default {dflt}"):
+                    continue
+                d = norm(dflt)
+                if isinstance(d, str) and d in consts:
+                    d = consts[d]
+                mine = p.default
+                mine = list(mine) if isinstance(mine, tuple) else (round(mine, 12) if isinstance(mine, float) else mine)
+                if isinstance(d, str) and not isinstance(mine, str):
+                    continue                                      # an expression (e.g. torch.device('cpu')): not comparable as data
+                check(mine == d, f"{modname}.{qual}: default of '{p.name}' is {mine!r}, the reference has {dflt}")
+            for p in got[len(wn):]:
+                check(p.default is not inspect.Parameter.empty or p.kind in (p.VAR_POSITIONAL, p.VAR_KEYWORD), f"{modname}.{qual}: extra parameter '{p.name}' without a default")
+                extras.append(f"{modname}.{qual}:{p.name}")
+            checked += 1
+    print(f"\n{checked} signatures equal to the reference's; opt-in extras: {extras}; not defined here: {len(missing)}")
+    assert not bad, "\n".join(bad)
+    assert checked >= 80
+    hot = ["deeplens.optics.Lensgroup.psf", "deeplens.optics.Lensgroup.psf_map", "deeplens.optics.Lensgroup.refocus", "deeplens.optics.Lensgroup.trace",
+           "deeplens.optics.Lensgroup.render_single_img", "deeplens.optics.Lensgroup.analysis", "deeplens.psfnet.PSFNet.render",
+           "deeplens.psfnet.PSFNet.calc_psf_map", "deeplens.psfnet.PSFNet.evaluate_psf_score", "deeplens.psfnet.PSFNet.train_psfnet",
+           "deeplens.render_psf.render_psf_map", "deeplens.render_psf.local_psf_render", "dff.utils.select_focus_dist", "dff.factory.get_dataset"]
+    assert not [h for h in hot if h in missing], [h for h in hot if h in missing]
