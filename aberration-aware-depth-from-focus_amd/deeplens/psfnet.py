@@ -463,6 +463,51 @@ class PSFNet(Lensgroup):
         return make_grid(psf.unsqueeze(1), nrow=psf_grid[1], padding=0)
 
     @torch.no_grad()
+    def get_training_psf_map(self, bs=8, psf_grid=(11, 11), psf_map_size=(128, 128)):
+        """`bs` ray-traced PSF maps at one random focus distance and random depths around it, resized to `psf_map_size`:
+        (inp [B,2] = (z, foc_z), psf_map_batch [B,3,*psf_map_size]) - the training data of the reference's PSF-map
+        architectures (psfnet.py:172-211; RNG order: np.random.choice, torch.randn, then per map the refocus and PSF draws).
+        torchvision's `F.resize` on a tensor is antialiased bilinear interpolation."""
+        foc_z = np.random.choice(self.foc_z_arr)
+        foc_dist = foc_z * (self.d_max - self.d_min) + self.d_min
+        z_gauss = torch.clamp(torch.randn(bs), min=-3, max=3)
+        z = torch.zeros_like(z_gauss)
+        z[z_gauss > 0] = (1 - foc_z) * z_gauss[z_gauss > 0] / 3 + foc_z
+        z[z_gauss < 0] = foc_z * z_gauss[z_gauss < 0] / 3 + foc_z
+        depth = self.z2depth(z)
+        inp = torch.stack((z, torch.full_like(z, foc_z)), dim=-1)
+        maps = torch.stack([self.calc_psf_map(foc_dist, float(d), psf_grid=psf_grid) for d in depth], dim=0)
+        maps = torch.nn.functional.interpolate(maps, size=tuple(psf_map_size), mode="bilinear", align_corners=False, antialias=True)
+        return inp, maps
+
+    def vis_psf_map(self, psf, filename=None):
+        """Picture of a [N,N,k,k] / [N,N,k^2] / [N,k,k] PSF set (reference: psfnet.py:456-486)."""
+        import matplotlib
+        matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+        if len(psf.shape) == 3 and psf.shape[0] == psf.shape[1] and int(round(psf.shape[2] ** 0.5)) ** 2 == psf.shape[2] and psf.shape[1] != psf.shape[2]:
+            k = int(round(psf.shape[2] ** 0.5))
+            psf = psf.reshape(psf.shape[0], psf.shape[1], k, k)
+        if len(psf.shape) == 4:
+            n = psf.shape[0]
+            fig, axs = plt.subplots(n, n, squeeze=False)
+            for i in range(n):
+                for j in range(n):
+                    axs[i, j].imshow(psf[i, j].detach().clone().cpu(), vmin=0.0, vmax=0.1)
+        elif len(psf.shape) == 3:
+            n = psf.shape[0]
+            fig, axs = plt.subplots(1, n, squeeze=False)
+            for i in range(n):
+                axs[0, i].imshow(psf[i].detach().clone().cpu(), vmin=0.0, vmax=0.1)
+        else:
+            raise ValueError("vis_psf_map: PSF of shape [N,N,k,k], [N,N,k^2] or [N,k,k] expected")
+        if filename is None:
+            plt.show()
+        else:
+            fig.savefig(filename, bbox_inches="tight")
+        plt.close(fig)
+
+    @torch.no_grad()
     def evaluate_psf_score(self, vis=False, evaluate_model=None, result_dir="./"):
         """Mean L1 / L2 distance between ray-traced and predicted PSFs over every focus distance of `foc_z_arr`, 40 depths
         and the `psf_grid` field points (reference: psfnet.py:305-366, with its `self.psf(o=..., kernel_size=...)` call

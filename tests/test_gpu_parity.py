@@ -1043,6 +1043,12 @@ def test_train_psfnet_runs_and_checkpoints(repo_root, tmp_path):
     assert torch.allclose(pm[0, 11:22, 22:33].cpu(), want[1 * 4 + 2].cpu(), atol=1e-6)       # float atomics: sum-order noise
     assert float(xs[0]) == pytest.approx(-0.875) and float(ys[0]) == pytest.approx(5 / 6)      # tile centres: 4 columns, 3 rows
     net.foc_z_arr, net.psf_grid, net.spp = net.foc_z_arr[:2], [2, 3], 256
+    np.random.seed(1)
+    torch.manual_seed(1)
+    inp, maps = net.get_training_psf_map(bs=3, psf_grid=(2, 2), psf_map_size=(16, 16))
+    assert inp.shape == (3, 2) and maps.shape == (3, 3, 16, 16) and bool((inp[:, 1] == inp[0, 1]).all()) and float(maps.min()) >= 0
+    net.vis_psf_map(want[:3], filename=str(tmp_path / "vis.png"))
+    assert os.path.getsize(tmp_path / "vis.png") > 1000
     l1, l2 = net.evaluate_psf_score(vis=True, result_dir=str(tmp_path))
     assert 0 < l2 <= l1 < 1 and len([f for f in os.listdir(tmp_path) if f.endswith("_gt.png")]) == 2 * 40       # a 1-iteration net: errors are large, finite
     sd = torch.load(tmp_path / "PSFNet_mlp.pkl", map_location="cpu")
