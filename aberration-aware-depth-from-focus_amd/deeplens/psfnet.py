@@ -493,12 +493,12 @@ class PSFNet(Lensgroup):
             fig, axs = plt.subplots(n, n, squeeze=False)
             for i in range(n):
                 for j in range(n):
-                    axs[i, j].imshow(psf[i, j].detach().clone().cpu(), vmin=0.0, vmax=0.1)
+                    axs[i, j].imshow(psf[i, j].detach().float().cpu().numpy(), vmin=0.0, vmax=0.1)
         elif len(psf.shape) == 3:
             n = psf.shape[0]
             fig, axs = plt.subplots(1, n, squeeze=False)
             for i in range(n):
-                axs[0, i].imshow(psf[i].detach().clone().cpu(), vmin=0.0, vmax=0.1)
+                axs[0, i].imshow(psf[i].detach().float().cpu().numpy(), vmin=0.0, vmax=0.1)
         else:
             raise ValueError("vis_psf_map: PSF of shape [N,N,k,k], [N,N,k^2] or [N,k,k] expected")
         if filename is None:
