@@ -584,3 +584,27 @@ def test_public_signatures_match_the_reference(golden_dir):
            "deeplens.psfnet.PSFNet.calc_psf_map", "deeplens.psfnet.PSFNet.evaluate_psf_score", "deeplens.psfnet.PSFNet.train_psfnet",
            "deeplens.render_psf.render_psf_map", "deeplens.render_psf.local_psf_render", "dff.utils.select_focus_dist", "dff.factory.get_dataset"]
     assert not [h for h in hot if h in missing], [h for h in hot if h in missing]
+
+
+def test_pfm_reader(tmp_path):
+    """pfmreader.read_pfm / read_and_clean_pfm (reference: pfmreader.py:5-50) on files written here: both byte orders, one and
+    three channels, bottom-up rows, inf / NaN cleaned; then 0_warm_up_with_pfm.py's disparity -> depth rule."""
+    from pfmreader import disparity_to_depth_mm, read_and_clean_pfm, read_pfm
+    rng = np.random.Generator(np.random.PCG64(2))
+    a = rng.random((5, 7), dtype=np.float32) * 200
+    a[1, 2], a[3, 3], a[4, 0] = np.inf, np.nan, -np.inf
+    for endian, scale in (("<", b"-1.0"), (">", b"1.0")):
+        p = tmp_path / f"d{scale.decode()}.pfm"
+        p.write_bytes(b"Pf\n7 5\n" + scale + b"\n" + np.flipud(a).astype(endian + "f4").tobytes())
+        got = read_pfm(str(p))
+        assert got.shape == (5, 7) and np.array_equal(got, a, equal_nan=True)
+        clean = read_and_clean_pfm(str(p))
+        assert clean[1, 2] == 0 and clean[3, 3] == 0 and clean[4, 0] == 0 and np.array_equal(clean[0], a[0])
+    c = rng.random((4, 3, 3), dtype=np.float32)
+    (tmp_path / "c.pfm").write_bytes(b"PF\n3 4\n-1.0\n" + np.flipud(c).astype("<f4").tobytes())
+    assert np.array_equal(read_pfm(str(tmp_path / "c.pfm")), c)
+    (tmp_path / "bad.pfm").write_bytes(b"Pf\nseven five\n-1.0\n")
+    with pytest.raises(Exception, match="Malformed PFM header"):
+        read_pfm(str(tmp_path / "bad.pfm"))
+    z = disparity_to_depth_mm(np.float32(100.0), 4161.221, 176.252, 209.059)
+    assert z == pytest.approx(4161.221 * 176.252 / 309.059)
