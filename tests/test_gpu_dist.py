@@ -65,6 +65,25 @@ def test_config3_at_its_real_size_one_rank_and_two_emulated_ranks(tmp_path):
 
 
 @pytest.mark.timeout(900)
+def test_config3_partition_at_eight_emulated_ranks(tmp_path):
+    """Config 3's rank count through the HIP renderer: 16 scenes x 10 slices = 160 units over EIGHT ranks (emulated on the one
+    GPU over gloo, small images), whole-scene blocks (rank r renders scenes r and r + 8) and SURVEY 8e's round robin (every
+    rank owns 1-2 slices of every scene and skips the draws of the rest): in every rank every gathered unit equals the plain
+    per-scene stack."""
+    worker = os.path.join(HERE, "dist_gpu_worker.py")
+    args = [worker, "--out", str(tmp_path), "--scenes", "16", "--res", "64", "--slices", "10", "--grid", "3", "--spp", "256", "--check-inproc"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    for extra in ([], ["--block", "1"]):
+        for f in os.listdir(tmp_path):
+            os.remove(tmp_path / f)
+        assert spawn_ranks(args + extra, 8, emulate=True, env=env, timeout=800) == 0, extra
+        recs = [json.load(open(tmp_path / f"check_w8_r{r}.json")) for r in range(8)]
+        assert all(rec["units"] == 160 and rec["shape"] == [160, 3, 64, 64] and rec["worst_abs_diff"] <= 5e-6 and rec["mean_abs_pixel"] > 0.05 for rec in recs)
+        print(f"\n8 emulated ranks {extra or ['whole-scene blocks']}: worst |gathered - plain| over the ranks = {max(r['worst_abs_diff'] for r in recs):.2e}")
+
+
+@pytest.mark.timeout(900)
 def test_bench_self_launches_two_emulated_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     for extra in ([], ["--gather"]):
