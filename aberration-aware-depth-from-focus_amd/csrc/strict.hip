@@ -244,7 +244,7 @@ extern "C" int aadff_trace_rays_strict(float* o, float* d, float* ra, int n, con
     }
     if (propagate) hipLaunchKernelGGL(strict::propagate_kernel, g, b, 0, st, o, d, n, z_sensor);
     if (flags_or_null) {
-        // NaN in a Newton residual (the reference exits, surfaces.py:555-558): OR the scratch flag into the caller's word
+        // NaN in a Newton residual (the reference exits, surfaces.py:555-558): this call's flag word REPLACES the caller's word
         AADFF_CHECK_HIP(hipMemcpyAsync(flags_or_null, flag, sizeof(int), hipMemcpyDeviceToDevice, st));
     }
     AADFF_CHECK_LAUNCH();
