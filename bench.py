@@ -91,7 +91,9 @@ def main():
                          "exercises launcher, sharding and gather order on a 1-GPU box; not a scaling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--device-rng", action="store_true", help="draw pupil samples on the GPU (not sample-comparable)")
-    ap.add_argument("--spinup-s", type=float, default=0.3, help="untimed device spin-up before the warm-up steps [s]")
+    ap.add_argument("--spinup-s", type=float, default=2.0,
+                    help="untimed device spin-up before the warm-up steps [s]: the FIRST GPU process on a fresh box needs ~2 s of load before its clocks settle "
+                         "(measured: 29.8 k MP/s with 0.3 s against 31.3 k with 3 s, later processes 31.0-31.2 k either way)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("AADFF_BENCH_STREAMS", "2")),
                     help="M1: stacks in flight on this many HIP streams of the one GPU (aadff.focal_stack.StackPipeline).  Default 2: the "
                          "VALU-bound PSF-grid kernel of stack i+1 runs beside the LDS/MFMA/HBM-bound convolution of stack i and fills the "
@@ -181,8 +183,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # device spin-up (untimed, before the warm-up steps): a fresh box needs ~0.2 s under load before the shader
-    # clock settles; a cold first run otherwise reads 10 % low (0.51 vs 0.46 ms/step with identical code)
+    # device spin-up (untimed, before the warm-up steps): the first GPU process on a fresh box needs ~2 s under load before
+    # the clocks settle; a cold first run otherwise reads 4-10 % low with identical code
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < args.spinup_s:
         for i in range(16):
@@ -393,6 +395,10 @@ def main_c3(args):
             torch.cuda.current_stream(dev).wait_event(done)
         return full
 
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup_s:      # clocks of a fresh box (see main); rank-local work only: the
+        render_scenes_sharded(rend, gather=False, block=block)   # ranks may make different numbers of spin-up passes
+        torch.cuda.synchronize(dev)
     for _ in range(warm):
         step()
     torch.cuda.synchronize(dev)
