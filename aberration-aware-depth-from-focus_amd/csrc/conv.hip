@@ -265,6 +265,15 @@ __device__ __forceinline__ void pow2_scale(float amax, float& s, float& inv) {
     inv = ok ? __uint_as_float((unsigned)(127 - 9 + e) << 23) : 1.f;
 }
 
+#ifdef AADFF_SB_TRACE
+// Timeline instrumentation (tools/conv_timeline.py, build libaadff_sbtrace.so): wave 0 of every workgroup stamps the 100 MHz
+// real-time counter at its start, after the band is staged, at the start of the matrix phase and at its end, plus HW_ID.
+__device__ unsigned long long* g_sb_trace = nullptr;
+#define AADFF_SB_STAMP(slot) do { if (g_sb_trace && threadIdx.x == 0) g_sb_trace[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AADFF_SB_STAMP(slot) do {} while (0)
+#endif
+
 template <int KS, int NW, int SPW>
 __global__ __launch_bounds__(64 * NW) void conv_psf_map_mfma_kernel(
     const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
@@ -290,6 +299,20 @@ __global__ __launch_bounds__(64 * NW) void conv_psf_map_mfma_kernel(
     const int x0 = pb.wb[pj] + tx * TW, y0 = pb.hb[pi] + ty * TH;
     if (x0 >= x_hi || y0 >= y_hi) return;
     const int G = grid * KS;
+    AADFF_SB_STAMP(0);
+
+    // this wave's taps: lane i < RP owns padded index i, i.e. tap column v = i - 15, for every tap row u.  The loads of the
+    // wave's FIRST slice are issued here, in front of the image loads, so that they are not a second exposed memory latency
+    // behind the staging (a lone slice is one wave per workgroup: 1.5 of its 13.6 us, tools/conv_single_timeline.py)
+    float wcol[KS];
+    auto load_taps = [&](int s) {
+        const int tv = lane - 15;
+        const bool in = s < S && tv >= 0 && tv < KS;
+        const float* wp = psf + ((size_t)((s < S ? s : 0) * C + c) * G + pi * KS) * G + pj * KS;
+#pragma unroll
+        for (int u = 0; u < KS; ++u) wcol[u] = in ? wp[(size_t)(KS - 1 - u) * G + (KS - 1 - tv)] : 0.f;       // w(u,v) = psf[KS-1-u][KS-1-v]
+    };
+    load_taps(chunk * SPW * NW + wave);
 
     // ---- stage: image window -> registers (column = lane, rows strided over waves), this wave's taps -> LDS ----
     constexpr int NR = (THP + NW - 1) / NW;
@@ -307,6 +330,7 @@ __global__ __launch_bounds__(64 * NW) void conv_psf_map_mfma_kernel(
         }
     }
     amax = wave_max(amax);
+    AADFF_SB_STAMP(1);                                                   // image loads have arrived
     if (lane == 0) red[wave] = amax;
     __syncthreads();
     float tmax = red[0];
@@ -325,6 +349,7 @@ __global__ __launch_bounds__(64 * NW) void conv_psf_map_mfma_kernel(
         }
     }
     __syncthreads();
+    AADFF_SB_STAMP(2);                                                   // tile in LDS
 
     // lane holds B[k = 8(l>>4)+j][n = l&15] = w(u, k-n) = R_u[st + j], st = 8(l>>4) - n + 15
     const int kq = lane >> 4, n = lane & 15;
@@ -345,19 +370,10 @@ __global__ __launch_bounds__(64 * NW) void conv_psf_map_mfma_kernel(
     for (int sp = 0; sp < SPW; ++sp) {
     const int s = (chunk * SPW + sp) * NW + wave;
     if (s >= S) break;
-    // this wave's taps: lane i < RP owns padded index i, i.e. tap column v = i - 15, for every tap row u
-    float wcol[KS];
+    if (sp > 0) load_taps(s);
     float wmax = 0.f;
-    {
-        const int tv = lane - 15;
-        const bool in = s < S && tv >= 0 && tv < KS;
-        const float* wp = psf + ((size_t)((s < S ? s : 0) * C + c) * G + pi * KS) * G + pj * KS;
 #pragma unroll
-        for (int u = 0; u < KS; ++u) {
-            wcol[u] = in ? wp[(size_t)(KS - 1 - u) * G + (KS - 1 - tv)] : 0.f;       // w(u,v) = psf[KS-1-u][KS-1-v]
-            wmax = fmaxf(wmax, fabsf(wcol[u]));
-        }
-    }
+    for (int u = 0; u < KS; ++u) wmax = fmaxf(wmax, fabsf(wcol[u]));
     wmax = wave_max(wmax);
     float sw, isw;
     pow2_scale(wmax, sw, isw);
@@ -373,6 +389,7 @@ __global__ __launch_bounds__(64 * NW) void conv_psf_map_mfma_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    AADFF_SB_STAMP(3);                                                   // tap rows in LDS
 
     const float inv = isx * isw;
     float* oplane = out + (size_t)bc * sbc + (size_t)s * ss;
@@ -399,6 +416,10 @@ __global__ __launch_bounds__(64 * NW) void conv_psf_map_mfma_kernel(
                 acc[by][bx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[by][bx], 0, 0, 0);
             }
     }
+#ifdef AADFF_SB_TRACE
+    asm volatile("s_nop 0" :: "v"(acc[NBY - 1][NBX - 1][0]) : "memory");   // the stamp waits for the last MFMA's result
+    AADFF_SB_STAMP(4);
+#endif
     // C/D layout: column n = l&15, rows 4(l>>4) + r
 #pragma unroll
     for (int by = 0; by < NBY; ++by)
@@ -411,6 +432,10 @@ __global__ __launch_bounds__(64 * NW) void conv_psf_map_mfma_kernel(
                     if (yb + r < y_hi) oplane[(size_t)(yb + r) * W + x] = acc[by][bx][r] * inv;
             }
         }
+#ifdef AADFF_SB_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stores retired
+    AADFF_SB_STAMP(5);
+#endif
     __builtin_amdgcn_wave_barrier();      // the next slice overwrites this wave's tap rows
     }
 }
@@ -488,15 +513,6 @@ __device__ __forceinline__ void lds_share16(const uint2v& a, uint2v& b) {
 #endif
 }
 }  // namespace sb
-
-#ifdef AADFF_SB_TRACE
-// Timeline instrumentation (tools/conv_timeline.py, build libaadff_sbtrace.so): wave 0 of every workgroup stamps the 100 MHz
-// real-time counter at its start, after the band is staged, at the start of the matrix phase and at its end, plus HW_ID.
-__device__ unsigned long long* g_sb_trace = nullptr;
-#define AADFF_SB_STAMP(slot) do { if (g_sb_trace && threadIdx.x == 0) g_sb_trace[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define AADFF_SB_STAMP(slot) do {} while (0)
-#endif
 
 // Workgroup = one band of RB output rows x 96 columns of one patch and channel plane; wave = one chunk of 4 slices
 // (NC waves).  The band is staged once for all slices (HBM reads the image once), every wave builds the T fragments
