@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Whole-stack and per-slice parity of the bench workload (BASELINE.json configs[1]) for SEVERAL generator seeds and
+scenes, not only the seed-0 stack that bench.py and fixture G9 hold: HIP path (fast and parity="strict") against the oracle
+slices computed here on the host cores (about 11 s per stack on the GPU box's 16 cores).
+
+    python tools/parity_seeds.py [--cases 4]          # prints one JSON object
+
+Case k: torch.manual_seed(k), scene = synth_rgb(seed 1234 + k) / synth_depth_mm(seed 5678 + k)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "aberration-aware-depth-from-focus_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=4)
+    ap.add_argument("--no-strict", action="store_true")
+    a = ap.parse_args()
+    import bench
+    from aadff.focal_stack import render_focal_stack_m1
+    from aadff.synth import synth_depth_mm, synth_rgb
+    from deeplens.optics import Lensgroup
+    from oracle import conv as oconv
+    from oracle.lens import OracleLens
+    H = W = 1024
+    S, GRID, KS, SPP = 10, 11, 11, 2048
+    dev = torch.device("cuda", 0)
+    lens_path = os.path.join(REPO, "lenses", "rf50mm", "lens.json")
+    torch.set_num_threads(bench.usable_cpus())
+    fast = Lensgroup(lens_path, sensor_res=(H, W), device=dev)
+    strict = None if a.no_strict else Lensgroup(lens_path, sensor_res=(H, W), device=dev, parity="strict")
+    olens = OracleLens(lens_path, sensor_res=(H, W))
+    rows = []
+    for k in range(a.cases):
+        img_h = torch.from_numpy(synth_rgb(H, W, seed=1234 + k))[None]
+        depth = synth_depth_mm(H, W, seed=5678 + k)
+        dbar, fds = -float(depth.mean()), -np.linspace(depth.min(), depth.max(), S)
+        torch.manual_seed(k)
+        t0 = time.perf_counter()
+        want = []
+        for f in fds:
+            olens.refocus(float(f))
+            want.append(oconv.render_psf_map(img_h, olens.psf_map(depth=dbar, grid=GRID, ks=KS, spp=SPP), GRID)[0].numpy())
+        t_or = time.perf_counter() - t0
+        b = np.stack(want, 1).astype(np.float64)                       # [3,S,H,W]
+        img = img_h.to(dev)
+        rec = {"case": k, "depth_plane_mm": round(dbar, 1), "focus_mm": [round(float(f), 1) for f in fds], "oracle_s": round(t_or, 1)}
+        for name, lens in (("fast", fast), ("strict", strict)):
+            if lens is None:
+                continue
+            torch.manual_seed(k)
+            out = render_focal_stack_m1(lens, img, dbar, fds, GRID, KS, SPP)[0].cpu().numpy().astype(np.float64)
+            per = [float(np.linalg.norm(out[:, s] - b[:, s]) / np.linalg.norm(b[:, s])) for s in range(S)]
+            rec[name] = {"rel_l2": float(f"{np.linalg.norm(out - b) / np.linalg.norm(b):.3e}"), "worst_slice": float(f"{max(per):.3e}"),
+                         "per_slice": [float(f"{v:.2e}") for v in per]}
+        rows.append(rec)
+        print(json.dumps(rec), file=sys.stderr, flush=True)
+    summary = {"cases": a.cases, "tolerance": 1e-4,
+               "fast_rel_l2_max": max(r["fast"]["rel_l2"] for r in rows), "fast_worst_slice_max": max(r["fast"]["worst_slice"] for r in rows)}
+    if strict is not None:
+        summary.update({"strict_rel_l2_max": max(r["strict"]["rel_l2"] for r in rows), "strict_worst_slice_max": max(r["strict"]["worst_slice"] for r in rows)})
+    print(json.dumps({"summary": summary, "rows": rows}))
+
+
+if __name__ == "__main__":
+    main()
