@@ -22,10 +22,26 @@ import torch.nn.functional as F
 from scipy import stats
 from tqdm import tqdm            # noqa: F401
 
+class _LazyPyplot:
+    """`plt` of the star surface (deeplens/optics.py:13 imports matplotlib.pyplot at module level): the name is there, the
+    import - 0.6 s, and a font-cache build of many seconds on a fresh machine - happens at the first attribute access."""
+    _mod = None
+
+    def _load(self):
+        if _LazyPyplot._mod is None:
+            import matplotlib
+            matplotlib.use("Agg", force=False)
+            import matplotlib.pyplot as mod
+            _LazyPyplot._mod = mod
+        return _LazyPyplot._mod
+
+    def __getattr__(self, name):
+        return getattr(self._load(), name)
+
+
 try:                             # plotting is out of scope, the NAME is part of the star surface
-    import matplotlib
-    matplotlib.use("Agg", force=False)
-    import matplotlib.pyplot as plt   # noqa: F401
+    import importlib.util as _ilu
+    plt = _LazyPyplot() if _ilu.find_spec("matplotlib") is not None else None
 except Exception:                # pragma: no cover - matplotlib is present in the image
     plt = None
 
