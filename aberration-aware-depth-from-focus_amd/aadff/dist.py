@@ -76,16 +76,34 @@ def emulated():
     return os.environ.get("AADFF_EMULATE_RANKS", "0") == "1"
 
 
+def forced_group():
+    """AADFF_FORCE_GROUP=1: a process group is formed even for ONE rank, and the sharded renderers / bench take their
+    collective branch through it.  A one-rank RCCL group on a one-GPU box executes everything that only exists under RCCL -
+    `init_process_group("nccl", device_id=...)`, the IN-PLACE row gather whose send buffer aliases the receive buffer,
+    all_reduce on a device tensor, barrier, teardown - so the first real multi-GPU launch cannot fail on something one GPU
+    would have shown (tests/test_gpu_dist.py::test_rccl_branch_on_a_one_rank_group)."""
+    return os.environ.get("AADFF_FORCE_GROUP", "0") == "1"
+
+
+def grouped():
+    """True when collectives are to be issued: more than one rank, or a forced one-rank group."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced_group())
+
+
 def init_from_env(backend=None, device=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
-    Returns (rank, world).  Single-process runs need no group.  Ranks emulated on one GPU use gloo."""
+    Returns (rank, world).  Single-process runs need no group (AADFF_FORCE_GROUP=1 forms one all the same: `forced_group`).
+    Ranks emulated on one GPU use gloo."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced_group()) and not dist.is_initialized():
         if emulated():
             backend = "gloo"
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world
 
@@ -205,7 +223,7 @@ def render_sharded(n_units, render_unit, unit_shape, dtype=torch.float32, device
     world = dist.get_world_size() if dist.is_initialized() else 1
     share = padded_share(n_units, world, block)
     mine = shard_units(n_units, rank, world, block)
-    if not gather or world == 1:
+    if not gather or (world == 1 and not grouped()):
         local = torch.zeros((share,) + tuple(unit_shape), dtype=dtype, device=device)
         for i, u in enumerate(mine):
             local[i].copy_(render_unit(u))

@@ -209,6 +209,23 @@ class StackPlan:
         return hit
 
 
+def _conv_into_units(x, maps, dest, B, C_, S, H, W, grid, ks, st):
+    """Stack convolution with slice k written as the [C,H,W] unit `units[first + k*step]` of the caller's contiguous
+    [M,C,H,W] buffer (aadff_render_psf_map_stack_strided); returns `units`."""
+    units, first, ustep = dest
+    assert B == 1 and units.is_cuda and units.is_contiguous() and units.dtype == torch.float32 and tuple(units.shape[1:]) == (C_, H, W)
+    assert ustep >= 1 and 0 <= first and first + (S - 1) * ustep < units.shape[0], "dest units out of range"
+    _abi.call("aadff_render_psf_map_stack_strided", _abi.ptr(x), _abi.ptr(maps),
+              C.c_void_p(units.data_ptr() + 4 * first * C_ * H * W), H * W, ustep * C_ * H * W, 1, C_, S, H, W, grid, ks, st)
+    return units
+
+
+def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp):
+    """PSF maps [S,3,g*ks,g*ks] of a strict-parity lens by the reference's loop: refocus(f_k) then psf_map, slice by slice, in
+    the reference's host-RNG order (2_aber_aware_dff_aif.py:104-114 with deeplens/optics.py:779-783)."""
+    return torch.stack([(lens.refocus(f), lens.psf_map(depth=depth_plane_mm, grid=grid, ks=ks, spp=spp))[1] for f in focus])
+
+
 @torch.no_grad()
 def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, spp=GEO_SPP, plan=None,
                           return_maps=False, update_lens=True, dest=None):
@@ -227,11 +244,21 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
         # verification mode: the reference's own loop (refocus -> psf_map per slice, 2_aber_aware_dff_aif.py:104-114) with the
         # strict trace behind every call; only the convolution is shared with the fast path (deterministic to 2e-6 abs)
         dev = lens._gpu()
-        maps = torch.stack([(lens.refocus(f), lens.psf_map(depth=depth_plane_mm, grid=grid, ks=ks, spp=spp))[1] for f in focus]).to(dev)
+        keep = None if update_lens else _abi.LensState.from_buffer_copy(bytes(lens._state_sync()))
+        try:
+            maps = strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp).to(dev).contiguous()
+        finally:
+            if keep is not None:                                 # update_lens=False: the lens stays focused where it was
+                lens._state_host = keep
+                if lens._state_dev is not None:
+                    lens._state_upload()
         x = _abi.f32c(img, dev)
-        out = torch.empty((B, C_, S, H, W), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(maps.contiguous()), _abi.ptr(out), B, C_, S, H, W, grid, ks, _abi.stream_ptr(dev))
+            if dest is None:
+                out = torch.empty((B, C_, S, H, W), dtype=torch.float32, device=dev)
+                _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(maps), _abi.ptr(out), B, C_, S, H, W, grid, ks, _abi.stream_ptr(dev))
+            else:
+                out = _conv_into_units(x, maps, dest, B, C_, S, H, W, grid, ks, _abi.stream_ptr(dev))
         return (out, maps) if return_maps else out
     own_plan = plan is None
     if own_plan:
@@ -296,11 +323,7 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
             _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(plan.psf_maps), _abi.ptr(plan.out), B, C_, S,
                       H, W, grid, ks, st)
         else:
-            units, first, ustep = dest
-            assert B == 1 and units.is_cuda and units.is_contiguous() and units.dtype == torch.float32 and tuple(units.shape[1:]) == (C_, H, W)
-            assert ustep >= 1 and 0 <= first and first + (S - 1) * ustep < units.shape[0], "dest units out of range"
-            _abi.call("aadff_render_psf_map_stack_strided", _abi.ptr(x), _abi.ptr(plan.psf_maps),
-                      C.c_void_p(units.data_ptr() + 4 * first * C_ * H * W), H * W, ustep * C_ * H * W, 1, C_, S, H, W, grid, ks, st)
+            _conv_into_units(x, plan.psf_maps, dest, B, C_, S, H, W, grid, ks, st)
         if plan.conv_events is not None:
             plan.conv_events[1].record()
         if stage is not None:
@@ -610,7 +633,8 @@ class SceneUnitRenderer:
                     plan = self.plans[(n, slot)] = StackPlan(lens, n, H, W, 1, C_, self.grid, self.ks, self.spp)
                 step = dst[1] - dst[0] if n > 1 else 1
                 direct = (B == 1 and step >= 1 and all(dst[i] == dst[0] + i * step for i in range(n)) and out.is_cuda
-                          and out.is_contiguous() and out.dtype == torch.float32 and step * C_ * H * W < (1 << 28))
+                          and out.is_contiguous() and out.dtype == torch.float32
+                          and 16 * step * C_ * H * W + 4 * H * W < (1 << 32))          # the kernel's 32-bit store offsets (conv.hip)
                 with (torch.cuda.stream(self.streams[slot]) if multi else contextlib.nullcontext()):
                     st = render_focal_stack_m1(lens, img, depth_plane_mm, [focus[k] for k in sl], self.grid, self.ks, self.spp,
                                                plan=plan, update_lens=False, dest=(out, dst[0], step) if direct else None)
@@ -658,8 +682,10 @@ def render_scenes_sharded(renderer, gather=True, stream=None, block=None):
     img0 = renderer.scenes[0][0]
     dev = renderer.lens._gpu()
     unit_shape = tuple(img0.shape[1:])
-    if not gather or world == 1:
+    if not gather or (world == 1 and not adist.grouped()):
         local = torch.empty((share,) + unit_shape, dtype=torch.float32, device=dev)
+        if len(mine) < share:
+            local[len(mine):].zero_()                   # padding units of the equal share: defined, like dist.render_sharded's
         renderer.render(mine, out=local[:len(mine)])
         return (local[:len(mine)] if world == 1 else local, mine) if stream is None else (local[:len(mine)] if world == 1 else local, mine, None)
     full = torch.empty((share * world,) + unit_shape, dtype=torch.float32, device=dev)
@@ -675,6 +701,8 @@ def render_scenes_sharded(renderer, gather=True, stream=None, block=None):
     side = stream if stream is not None else cur
     if stream is not None:
         full.record_stream(stream)
+        side.wait_stream(cur)                           # the padding zero_() above is queued on `cur`: a rank that owns nothing
+                                                        # would otherwise gather its rows before they are written
     state = {"next": 0}
 
     def gather_ready():

@@ -479,64 +479,27 @@ struct __attribute__((packed, aligned(4))) f2u { float x, y; };       // 8-byte 
 // address register - the second read then takes its address from a register the first one's returning data overwrites
 // whenever the wave is held between the two for longer than the LDS latency (seen in round 3 as one wrong 2x2 output
 // block per ~100 000, never the same one: `ds_read_b64 v[50:51], v50 ...; ds_read_b64 v[52:53], v50 ...`).
-// -DAADFF_SB_DPP=1 (experiment, round 3, rejected): the matrix phase is bound by the LDS operand reads (17 wave-bands x 720
-// reads x 4 cycles = 20 us per CU against 15 us of MFMA), and half of what it reads is read twice - lane cx's second 8
-// bytes (columns 2, 3 of its 2 x 4 block) are lane cx + 1's first 8.  In this form only the LAST lane of each 16-lane row
-// fetches its second half from LDS (a 4-lane ds_read_b64 under an exec mask: same instruction count, so the lgkmcnt
-// bookkeeping is unchanged) and lanes 0..14 take it from their right-hand neighbour with a DPP row shift once the data has
-// landed (lds_share16).  Bit-equal output, but SLOWER (matrix phase 18.6 -> 23.7 us): a ds_read_b64 occupies the LDS pipe
-// for its four passes whatever the exec mask, so the bytes saved buy nothing and the exec switches + 4 DPP moves are pure cost.
-#ifndef AADFF_SB_DPP
-#define AADFF_SB_DPP 0
-#endif
 template <int OFF>
 __device__ __forceinline__ void lds_read16(uint2v& a, uint2v& b, unsigned byte_addr) {
-#if AADFF_SB_DPP
-    unsigned long long keep;
-    // (s_mov, not s_and_saveexec: the statement must leave SCC alone - the compiler keeps loop conditions in it; every lane
-    // is active in the matrix phase, so the mask itself is the wanted EXEC)
-    asm volatile("ds_read_b64 %0, %3 offset:%5\n\t"
-                 "s_mov_b64 %2, exec\n\t"
-                 "s_mov_b64 exec, %4\n\t"
-                 "ds_read_b64 %1, %3 offset:%6\n\t"
-                 "s_mov_b64 exec, %2"
-                 : "=&v"(a), "=&v"(b), "=&s"(keep) : "v"(byte_addr), "s"(0x8000800080008000ull), "n"(OFF), "n"(OFF + 8));
-#else
     asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4" : "=&v"(a), "=&v"(b) : "v"(byte_addr), "n"(OFF), "n"(OFF + 8));
-#endif
-}
-// after the wait that retires a lds_read16: second half of lanes 0..14 of every row = first half of the lane to the right
-__device__ __forceinline__ void lds_share16(const uint2v& a, uint2v& b) {
-#if AADFF_SB_DPP
-    b.x = (unsigned)__builtin_amdgcn_update_dpp((int)b.x, (int)a.x, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
-    b.y = (unsigned)__builtin_amdgcn_update_dpp((int)b.y, (int)a.y, 0x101, 0xf, 0xf, false);
-#endif
 }
 }  // namespace sb
 
 // Workgroup = one band of RB output rows x 96 columns of one patch and channel plane; wave = one chunk of 4 slices
 // (NC waves).  The band is staged once for all slices (HBM reads the image once), every wave builds the T fragments
 // of its own chunk and walks the band's row pairs.
-#ifndef AADFF_SB_ILP
-#define AADFF_SB_ILP 0                  // 1: three accumulators per row pair, k-step outermost (158 VGPRs: 4 workgroups per CU)
-#endif
 #ifndef AADFF_CONV_PAIR_DEFAULT
 #define AADFF_CONV_PAIR_DEFAULT 0      // measured: every pairing is slower than one band per workgroup
 #endif
 // TIMED: the same code under a second name - the launches that carry aadff_time_next_launch's events (bench.py's solo leg) then
 // have their own row in a rocprofv3 --stats summary of the very same command, separate from the launches of the timed region
 // that share the device with the next stack's PSF-grid kernel.
-template <int RB, int NC, bool PAIR, bool TIMED = false, int RS = 1, bool ILP = PAIR && AADFF_SB_ILP>
-// Round 3: 5 waves per SIMD (96 VGPRs) = 6 workgroups per CU = 1536 slots: the 1452 workgroups of the bench launch are all
-// resident in ONE round (round 2: 104 VGPRs, 5 per CU, 172 workgroups in a second round that ended 12 us after the first).
-// What made 96 possible without spilling in the loop: two operand buffers instead of three (AADFF_SB_NBUF).
-#ifndef AADFF_SB_MINWAVES
-#define AADFF_SB_MINWAVES 5
-#endif
-#ifndef AADFF_SB_NBUF
-#define AADFF_SB_NBUF 2
-#endif
-__global__ __launch_bounds__(64 * NC * RS, (PAIR && AADFF_SB_ILP ? 3 : AADFF_SB_MINWAVES)) void conv_psf_map_sbatch_kernel(
+// 5 waves per SIMD (96 VGPRs) = 6 workgroups per CU = 1536 slots: the 1452 workgroups of the bench launch are all resident in
+// ONE round (round 2: 104 VGPRs, 5 per CU, 172 workgroups in a second round that ended 12 us after the first).  What made 96
+// possible without spilling in the loop: two operand buffers instead of three.  Forms measured and dropped in round 3 (three
+// accumulators per row pair, DPP operand sharing, 32/48-row bands, two row groups per chunk): DESIGN.md 4.1; git history has them.
+template <int RB, int NC, bool PAIR, bool TIMED = false>
+__global__ __launch_bounds__(64 * NC, 5) void conv_psf_map_sbatch_kernel(
     const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
     int grid, int ntx, int nty, int npass, PatchBounds pb, int stagger, int pair_mod) {
     using namespace sb;
@@ -549,9 +512,7 @@ __global__ __launch_bounds__(64 * NC * RS, (PAIR && AADFF_SB_ILP ? 3 : AADFF_SB_
         const int slot = (int)((lin >> 8) % 6u);
         for (int i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(32);
     }
-    // RS > 1: RS row groups per chunk - wave = (row group, chunk); the waves of a chunk share its tap rows and T fragments
-    // source, and split the band's row pairs among themselves in the matrix phase
-    constexpr int NW = NC * RS, THP = RB + KS - 1, NSL = 4 * NC;
+    constexpr int NW = NC, THP = RB + KS - 1, NSL = 4 * NC;
     static_assert(RB % 2 == 0 && THP % 2 == 0, "bands are whole row pairs");
     static_assert(WDW <= 64, "one lane per dword column");
     __shared__ __attribute__((aligned(16))) unsigned tile[(THP / 2) * RPP];
@@ -592,7 +553,7 @@ __global__ __launch_bounds__(64 * NC * RS, (PAIR && AADFF_SB_ILP ? 3 : AADFF_SB_
 #endif
     const int G = grid * KS;
     const int s_base = pass * NSL;                       // first slice of this workgroup
-    const int chunk = RS == 1 ? wave : wave % NC, rgroup = RS == 1 ? 0 : wave / NC;
+    const int chunk = wave;
     const int kg = lane >> 4, lo4 = lane & 15;
 
     // ---- global loads up front: this wave's taps (4 slices, 2 per lane and slice), then its share of the image rows ----
@@ -627,9 +588,8 @@ __global__ __launch_bounds__(64 * NC * RS, (PAIR && AADFF_SB_ILP ? 3 : AADFF_SB_
             amax = fmaxf(amax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
         }
     }
-    // ---- padded fp16 hi/lo tap rows of this wave's chunk (RS > 1: written by the chunk's first row group only; everybody
-    //      reads them after the barrier below) ----
-    if (rgroup == 0) {
+    // ---- padded fp16 hi/lo tap rows of this wave's chunk ----
+    {
         _Float16* ph = reinterpret_cast<_Float16*>(&prow[0][0]);
         _Float16* pl = reinterpret_cast<_Float16*>(&prow[1][0]);
         for (int e = lane; e < 4 * PSL; e += 64) { prow[0][4 * chunk * PSL + e] = 0u; prow[1][4 * chunk * PSL + e] = 0u; }
@@ -757,123 +717,10 @@ __global__ __launch_bounds__(64 * NC * RS, (PAIR && AADFF_SB_ILP ? 3 : AADFF_SB_
     }
 
     // ---- matrix phase of one band (rows yb .. yb + RB - 1 of the image, staged in `tile`) ----
-    auto run_band = [&](const int yb0, const float inv) {
-        int npairs_all = (y_hi - yb0 + 1) / 2;              // row pairs of this band that hold valid rows
-        npairs_all = npairs_all > RB / 2 ? RB / 2 : npairs_all;
-        // this wave's share of the row pairs (row group): the code below sees a band that starts at its first row pair
-        constexpr int RPG = (RB / 2 + RS - 1) / RS;
-        const int rp0 = rgroup * RPG;
-        int npairs = npairs_all - rp0;
-        npairs = npairs > RPG ? RPG : (npairs < 0 ? 0 : npairs);
-        const int yb = yb0 + 2 * rp0;
-        const unsigned rowb0 = (unsigned)(rp0 * RPP * 4);
-        if constexpr (ILP) {
-            // k-step outermost, the three column blocks of a row pair in three accumulators: the nine MFMAs of a k-step go out
-            // as hh(0) hh(1) hh(2) hl(0) hl(1) hl(2) lh(0) lh(1) lh(2), so an accumulator is touched every third issue slot
-            // (48 cycles: the latency of a dependent 16x16x32 MFMA) instead of 15 times in a row - with the 8-9 waves per CU of
-            // the paired launch a wave can no longer count on other waves to fill its dependency gaps.  Operands of the next
-            // k-step (3 fragments, 12 ds_read_b64) are fetched while the current one is in the matrix pipe; two sets of
-            // registers alternate, and since a row pair has five k-steps the roles swap from one row pair to the next (P).
-            uint2v xs[2][3][4];                             // [set][column block][hi0, hi1, lo0, lo1]
-            auto issue_set = [&](auto setc, auto stc, unsigned rowb) {
-                constexpr int set = decltype(setc)::value, st = decltype(stc)::value;
-                const unsigned a = xaddr[st] + rowb;
-                lds_read16<0>(xs[set][0][0], xs[set][0][1], a);
-                lds_read16<LO * 4>(xs[set][0][2], xs[set][0][3], a);
-                lds_read16<128>(xs[set][1][0], xs[set][1][1], a);
-                lds_read16<LO * 4 + 128>(xs[set][1][2], xs[set][1][3], a);
-                lds_read16<256>(xs[set][2][0], xs[set][2][1], a);
-                lds_read16<LO * 4 + 256>(xs[set][2][2], xs[set][2][3], a);
-            };
-            auto row_pair = [&](auto pc, const int rpi) {
-                constexpr int P = decltype(pc)::value;
-                const unsigned rowb = rowb0 + (unsigned)(rpi * RPP * 4);
-                const unsigned rowb_next = rowb0 + (unsigned)((rpi + 1 < npairs ? rpi + 1 : rpi) * RPP * 4);
-                const int yl = 2 * rpi;
-                const bool row1 = yb + yl + 1 < y_hi;
-                const unsigned loff = koff + (unsigned)(yb + yl) * w4 + (unsigned)(x0 + 2 * lo4) * 4u;
-                float4v acc[3];
-                auto kstep = [&](auto stc) {
-                    constexpr int st = decltype(stc)::value, cur = (P + st) & 1, nxt = cur ^ 1;
-#if defined(AADFF_SB_ABL) && AADFF_SB_ABL == 3      // ablation: operand reads only for the first k-step of a band
-                    if (rpi == 0 && st == 0) {
-#else
-                    {
-#endif
-                    if constexpr (st < 4) issue_set(std::integral_constant<int, nxt>{}, std::integral_constant<int, st + 1>{}, rowb);
-                    else issue_set(std::integral_constant<int, nxt>{}, std::integral_constant<int, 0>{}, rowb_next);
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(12)"
-                                 : "+v"(xs[cur][0][0]), "+v"(xs[cur][0][1]), "+v"(xs[cur][0][2]), "+v"(xs[cur][0][3]),
-                                   "+v"(xs[cur][1][0]), "+v"(xs[cur][1][1]), "+v"(xs[cur][1][2]), "+v"(xs[cur][1][3]),
-                                   "+v"(xs[cur][2][0]), "+v"(xs[cur][2][1]), "+v"(xs[cur][2][2]), "+v"(xs[cur][2][3]));
-                    half8v bh[3], bl[3];
-#pragma unroll
-                    for (int cb = 0; cb < 3; ++cb) {
-                        lds_share16(xs[cur][cb][0], xs[cur][cb][1]);
-                        lds_share16(xs[cur][cb][2], xs[cur][cb][3]);
-                        const uint4v h4 = {xs[cur][cb][0].x, xs[cur][cb][0].y, xs[cur][cb][1].x, xs[cur][cb][1].y};
-                        const uint4v l4 = {xs[cur][cb][2].x, xs[cur][cb][2].y, xs[cur][cb][3].x, xs[cur][cb][3].y};
-                        bh[cb] = __builtin_bit_cast(half8v, h4);
-                        bl[cb] = __builtin_bit_cast(half8v, l4);
-                    }
-                    const half8v th = __builtin_bit_cast(half8v, Th[st]), tl = __builtin_bit_cast(half8v, Tl[st]);
-                    if constexpr (st == 0) {
-#pragma unroll
-                        for (int cb = 0; cb < 3; ++cb) acc[cb] = (float4v){0.f, 0.f, 0.f, 0.f};
-                    }
-#if defined(AADFF_SB_ABL) && AADFF_SB_ABL == 2      // ablation: no matrix work (one cheap VALU op keeps the operands live)
-#pragma unroll
-                    for (int cb = 0; cb < 3; ++cb) acc[cb][0] += __builtin_bit_cast(float, xs[cur][cb][0].x ^ xs[cur][cb][2].y ^ Th[st].x);
-#else
-#pragma unroll
-                    for (int cb = 0; cb < 3; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bh[cb], acc[cb], 0, 0, 0);
-#pragma unroll
-                    for (int cb = 0; cb < 3; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bl[cb], acc[cb], 0, 0, 0);
-#pragma unroll
-                    for (int cb = 0; cb < 3; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl, bh[cb], acc[cb], 0, 0, 0);
-#endif
-                };
-                kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{}); kstep(std::integral_constant<int, 2>{});
-                kstep(std::integral_constant<int, 3>{}); kstep(std::integral_constant<int, 4>{});
-#pragma unroll
-                for (int cb = 0; cb < 3; ++cb) {
-                    // D[m = 4 kg + i][n = cx]: i = (du, j) -> out[slice kg][y + du][x0 + 32 cb + 2 cx + j]
-                    const float a0 = acc[cb][0] * inv, b0 = acc[cb][1] * inv, a1 = acc[cb][2] * inv, b1 = acc[cb][3] * inv;
-                    char* o0 = wbase + loff + cb * 128;
-                    char* o1 = wbase + (loff + w4) + cb * 128;
-#if defined(AADFF_SB_ABL) && AADFF_SB_ABL == 1      // ablation: no stores unless a value is NaN (never)
-                    if (a0 != a0 || b0 != b0 || a1 != a1 || b1 != b1)
-#endif
-                    if (pair_ok[cb]) {
-                        *reinterpret_cast<f2u*>(o0) = (f2u){a0, b0};
-                        if (row1) *reinterpret_cast<f2u*>(o1) = (f2u){a1, b1};
-                    } else if (one_ok[cb]) {
-                        *reinterpret_cast<float*>(o0) = a0;
-                        if (row1) *reinterpret_cast<float*>(o1) = a1;
-                    }
-                }
-            };
-            issue_set(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, rowb0);
-            int rpi = 0;
-#pragma unroll 1
-            for (; rpi + 1 < npairs; rpi += 2) {
-                row_pair(std::integral_constant<int, 0>{}, rpi);
-                row_pair(std::integral_constant<int, 1>{}, rpi + 1);
-            }
-            if (rpi < npairs) row_pair(std::integral_constant<int, 0>{}, rpi);
-            // The set prefetched by the last k-step is never consumed: its destination registers must stay OWNED until the
-            // reads have landed (named here), or the allocator hands them to the next address computation and a late return
-            // overwrites it (seen as a write fault in the instrumented build).
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(xs[0][0][0]), "+v"(xs[0][0][1]), "+v"(xs[0][0][2]), "+v"(xs[0][0][3]), "+v"(xs[0][1][0]), "+v"(xs[0][1][1]),
-                           "+v"(xs[0][1][2]), "+v"(xs[0][1][3]), "+v"(xs[0][2][0]), "+v"(xs[0][2][1]), "+v"(xs[0][2][2]), "+v"(xs[0][2][3]),
-                           "+v"(xs[1][0][0]), "+v"(xs[1][0][1]), "+v"(xs[1][0][2]), "+v"(xs[1][0][3]), "+v"(xs[1][1][0]), "+v"(xs[1][1][1]),
-                           "+v"(xs[1][1][2]), "+v"(xs[1][1][3]), "+v"(xs[1][2][0]), "+v"(xs[1][2][1]), "+v"(xs[1][2][2]), "+v"(xs[1][2][3])
-                         :: "memory");
-            return;
-        }
-#if AADFF_SB_NBUF == 2
+    auto run_band = [&](const int yb, const float inv) {
+        int npairs = (y_hi - yb + 1) / 2;                   // row pairs of this band that hold valid rows
+        npairs = npairs > RB / 2 ? RB / 2 : npairs;
+        const unsigned rowb0 = 0u;
         {
             // Two operand buffers, reads ONE step ahead: 8 VGPRs fewer than the three-buffer form - what it takes to fit
             // 96 VGPRs = 5 waves per SIMD = 6 workgroups (18 waves) per CU, i.e. all 1452 workgroups of the bench launch
@@ -937,69 +784,7 @@ __global__ __launch_bounds__(64 * NC * RS, (PAIR && AADFF_SB_ILP ? 3 : AADFF_SB_
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(xq[0][0]), "+v"(xq[0][1]), "+v"(xq[0][2]), "+v"(xq[0][3]), "+v"(xq[1][0]), "+v"(xq[1][1]), "+v"(xq[1][2]), "+v"(xq[1][3])
                          :: "memory");
-            return;
         }
-#endif
-        // 15 (cb, st) steps per row pair, operand reads two steps ahead (three 8-register buffers; 15 % 3 == 0 keeps the
-        // rotation across row pairs, so the last two steps prefetch the next row pair's first two).  Column block
-        // outermost: one accumulator live, its stores overlap the next block's MFMAs.
-        uint2v xq[3][4];                                    // [buffer][hi0, hi1, lo0, lo1]
-        auto issue = [&](auto stepc, unsigned rowb) {
-            constexpr int step = decltype(stepc)::value, cb = step / 5, st = step % 5, bf = step % 3;
-            const unsigned a = xaddr[st] + rowb;
-            lds_read16<cb * 128>(xq[bf][0], xq[bf][1], a);
-            lds_read16<LO * 4 + cb * 128>(xq[bf][2], xq[bf][3], a);
-        };
-        issue(std::integral_constant<int, 0>{}, rowb0);
-        issue(std::integral_constant<int, 1>{}, rowb0);
-    #pragma unroll 1
-        for (int rpi = 0; rpi < npairs; ++rpi) {
-            const unsigned rowb = rowb0 + (unsigned)(rpi * RPP * 4);
-            const unsigned rowb_next = rowb0 + (unsigned)((rpi + 1 < npairs ? rpi + 1 : rpi) * RPP * 4);
-            const int yl = 2 * rpi;
-            const bool row1 = yb + yl + 1 < y_hi;           // row 0 of the pair is valid by construction of npairs
-            const unsigned loff = koff + (unsigned)(yb + yl) * w4 + (unsigned)(x0 + 2 * lo4) * 4u;
-            float4v acc;
-            auto step_fn = [&](auto stepc) {
-                constexpr int step = decltype(stepc)::value, cb = step / 5, st = step % 5, bf = step % 3;
-                if constexpr (step + 2 < 15) issue(std::integral_constant<int, step + 2>{}, rowb);
-                else issue(std::integral_constant<int, step + 2 - 15>{}, rowb_next);
-                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xq[bf][0]), "+v"(xq[bf][1]), "+v"(xq[bf][2]), "+v"(xq[bf][3]));
-                lds_share16(xq[bf][0], xq[bf][1]);
-                lds_share16(xq[bf][2], xq[bf][3]);
-                const uint4v h4 = {xq[bf][0].x, xq[bf][0].y, xq[bf][1].x, xq[bf][1].y};
-                const uint4v l4 = {xq[bf][2].x, xq[bf][2].y, xq[bf][3].x, xq[bf][3].y};
-                const half8v bh = __builtin_bit_cast(half8v, h4), bl = __builtin_bit_cast(half8v, l4);
-                const half8v th = __builtin_bit_cast(half8v, Th[st]), tl = __builtin_bit_cast(half8v, Tl[st]);
-                if constexpr (st == 0) acc = (float4v){0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl, bh, acc, 0, 0, 0);
-                if constexpr (st == 4) {
-                    // D[m = 4 kg + i][n = cx]: i = (du, j) -> out[slice kg][y + du][x0 + 32 cb + 2 cx + j]
-                    const float a0 = acc[0] * inv, b0 = acc[1] * inv, a1 = acc[2] * inv, b1 = acc[3] * inv;
-                    char* o0 = wbase + loff + cb * 128;
-                    char* o1 = wbase + (loff + w4) + cb * 128;
-                    if (pair_ok[cb]) {
-                        *reinterpret_cast<f2u*>(o0) = (f2u){a0, b0};
-                        if (row1) *reinterpret_cast<f2u*>(o1) = (f2u){a1, b1};
-                    } else if (one_ok[cb]) {
-                        *reinterpret_cast<float*>(o0) = a0;
-                        if (row1) *reinterpret_cast<float*>(o1) = a1;
-                    }
-                }
-            };
-            step_fn(std::integral_constant<int, 0>{}); step_fn(std::integral_constant<int, 1>{}); step_fn(std::integral_constant<int, 2>{});
-            step_fn(std::integral_constant<int, 3>{}); step_fn(std::integral_constant<int, 4>{}); step_fn(std::integral_constant<int, 5>{});
-            step_fn(std::integral_constant<int, 6>{}); step_fn(std::integral_constant<int, 7>{}); step_fn(std::integral_constant<int, 8>{});
-            step_fn(std::integral_constant<int, 9>{}); step_fn(std::integral_constant<int, 10>{}); step_fn(std::integral_constant<int, 11>{});
-            step_fn(std::integral_constant<int, 12>{}); step_fn(std::integral_constant<int, 13>{}); step_fn(std::integral_constant<int, 14>{});
-        }
-        // the two prefetches issued by the last row pair are never consumed: their registers stay owned until they have landed
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(xq[0][0]), "+v"(xq[0][1]), "+v"(xq[0][2]), "+v"(xq[0][3]), "+v"(xq[1][0]), "+v"(xq[1][1]), "+v"(xq[1][2]), "+v"(xq[1][3]),
-                       "+v"(xq[2][0]), "+v"(xq[2][1]), "+v"(xq[2][2]), "+v"(xq[2][3])
-                     :: "memory");
     };
     run_band(y0, inv);
     AADFF_SB_STAMP(4);
@@ -1047,6 +832,198 @@ __global__ __launch_bounds__(64 * NC * RS, (PAIR && AADFF_SB_ILP ? 3 : AADFF_SB_
         }
     }
 #ifdef AADFF_SB_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stores retired
+    AADFF_SB_STAMP(5);
+#endif
+}
+
+// ------------------------------------------------------------------------------------
+// Block-GEMM path for LONE slices (ks 9 / 11, S < 3: `render_psf_map` / `render_psf` themselves, deeplens/render_psf.py:12-73).
+// With one slice there is nothing to batch on M, so a 4 x 4 block of OUTPUT PIXELS rides there instead:
+//   D[m][n] += sum_k T[m][k] X[k][n]
+//   n = (ry, cx): base pixel (y + 4 ry, X0 + 4 cx) of an 8-row x 32-column group          (2 x 8 = 16)
+//   m = (du, j): output pixel (base row + du, base column + j), du, j = 0..3              (16)
+//   k = (u, t): input rows u = 0..13, input columns t = 0..15 of the base's 14 x 14 window (224 = 7 k-steps; 196 real)
+//   X[(u,t)][(ry,cx)] = in[y + 4 ry + u][X0 + 4 cx + t],   T[(du,j)][(u,t)] = w(u - du, t - j)  (0 outside the ks x ks taps)
+// -> 21 MFMAs per 256 outputs where the Toeplitz form above needs 33, and per k-step ONE aligned ds_read_b128 per operand
+// plane: k-step st = input row pair (2 st, 2 st + 1), lane group kg = columns 4 kg .. 4 kg + 3, and in the row-pair
+// interleaved tile of the slice-batched kernel ([row pair][dword column][row parity]) that 2 x 4 block is 16 contiguous,
+// 16-byte aligned bytes.  Row-pair pitch 240 dwords (== 16 mod 32): the two base rows of a 16-lane read group (8 lanes x 16 B
+// each, 2 row pairs apart) fall on disjoint halves of the 64 banks.  A lane ends up with 4 consecutive output pixels of one
+// row: 16-byte stores.  Staging (24-row x 96-column band of one patch and plane, image read as fp32, tile-wide power-of-two
+// scale, exact fp16 hi/lo split) is the slice-batched kernel's; wave w renders column block w of the band (3 groups of 8 rows).
+// ------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };   // 16-byte load / store at 4-byte alignment
+
+namespace blk {
+constexpr int TCOLS = 96, WCOLS = TCOLS + 12, WDW = WCOLS / 2, RB = 24, THP = RB + 10, NW = 3;
+constexpr int RPP = 240, LO = 112;        // row-pair pitch, offset of the lo plane (dwords)
+constexpr int TROWS = 17, TPD = 11;       // padded tap rows (a = -3 .. 13), dwords per row (b = -3 .. 18 as halves)
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+}  // namespace blk
+
+template <int KS, bool TIMED = false>
+__global__ __launch_bounds__(64 * blk::NW, 5) void conv_psf_map_blk_kernel(
+    const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
+    int grid, int ntx, int nty, PatchBounds pb) {
+    using namespace blk;
+    constexpr int PAD = KS / 2;
+    static_assert(KS == 9 || KS == 11, "the 14 x 14 window of a 4 x 4 block holds taps up to 11 x 11");
+    AADFF_SB_STAMP(0);
+    __shared__ __attribute__((aligned(16))) unsigned tile[(THP / 2) * RPP];
+    __shared__ __attribute__((aligned(16))) unsigned ptap[2][TROWS * TPD];       // [hi | lo] planes of the zero-padded taps
+    __shared__ float red[NW];
+    __shared__ float s_isw;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pj = udiv_magic(blockIdx.x, ntx, pb.m_ntx), tx = blockIdx.x - pj * ntx;
+    const int pi = udiv_magic(blockIdx.y, nty, pb.m_nty), ty = blockIdx.y - pi * nty;
+    const int bc = udiv_magic(blockIdx.z, S, pb.m_nchunk), s = blockIdx.z - bc * S;
+    const int c = bc - udiv_magic(bc, C, pb.m_c) * C;
+    const int x_hi = pb.wb[pj + 1], y_hi = pb.hb[pi + 1];
+    const int x0 = pb.wb[pj] + tx * TCOLS, y0 = pb.hb[pi] + ty * RB;
+    if (x0 >= x_hi || y0 >= y_hi) return;
+    const int G = grid * KS;
+
+    // ---- global loads up front: the taps (wave 0, two per lane), then this wave's share of the image rows ----
+    float tw0 = 0.f, tw1 = 0.f;
+    const int t0 = lane, t1 = lane + 64;
+    const int tu0 = t0 / KS, tc0 = t0 - tu0 * KS, tu1 = t1 / KS, tc1 = t1 - tu1 * KS;
+    if (wave == 0) {
+        // w(a,b) = psf[KS-1-a][KS-1-b]  (deeplens/render_psf.py:60 flips the kernel before conv2d)
+        const float* wp = psf + ((size_t)(s * C + c) * G + pi * KS) * G + pj * KS;
+        if (t0 < KS * KS) tw0 = wp[(size_t)(KS - 1 - tu0) * G + (KS - 1 - tc0)];
+        if (t1 < KS * KS) tw1 = wp[(size_t)(KS - 1 - tu1) * G + (KS - 1 - tc1)];
+    }
+    constexpr int NPT = (THP + NW - 1) / NW;
+    float v0[NPT], v1[NPT];
+    float amax = 0.f;
+    {
+        const float* plane = img + (size_t)bc * H * W;
+        const int xa = reflect_idx(x0 - PAD + 2 * lane, W), xb = reflect_idx(x0 - PAD + 2 * lane + 1, W);
+#pragma unroll
+        for (int e = 0; e < NPT; ++e) {
+            const int r = wave + e * NW;
+            const bool in = lane < WDW && r < THP;
+            const float* row = plane + (size_t)reflect_idx(y0 - PAD + r, H) * W;
+            v0[e] = in ? row[xa] : 0.f;
+            v1[e] = in ? row[xb] : 0.f;
+            amax = fmaxf(amax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
+        }
+    }
+    if (wave == 0) {
+        // zero-padded fp16 hi/lo taps: tap (a, b) at half index (a + 3) * 2 TPD + (b + 3)
+        for (int e = lane; e < TROWS * TPD; e += 64) { ptap[0][e] = 0u; ptap[1][e] = 0u; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float wmax = wave_max(fmaxf(fabsf(tw0), fabsf(tw1)));
+        float sw, isw;
+        pow2_scale(wmax, sw, isw);
+        if (lane == 0) s_isw = isw;
+        _Float16* ph = reinterpret_cast<_Float16*>(&ptap[0][0]);
+        _Float16* pl = reinterpret_cast<_Float16*>(&ptap[1][0]);
+        if (t0 < KS * KS) {
+            const float a = tw0 * sw;
+            const _Float16 h = (_Float16)a;
+            ph[(tu0 + 3) * 2 * TPD + tc0 + 3] = h;
+            pl[(tu0 + 3) * 2 * TPD + tc0 + 3] = (_Float16)(a - (float)h);
+        }
+        if (t1 < KS * KS) {
+            const float a = tw1 * sw;
+            const _Float16 h = (_Float16)a;
+            ph[(tu1 + 3) * 2 * TPD + tc1 + 3] = h;
+            pl[(tu1 + 3) * 2 * TPD + tc1 + 3] = (_Float16)(a - (float)h);
+        }
+    }
+    amax = wave_max(amax);
+    if (lane == 0) red[wave] = amax;
+    AADFF_SB_STAMP(1);                                                        // global loads have arrived (wave 0)
+    __syncthreads();
+    float tmax = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) tmax = fmaxf(tmax, red[w]);
+    float sx, isx;
+    pow2_scale(tmax, sx, isx);
+#pragma unroll
+    for (int e = 0; e < NPT; ++e) {
+        const int r = wave + e * NW;
+        if (lane < WDW && r < THP) {
+            const float a = v0[e] * sx, b = v1[e] * sx;
+            const _Float16 ah = (_Float16)a, bh = (_Float16)b;
+            const _Float16 al = (_Float16)(a - (float)ah), bl = (_Float16)(b - (float)bh);
+            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+            const int d = (r >> 1) * RPP + 2 * lane + (r & 1);
+            tile[d] = __builtin_bit_cast(unsigned, (half2v){ah, bh});
+            tile[d + LO] = __builtin_bit_cast(unsigned, (half2v){al, bl});
+        }
+    }
+
+    // ---- T fragments: lane (m = (du, j), kg), k-step st: halves i = 0..7 = (row 2 st + (i >> 1 & 1), column 4 kg + (i & 1) + 2 (i >> 2)) ----
+    const int kg = lane >> 4, n = lane & 15;
+    uint4v Th[7], Tl[7];
+    {
+        const int du = n >> 2, j = n & 3;
+        const int c0 = 4 * kg - j + 3;                                          // half index of tap column t - j, t = 4 kg
+        const int e = c0 >> 1;
+        const unsigned sh = (c0 & 1) * 16;
+#pragma unroll
+        for (int st = 0; st < 7; ++st) {
+            const int ra = 2 * st - du + 3;                                     // padded row of tap row u - du, u = 2 st
+            const unsigned* a0 = &ptap[0][ra * TPD + e];
+            const unsigned* a1 = &ptap[1][ra * TPD + e];
+            Th[st] = (uint4v){__builtin_amdgcn_alignbit(a0[1], a0[0], sh), __builtin_amdgcn_alignbit(a0[TPD + 1], a0[TPD], sh),
+                              __builtin_amdgcn_alignbit(a0[2], a0[1], sh), __builtin_amdgcn_alignbit(a0[TPD + 2], a0[TPD + 1], sh)};
+            Tl[st] = (uint4v){__builtin_amdgcn_alignbit(a1[1], a1[0], sh), __builtin_amdgcn_alignbit(a1[TPD + 1], a1[TPD], sh),
+                              __builtin_amdgcn_alignbit(a1[2], a1[1], sh), __builtin_amdgcn_alignbit(a1[TPD + 2], a1[TPD + 1], sh)};
+        }
+    }
+    const float inv = isx * s_isw;
+    __syncthreads();                                                          // the whole band is in LDS
+    AADFF_SB_STAMP(2);
+    AADFF_SB_STAMP(3);
+
+    // ---- matrix phase: column block `wave` of the band, groups of 8 rows ----
+    const int ry = n >> 3, cx = n & 7;
+    const int xw = x0 + 32 * wave;
+    if (xw < x_hi) {
+        const unsigned* xptr = tile + (2 * ry) * RPP + 32 * wave + 4 * cx + 4 * kg;
+        const int x = xw + 4 * cx;
+        const bool full = x + 3 < x_hi;
+        float* obase = out + (size_t)bc * sbc + (size_t)s * ss + x;
+#pragma unroll
+        for (int g = 0; g < RB / 8; ++g) {
+            const int yg = y0 + 8 * g;
+            if (yg < y_hi) {
+                float4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < 7; ++st) {
+                    const uint4v h4 = *reinterpret_cast<const uint4v*>(xptr + (4 * g + st) * RPP);
+                    const uint4v l4 = *reinterpret_cast<const uint4v*>(xptr + (4 * g + st) * RPP + LO);
+                    const half8v bh = __builtin_bit_cast(half8v, h4), bl = __builtin_bit_cast(half8v, l4);
+                    const half8v th = __builtin_bit_cast(half8v, Th[st]), tl = __builtin_bit_cast(half8v, Tl[st]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl, bh, acc, 0, 0, 0);
+                }
+                // D[m = 4 kg + r][n]: du = kg, j = r -> out[yg + 4 ry + kg][x + r]
+                const int y = yg + 4 * ry + kg;
+                if (y < y_hi) {
+                    float* o = obase + (size_t)y * W;
+                    const float a0 = acc[0] * inv, a1 = acc[1] * inv, a2 = acc[2] * inv, a3 = acc[3] * inv;
+                    if (full) *reinterpret_cast<f4u*>(o) = (f4u){a0, a1, a2, a3};
+                    else {
+                        if (x < x_hi) o[0] = a0;
+                        if (x + 1 < x_hi) o[1] = a1;
+                        if (x + 2 < x_hi) o[2] = a2;
+                    }
+                }
+            }
+        }
+    }
+#ifdef AADFF_SB_TRACE
+    AADFF_SB_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stores retired
     AADFF_SB_STAMP(5);
 #endif
@@ -1134,10 +1111,7 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
     if constexpr (KS == 11) {
         // stacks: slice-batched GEMM (the image is the shared operand); "toeplitz" / "valu" force the older paths
         if (S >= 3 && !penv) {
-#ifndef AADFF_SB_RB
-#define AADFF_SB_RB 24
-#endif
-            constexpr int RB = AADFF_SB_RB;
+            constexpr int RB = 24;          // band rows (8/12/16/32/48 measured slower)
             const int nc = S <= 4 ? 1 : (S <= 8 ? 2 : (S <= 12 ? 3 : 4));
             const int npass = (S + 4 * nc - 1) / (4 * nc);
             int mh = 0, mw = 0;
@@ -1153,8 +1127,6 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
             // AADFF_CONV_PAIR: 0 = one band per workgroup (round-2 form), N >= 1 = bands in pairs for every N-th (patch, plane)
             const int pair_mod = [] { const char* e = getenv("AADFF_CONV_PAIR"); const int v = e ? atoi(e) : AADFF_CONV_PAIR_DEFAULT; return v < 0 ? 0 : v; }();   // read per launch: tests switch it
             const bool pair = pair_mod > 0;
-            // (RS = 2 - two row groups per chunk, 6 waves per workgroup sharing one staged band - is implemented in the kernel and
-            // bit-equal, but with the paired form's 118 VGPRs it only fits 2 workgroups per CU or spills: 77 us; not instantiated)
             const int gny = snty;
             PatchBounds pbs = pb;
             pbs.m_ntx = magic_of(sntx); pbs.m_nty = magic_of(gny); pbs.m_nchunk = magic_of(npass); pbs.m_c = magic_of(C);
@@ -1163,10 +1135,10 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
             // aadff_time_next_launch: the two events ride ON this dispatch (kernel begin / end timestamps)
             hipEvent_t ev0 = g_time_start, ev1 = g_time_stop;
             g_time_start = g_time_stop = nullptr;
-#define AADFF_LAUNCH_S3(NCV, PR, RSV) do { \
-                if (ev0) hipExtLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR, true, RSV>), gs, dim3(64 * NCV * RSV), 0, st, ev0, ev1, 0, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); \
-                else hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR, false, RSV>), gs, dim3(64 * NCV * RSV), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); } while (0)
-#define AADFF_LAUNCH_S(NCV) do { if (pair) AADFF_LAUNCH_S3(NCV, true, 1); else AADFF_LAUNCH_S3(NCV, false, 1); } while (0)
+#define AADFF_LAUNCH_S3(NCV, PR) do { \
+                if (ev0) hipExtLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR, true>), gs, dim3(64 * NCV), 0, st, ev0, ev1, 0, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); \
+                else hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR, false>), gs, dim3(64 * NCV), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); } while (0)
+#define AADFF_LAUNCH_S(NCV) do { if (pair) AADFF_LAUNCH_S3(NCV, true); else AADFF_LAUNCH_S3(NCV, false); } while (0)
             switch (nc) {
                 case 1: AADFF_LAUNCH_S(1); break;
                 case 2: AADFF_LAUNCH_S(2); break;
@@ -1176,6 +1148,25 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
 #undef AADFF_LAUNCH_S
 #undef AADFF_LAUNCH_S3
             return 0;
+        }
+    }
+    if constexpr (KS == 9 || KS == 11) {
+        // lone slices (render_psf_map / render_psf as the reference calls them) and pairs: block-GEMM form, 21 instead of 33
+        // MFMAs per 256 outputs and the slice-batched kernel's staging; AADFF_CONV_PATH = toeplitz / valu force the older paths
+        if (S * B * C <= 65535 && !penv && (size_t)H * W <= ((size_t)1 << 30)) {
+            int mh = 0, mw = 0;
+            for (int i = 0; i < grid; ++i) {
+                mh = std::max(mh, pb.hb[i + 1] - pb.hb[i]);
+                mw = std::max(mw, pb.wb[i + 1] - pb.wb[i]);
+            }
+            const int bntx = (mw + blk::TCOLS - 1) / blk::TCOLS, bnty = (mh + blk::RB - 1) / blk::RB;
+            if ((size_t)bnty * grid <= 65535) {
+                PatchBounds pbb = pb;
+                pbb.m_ntx = magic_of(bntx); pbb.m_nty = magic_of(bnty); pbb.m_nchunk = magic_of(S); pbb.m_c = magic_of(C);
+                dim3 gb(bntx * grid, bnty * grid, B * C * S);
+                hipLaunchKernelGGL((conv_psf_map_blk_kernel<KS>), gb, dim3(64 * blk::NW), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, bntx, bnty, pbb);
+                return 0;
+            }
         }
     }
     if constexpr (KS <= 11) {
@@ -1265,7 +1256,6 @@ static int conv_dispatch(const float* img, const float* psf, float* out, long sb
 //     conflict-free);
 //   * no flip (render_psf.py:99-105 multiplies unfold() patches with the kernel as is).
 // ------------------------------------------------------------------------------------
-struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };   // 16-byte load at 4-byte alignment
 
 constexpr int LP_NPX = 64, LP_MAXC = 4;
 

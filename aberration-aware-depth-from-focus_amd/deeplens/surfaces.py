@@ -44,7 +44,14 @@ class Aspheric(Surface):
 
     def __init__(self, r, d, c=0., k=0., ai=None, mat1=None, mat2=None, is_square=False, device=DEVICE,
                  diff=False, square=False):
-        Surface.__init__(self, r, d, mat1, mat2, is_square or square, device)     # the reference's `square` overrides (:330)
+        # The reference passes `is_square` to Surface.__init__ (which only stores h, w) and then OVERWRITES the attribute with
+        # `square` (surfaces.py:303,330): Aspheric(is_square=True) ends up with a ROUND aperture, Aspheric(square=True) a square one.
+        Surface.__init__(self, r, d, mat1, mat2, False, device)
+        if is_square:
+            self.h = self.w = r * np.sqrt(2)
+        if square:
+            raise NotImplementedError("square apertures are outside the focal-stack hot path")
+        self.is_square = square
         self.c = torch.Tensor([c]).to(device)
         self.k = torch.Tensor([k]).to(device)
         if ai is not None:

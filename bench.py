@@ -148,7 +148,8 @@ def main():
     if args.device_rng:
         lens.sampler = DeviceSampler(dev, seed=rank)
     img = img_h.to(dev)
-    n_streams = 1 if (world > 1 and args.gather) else max(1, args.streams)
+    multi = world > 1 or adist.grouped()               # collectives are issued (AADFF_FORCE_GROUP=1: also on a one-rank RCCL group)
+    n_streams = 1 if (multi and args.gather) else max(1, args.streams)
     pipe = StackPipeline(lens, S, H, W, 1, 3, GRID, KS, SPP, depth=n_streams)
     plan = pipe.plans[0]
     # Kernel durations: HIP events ATTACHED to a kernel's own dispatch (aadff_time_next_launch -> hipExtLaunchKernelGGL):
@@ -164,7 +165,7 @@ def main():
 
     # --gather: the all-gather of step i runs on a side stream while step i+1 renders into the other output buffer
     ring = None
-    if world > 1 and args.gather:
+    if multi and args.gather:
         ring = adist.GatherRing(lambda: torch.empty_like(plan.out), world, slots=2, device=dev)
 
     def step(i, timed=False):
@@ -179,7 +180,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -355,7 +356,7 @@ def main():
                 print("bench: parity failed", file=sys.stderr, flush=True)
                 raise SystemExit(4)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -387,7 +388,8 @@ def main_c3(args):
     n_units = n_scenes * S
     block = int(os.environ.get("AADFF_C3_BLOCK", "0")) or adist.scene_block(n_units, S, world)
     steps, warm = (min(args.steps, 10) if args.steps == 200 else args.steps), min(args.warmup, 2)
-    side = torch.cuda.Stream(dev) if world > 1 else None
+    multi = world > 1 or adist.grouped()               # AADFF_FORCE_GROUP=1: the gather branch on a one-rank RCCL group
+    side = torch.cuda.Stream(dev) if multi else None
 
     def step():
         full, _, done = render_scenes_sharded(rend, gather=True, stream=side or torch.cuda.current_stream(dev), block=block)
@@ -402,13 +404,13 @@ def main_c3(args):
     for _ in range(warm):
         step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if multi:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         full = step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = adist.all_reduce_max(time.perf_counter() - t0)
     rend.check_flags()
@@ -468,7 +470,7 @@ def main_c3(args):
             "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"rf50mm, {n_scenes} scenes x {S} slices, 1024x1024, 11x11 PSF grid, ks 11, spp 2048, mode M1",
-                       "gather": world > 1, "ranks_emulated_on_one_gpu": adist.emulated(),
+                       "gather": multi, "ranks_emulated_on_one_gpu": adist.emulated(),
                        "partition": f"blocks of {block} consecutive units dealt round-robin (unit u -> rank (u // {block}) % N)",
                        "streams_per_rank": c3_streams,
                        "gather_form": "slices written by the convolution straight into the unit-order buffer [rows, world, block, C, H, W]; one "
@@ -476,7 +478,7 @@ def main_c3(args):
                                       "scene groups that produce this rank's block of the row have been launched",
                        "gathered_shape": list(full.shape)},
             "expected_scaling": exp}), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -19,6 +19,8 @@ def pytest_configure(config):
     import faulthandler
     faulthandler.enable()
     faulthandler.dump_traceback_later(1800, exit=True)
+    # children that exist before the first test (plugin helpers) are not this suite's to reap
+    _FOREIGN.update(_own_children())
     # The oracle is torch on the CPU.  The GPU box shows 256 logical CPUs under a 16-CPU quota and this container 8: an
     # OpenMP pool sized by the logical count stalls small ops (and has been seen to wedge a run), so size it by what is usable.
     try:
@@ -58,13 +60,17 @@ def margin():
     return record
 
 
+_FOREIGN = set()
+
+
 def _own_children():
-    """PIDs whose parent is this process (exact PIDs from /proc: nothing is matched by name)."""
+    """PIDs whose parent is this process and that were started after the session began (exact PIDs from /proc: nothing is
+    matched by name; helper processes a plugin started before the first test are left alone)."""
     me, out = os.getpid(), []
     for p in os.listdir("/proc"):
         if p.isdigit():
             try:
-                if int(open(f"/proc/{p}/stat").read().rsplit(")", 1)[1].split()[1]) == me:
+                if int(open(f"/proc/{p}/stat").read().rsplit(")", 1)[1].split()[1]) == me and int(p) not in _FOREIGN:
                     out.append(int(p))
             except (OSError, ValueError, IndexError):
                 pass
@@ -127,7 +133,11 @@ def pytest_unconfigure(config):
     # NON-ZERO status - a wedged exit is a failure to look at, not a pass (it does not restart or re-exec anything).
     import faulthandler
     faulthandler.cancel_dump_traceback_later()
-    _reap_children()
+    # The reaping touches multiprocessing's private tracker handle and ends leftover children of this process: not under
+    # pytest-xdist (controller or worker: their children are xdist's), and switchable off (AADFF_TEST_NO_REAP=1).
+    xdist = os.environ.get("PYTEST_XDIST_WORKER") or getattr(getattr(config, "option", None), "numprocesses", None)
+    if not xdist and os.environ.get("AADFF_TEST_NO_REAP", "0") != "1":
+        _reap_children()
     sys.stdout.flush()
     sys.stderr.flush()
     faulthandler.dump_traceback_later(120, exit=True)

@@ -50,7 +50,7 @@ def main():
     block = a.block or adist.scene_block(a.scenes * S, S, world)
     assert mine == adist.shard_units(a.scenes * S, rank, world, block) and all((u // block) % world == rank for u in mine)
     torch.cuda.synchronize(dev)
-    if world > 1:                                      # the overlapped form (side stream + event) must deliver the same bytes
+    if adist.grouped():                                # the overlapped form (side stream + event) must deliver the same bytes
         side = torch.cuda.Stream(dev)
         full2, mine2, done = render_scenes_sharded(rend, gather=True, stream=side, block=a.block)
         torch.cuda.current_stream(dev).wait_event(done)
@@ -92,7 +92,9 @@ def main():
             torch.manual_seed(sc)
             stacks.append(render_focal_stack_m1(lens, img, dbar, fds, GRID, KS, SPP)[0].permute(1, 0, 2, 3).cpu().numpy().copy())   # [S,3,H,W]
         np.save(os.path.join(a.out, "plain_stacks.npy"), np.concatenate(stacks, 0))
-    if world > 1:
+    if adist.grouped():
+        t = adist.all_reduce_max(float(rank + 1))          # device tensor under RCCL, host tensor under gloo
+        assert t == float(world), t
         dist.barrier()
         dist.destroy_process_group()
 

@@ -11,7 +11,8 @@ above the 1e-4 budget that the whole stack meets with margin.
 
 Stored: per-slice floors (PSF map and rendered image, rel-L2 fp32 vs fp64) and the float64 PSF maps of three slices
 (one quiet, the two noisiest) so that the GPU tests can report error-vs-truth next to error-vs-reference.
-Usage: python tests/golden/make_floor.py      (~90 s on 8 cores; needs no reference checkout)
+Usage: python tests/golden/make_floor.py [g13] [g13b]     (~90 s per case on 8 cores; needs no reference checkout;
+       g13b = the four further (seed, scene) cases of fixture G9b, floors only)
 """
 import os
 import sys
@@ -33,40 +34,61 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))
 
 
-def main():
+def floors(case, fixture):
+    """Per-slice and whole-stack fp32 floors of case k (scene seeds 1234 + k / 5678 + k, generator seed k)."""
     H = W = 1024
-    img = torch.from_numpy(synth_rgb(H, W, seed=1234))[None]
-    depth = synth_depth_mm(H, W, seed=5678)
+    img = torch.from_numpy(synth_rgb(H, W, seed=1234 + case))[None]
+    depth = synth_depth_mm(H, W, seed=5678 + case)
     dbar, fds = -float(depth.mean()), -np.linspace(depth.min(), depth.max(), 10)
-    g9 = np.load(os.path.join(HERE, "g9_stack_m1_1024.npz"))
+    g9 = np.load(os.path.join(HERE, fixture))
     lp = os.path.join(REPO, "lenses", "rf50mm", "lens.json")
+    torch.set_default_dtype(torch.float32)
     lens = OracleLens(lp, sensor_res=(H, W))
-    torch.manual_seed(0)
+    torch.manual_seed(case)
     im32 = []
     for k, f in enumerate(fds):
         lens.refocus(float(f))
         pm = lens.psf_map(depth=dbar, grid=11, ks=11, spp=2048)
-        assert np.abs(pm.numpy() - g9["psf_maps"][k]).max() <= 1e-6, "float32 oracle must reproduce G9"
+        assert np.abs(pm.numpy() - g9["psf_maps"][k]).max() <= 1e-6, f"float32 oracle must reproduce {fixture}"
         im32.append(oconv.render_psf_map(img, pm, 11)[0].numpy())
     torch.set_default_dtype(torch.float64)
     draw = torch.rand
     torch.rand = lambda *a, **k: draw(*a, dtype=torch.float32, **k).double()      # same float32 draws, same order
-    lens = OracleLens(lp, sensor_res=(H, W))
-    torch.manual_seed(0)
-    psf_floor, img_floor, maps64 = [], [], []
-    for k, f in enumerate(fds):
-        lens.refocus(float(f))
-        pm = lens.psf_map(depth=dbar, grid=11, ks=11, spp=2048)
-        im = oconv.render_psf_map(img.double(), pm, 11)[0].numpy()
-        psf_floor.append(rel(g9["psf_maps"][k], pm.numpy()))
-        img_floor.append(rel(im32[k], im))
-        maps64.append(pm.numpy())
-        print(f"slice {k} focus {f:8.1f}: PSF floor {psf_floor[-1]:.3e}  image floor {img_floor[-1]:.3e}", flush=True)
-    order = np.argsort(img_floor)
-    keep = sorted({int(order[0]), int(order[-1]), int(order[-2])})
-    np.savez_compressed(os.path.join(HERE, "g13_fp32_floor.npz"), psf_floor=np.array(psf_floor), img_floor=np.array(img_floor),
-                        truth_slices=np.array(keep), truth_maps=np.stack([maps64[k] for k in keep]).astype(np.float32),
-                        stack_img_floor=np.float64(rel(np.stack(im32), np.stack([oconv.render_psf_map(img.double(), torch.from_numpy(m), 11)[0].numpy() for m in maps64]))))
+    try:
+        lens = OracleLens(lp, sensor_res=(H, W))
+        torch.manual_seed(case)
+        psf_floor, img_floor, maps64 = [], [], []
+        for k, f in enumerate(fds):
+            lens.refocus(float(f))
+            pm = lens.psf_map(depth=dbar, grid=11, ks=11, spp=2048)
+            im = oconv.render_psf_map(img.double(), pm, 11)[0].numpy()
+            psf_floor.append(rel(g9["psf_maps"][k], pm.numpy()))
+            img_floor.append(rel(im32[k], im))
+            maps64.append(pm.numpy())
+            print(f"case {case} slice {k} focus {f:8.1f}: PSF floor {psf_floor[-1]:.3e}  image floor {img_floor[-1]:.3e}", flush=True)
+        stack = rel(np.stack(im32), np.stack([oconv.render_psf_map(img.double(), torch.from_numpy(m), 11)[0].numpy() for m in maps64]))
+    finally:
+        torch.rand = draw
+        torch.set_default_dtype(torch.float32)
+    return np.array(psf_floor), np.array(img_floor), maps64, stack
+
+
+def main():
+    what = sys.argv[1:] or ["g13"]
+    if "g13" in what:
+        psf_floor, img_floor, maps64, stack = floors(0, "g9_stack_m1_1024.npz")
+        order = np.argsort(img_floor)
+        keep = sorted({int(order[0]), int(order[-1]), int(order[-2])})
+        np.savez_compressed(os.path.join(HERE, "g13_fp32_floor.npz"), psf_floor=psf_floor, img_floor=img_floor,
+                            truth_slices=np.array(keep), truth_maps=np.stack([maps64[k] for k in keep]).astype(np.float32),
+                            stack_img_floor=np.float64(stack))
+    if "g13b" in what:
+        # G13b (round 4): the same floors for the (seed, scene) cases of G9b, numbers only
+        cases, rows = (1, 2, 3, 4), {}
+        for c in cases:
+            pf, imf, _, stack = floors(c, f"g9b_case{c}.npz")
+            rows[f"psf_floor_{c}"], rows[f"img_floor_{c}"], rows[f"stack_img_floor_{c}"] = pf, imf, np.float64(stack)
+        np.savez_compressed(os.path.join(HERE, "g13b_fp32_floor_cases.npz"), cases=np.array(cases), **rows)
 
 
 if __name__ == "__main__":

@@ -317,6 +317,35 @@ def g6_g7_psfnet():
     np.savez_compressed(f"{HERE}/g6_g7_psfnet.npz", **out)
 
 
+def g7b_config5_stack():
+    """G7b (round 4): BASELINE.json config 5's render at ITS size - configs/aber_aware_dff_dfv.yml:19-21 (bs 2, n_stack 8,
+    res 480x640, ks 11) through the loop of 2_aber_aware_dff_dfv.py:101-107: select_focus_dist(depth, 8, 'linear') then
+    PSFNet.render(aif, -depth*1e3, -foc_dist*1e3) per slice, stacked on dim 2.  Procedural weights (aadff.synth.mlp_state_dict) and
+    scenes; stored: the focus distances, three 64x64 crops, 16x16 block means and fp64 sums of every (sample, slice)."""
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    spec = importlib.util.spec_from_file_location("ref_dff_utils", f"{REF}/dff/utils.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    H, W, B, S = 480, 640, 2, 8
+    lens = PSFNet(filename=f"{REF}/lenses/rf50mm/lens.json", sensor_res=(H, W), kernel_size=11, device="cpu")
+    lens.psfnet.load_state_dict({k: torch.from_numpy(v) for k, v in mlp_state_dict(seed=4321).items()})
+    aif = torch.from_numpy(np.stack([synth_rgb(H, W, seed=31 + b) for b in range(B)]))
+    depth = torch.from_numpy(np.stack([synth_depth_mm(H, W, seed=41 + b) for b in range(B)]))[:, None] / 1e3      # metres
+    focus_dists = mod.select_focus_dist(depth, S, mode="linear")
+    crops, blocks, sums = {"a": [], "b": [], "c": []}, [], []
+    for i in range(S):
+        with torch.no_grad():
+            sl = lens.render(aif, depth=-depth * 1e3, foc_dist=-focus_dists[:, i] * 1e3).numpy()        # [B,3,H,W]
+        crops["a"].append(sl[:, :, 0:64, 0:64])
+        crops["b"].append(sl[:, :, 208:272, 288:352])
+        crops["c"].append(sl[:, :, 416:480, 576:640])
+        blocks.append(sl.astype(np.float64).reshape(B, 3, H // 16, 16, W // 16, 16).mean((3, 5)).astype(np.float32))
+        sums.append(sl.astype(np.float64).sum((2, 3)))
+        print("G7b slice", i, flush=True)
+    np.savez_compressed(f"{HERE}/g7b_config5_stack.npz", focus_dists=focus_dists.numpy(), block_means=np.stack(blocks, 2),
+                        sums=np.stack(sums, 2), **{f"crop_{k}": np.stack(v, 2) for k, v in crops.items()})
+
+
 def g8_focal_stack_m1():
     """Config-0 scale M1 stack: 256^2, 5 slices, seed 0: per slice refocus -> psf_map -> render_psf_map."""
     H = W = 256
@@ -339,32 +368,51 @@ def g8_focal_stack_m1():
                         crop=stack[:, :, 96:160, 96:160], sums=stack.astype(np.float64).sum((2, 3)))
 
 
-def g9_stack_m1_full():
-    """The bench workload itself (BASELINE.json configs[1]): rf50mm, 1024^2, 10 focus distances, grid 11, ks 11,
-    spp 2048, seed 0 — same image / depth plane / focus list as bench.py.  Stored: PSF maps, d_sensor per slice,
-    three 64x64 crops per slice (patch seam, centre, corner), 16x16 block means of every slice, fp64 sums."""
+def _g9_case(case, out_name):
+    """Case k of the bench workload: torch.manual_seed(k), scene = synth_rgb(seed 1234 + k) / synth_depth_mm(seed 5678 + k) (k = 0 is
+    bench.py's stack).  Stored: PSF maps, d_sensor / hfov per slice, three 64x64 crops per slice (patch seam, centre, corner), 16x16
+    block means of every slice, fp64 sums."""
     H = W = 1024
     lens = Lensgroup(filename=f"{REF}/lenses/rf50mm/lens.json", sensor_res=(H, W), device=CPU)
-    img = torch.from_numpy(synth_rgb(H, W, seed=1234))[None]
-    depth = synth_depth_mm(H, W, seed=5678)
+    img = torch.from_numpy(synth_rgb(H, W, seed=1234 + case))[None]
+    depth = synth_depth_mm(H, W, seed=5678 + case)
     dbar = -float(depth.mean())
     fds = -np.linspace(depth.min(), depth.max(), 10)
-    torch.manual_seed(0)
-    maps, dsens, crops, blocks, sums = [], [], {"seam": [], "centre": [], "corner": []}, [], []
+    torch.manual_seed(case)
+    maps, dsens, hfovs, crops, blocks, sums = [], [], [], {"seam": [], "centre": [], "corner": []}, [], []
     for f in fds:
         lens.refocus(float(f))
         pm = lens.psf_map(depth=dbar, grid=11, ks=11, spp=GEO_SPP)
         sl = ref_render.render_psf_map(img, pm, 11)[0].numpy()           # [3,H,W]
         maps.append(pm.numpy())
         dsens.append(lens.d_sensor)
+        hfovs.append(lens.hfov)
         crops["seam"].append(sl[:, 61:125, 154:218])                       # patch borders at 93 and 186
         crops["centre"].append(sl[:, 480:544, 480:544])
         crops["corner"].append(sl[:, 960:1024, 960:1024])
         blocks.append(sl.astype(np.float64).reshape(3, 64, 16, 64, 16).mean((2, 4)).astype(np.float32))
         sums.append(sl.astype(np.float64).sum((1, 2)))
-    np.savez_compressed(f"{HERE}/g9_stack_m1_1024.npz", fds=fds, dbar=np.float64(dbar), d_sensor=np.array(dsens),
+    extra = {} if case == 0 else {"hfov": np.array(hfovs), "case": np.int64(case)}       # G9 keeps its round-2 key set (bit-identical file)
+    np.savez_compressed(f"{HERE}/{out_name}", fds=fds, dbar=np.float64(dbar), d_sensor=np.array(dsens),
                         psf_maps=np.stack(maps), sums=np.stack(sums), block_means=np.stack(blocks, 1),
-                        **{f"crop_{k}": np.stack(v, 1) for k, v in crops.items()})
+                        **{f"crop_{k}": np.stack(v, 1) for k, v in crops.items()}, **extra)
+
+
+def g9_stack_m1_full():
+    """The bench workload itself (BASELINE.json configs[1]): rf50mm, 1024^2, 10 focus distances, grid 11, ks 11,
+    spp 2048, seed 0 — same image / depth plane / focus list as bench.py."""
+    _g9_case(0, "g9_stack_m1_1024.npz")
+
+
+G9B_CASES = (1, 2, 3, 4)
+
+
+def g9b_more_seeds_and_scenes():
+    """G9b (round 4): the same workload for four further (generator seed, scene) pairs - the reference draws new pupil samples in
+    every call (deeplens/optics.py:480-481), so one stack pins one realisation of the Monte-Carlo noise only."""
+    for k in G9B_CASES:
+        _g9_case(k, f"g9b_case{k}.npz")
+        print("G9b case", k, flush=True)
 
 
 def g10_training_data():
@@ -529,8 +577,8 @@ def g15_ai_degree4():
                         psf_map=pm.numpy(), d_sensor=np.float64(lens.d_sensor), hfov=np.float64(lens.hfov))
 
 ALL = [("G1", lambda: g1_scalars()), ("G2/G3", lambda: g2_g3_trace_and_splat()), ("G4", lambda: g4_psf_map()),
-       ("G5", lambda: g5_conv()), ("G6/G7", lambda: g6_g7_psfnet()), ("G8", lambda: g8_focal_stack_m1()),
-       ("G9", lambda: g9_stack_m1_full()), ("G10", lambda: g10_training_data()),
+       ("G5", lambda: g5_conv()), ("G6/G7", lambda: g6_g7_psfnet()), ("G7B", lambda: g7b_config5_stack()), ("G8", lambda: g8_focal_stack_m1()),
+       ("G9", lambda: g9_stack_m1_full()), ("G9B", lambda: g9b_more_seeds_and_scenes()), ("G10", lambda: g10_training_data()),
        ("G11", lambda: g11_ckpt_activation_range()), ("G12", lambda: g12_select_focus_dist()), ("G14", lambda: g14_glass()), ("G15", lambda: g15_ai_degree4())]
 
 if __name__ == "__main__":

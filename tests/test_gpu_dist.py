@@ -126,3 +126,34 @@ def test_config5_ddp_consumer_on_hip_rendered_stacks_two_emulated_ranks(tmp_path
     a, b = (torch.load(tmp_path / f"config5_rank{r}.pt") for r in range(2))
     assert all(torch.equal(x, y) for x, y in zip(a["params"], b["params"])), "DDP ranks ended with different consumer weights"
     assert np.isfinite(a["loss"]) and np.isfinite(b["loss"]) and a["loss"] != b["loss"]      # different scenes per rank
+
+
+@pytest.mark.timeout(900)
+def test_rccl_branch_on_a_one_rank_group(tmp_path):
+    """Everything that only exists under RCCL, executed once on the one GPU (AADFF_FORCE_GROUP=1 forms a ONE-rank `nccl` group):
+    `init_process_group("nccl", device_id=...)`, the IN-PLACE per-row all-gather whose send buffer aliases the receive buffer
+    (aadff.dist.gather_row), the side-stream form, GatherRing, all_reduce_max on a device tensor, barrier and teardown - through
+    the sharded renderer (every gathered unit equal to the plain per-scene stack) and through `bench.py --gather` / `--mode c3`.
+    The multi-rank tests above run over gloo (RCCL refuses two ranks per device); this one makes sure that the first real
+    `bench.py --gpus 8 [--mode c3] [--gather]` cannot fail on something a single GPU would have shown."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "AADFF_EMULATE_RANKS")}
+    env.update(AADFF_FORCE_GROUP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(HERE, "dist_gpu_worker.py")
+    for extra in ([], ["--block", "1", "--streams", "2"]):
+        args = [worker, "--out", str(tmp_path), "--scenes", "4", "--res", "128", "--slices", "10", "--check-inproc"] + extra
+        p = subprocess.run([sys.executable] + args, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        rec = json.load(open(tmp_path / "check_w1_r0.json"))
+        assert rec["units"] == 40 and rec["worst_abs_diff"] <= 5e-6 and rec["mean_abs_pixel"] > 0.05
+        print(f"\none-rank RCCL group {extra}: 40 units gathered in place, worst |gathered - plain| = {rec['worst_abs_diff']:.2e}")
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gather", "--steps", "6", "--warmup", "2", "--spinup-s", "0.05",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["n_gpus"] == 1 and rec["config"]["gather"] is True and not rec["config"]["ranks_emulated_on_one_gpu"] and rec["value"] > 0
+    env["AADFF_C3_SCENES"] = "4"
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--mode", "c3", "--steps", "3", "--warmup", "1", "--spinup-s", "0.05"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["config"]["gather"] is True and rec["config"]["gathered_shape"] == [40, 3, 1024, 1024] and rec["value"] > 0

@@ -137,6 +137,33 @@ def test_render_psf_map_stack_slice_batched_path_vs_oracle(B, H, W, g, S):
         assert np.abs(got[:, :, s] - want).max() <= 4e-6 * 40, f"slice {s}"
 
 
+@pytest.mark.parametrize("B,Cn,H,W,g,S,ks", [(1, 3, 50, 50, 3, 1, 11), (2, 3, 97, 131, 1, 1, 11), (1, 3, 64, 230, 1, 2, 11), (1, 1, 33, 40, 4, 2, 11),
+                                             (1, 3, 201, 97, 2, 1, 9), (1, 4, 120, 120, 11, 1, 11), (1, 3, 25, 300, 2, 2, 9), (1, 3, 203, 203, 2, 1, 11),
+                                             (1, 3, 61, 83, 3, 7, 9)])
+def test_render_psf_map_block_gemm_path_vs_oracle_and_toeplitz(B, Cn, H, W, g, S, ks, monkeypatch):
+    """Lone slices and pairs at ks 9 / 11 (round 4: `conv_psf_map_blk_kernel`, a 4 x 4 block of output pixels on the MFMA M
+    dimension): patches wider than one 96-column tile, column blocks cut by the patch border inside a 4-pixel store, bands shorter
+    than 24 rows and 8-row groups cut by the patch border, odd patch origins (16-byte stores at 4-byte alignment), B > 1, C != 3,
+    inputs far from [0, 1] (tile pre-scale) and a 1e-3 PSF (tap pre-scale).  Oracle = the reference's loop; and the Toeplitz
+    form (AADFF_CONV_PATH=toeplitz), which carries the same exact operand split, to 1e-6 of the data range."""
+    rng = np.random.Generator(np.random.PCG64(B * 1000 + H * 7 + W + S + ks))
+    img = tt(rng.random((B, Cn, H, W), dtype=np.float32)) * 37.5 - 3.0
+    maps = tt(rng.random((S, Cn, g * ks, g * ks), dtype=np.float32)) / (ks * ks)
+    maps[S // 2, 0] *= 1e-3
+    got = rp.render_psf_map_stack(img.to(DEV), maps.to(DEV), g)
+    assert got.shape == (B, Cn, S, H, W)
+    one = rp.render_psf_map(img.to(DEV), maps[0].to(DEV), g)
+    assert torch.equal(one, got[:, :, 0])                                      # the single-slice entry is the same launch with S = 1
+    monkeypatch.setenv("AADFF_CONV_PATH", "toeplitz")
+    toe = rp.render_psf_map_stack(img.to(DEV), maps.to(DEV), g)
+    monkeypatch.delenv("AADFF_CONV_PATH")
+    assert (toe - got).abs().max().item() <= 4e-6 * 40
+    gotn = got.cpu().numpy()
+    for s in range(S):
+        want = oconv.render_psf_map(img, maps[s], g).numpy()
+        assert np.abs(gotn[:, :, s] - want).max() <= 4e-6 * 40, f"slice {s}"
+
+
 @pytest.mark.parametrize("Cn", [1, 2, 4, 6])
 def test_channel_counts_other_than_three_vs_oracle(Cn):
     """The reference's functions are channel-generic (depthwise conv2d with groups = C; the gather stacks the kernel C
@@ -428,10 +455,12 @@ def test_square_aperture_is_refused_cleanly():
     path; they cannot come from a lens file (read_lens_json never passes the flag) and the constructors say so."""
     from deeplens.surfaces import Aspheric, Surface
     for make in (lambda: Surface(5.0, 0.0, "air", "air", is_square=True, device="cpu"),
-                 lambda: Aspheric(5.0, 0.0, c=0.0, mat1="air", mat2="air", is_square=True, device="cpu"),
                  lambda: Aspheric(5.0, 0.0, c=0.0, mat1="air", mat2="air", square=True, device="cpu")):
         with pytest.raises(NotImplementedError, match="square apertures"):
             make()
+    # the reference overwrites `is_square` with `square` (surfaces.py:330): is_square=True alone leaves a ROUND aperture
+    s = Aspheric(5.0, 0.0, c=0.0, mat1="air", mat2="air", is_square=True, device="cpu")
+    assert s.is_square is False and s.h == pytest.approx(5.0 * np.sqrt(2))
 
 
 # ================================================================= G2/G3: trace and splat

@@ -249,6 +249,71 @@ def test_star_import_surface_of_the_reference_scripts():
     assert ns["nn"].DataParallel is torch.nn.DataParallel          # 2_aber_aware_dff_aif.py:67 resolves it this way
 
 
+def test_dff_star_import_surface_of_the_reference_scripts():
+    """`from dff import *` (2_aber_aware_dff_aif.py:25, 2_aber_aware_dff_dfv.py:25; reference dff/__init__.py:1-6) binds what the
+    scripts use from the rendering side (:57 get_lens, :73 get_dataset, :106 select_focus_dist) and, for the consumer-side names
+    (AiFDepthNet :66, the mask_* metrics :194-214), stubs that say where they come from."""
+    ns = {}
+    exec("from dff import *", ns)
+    for name in ("get_lens", "get_dataset", "select_focus_dist", "Matterport3D", "FlyingThings3D", "Middlebury", "RealWorld",
+                 "dataset", "factory", "utils", "PSFNet", "ThinLens", "AiFDepthNet", "mask_abs_rel", "mask_psnr", "mask_ssim"):
+        assert name in ns, name
+    import dff
+    assert ns["select_focus_dist"] is select_focus_dist and ns["get_lens"] is dff.factory.get_lens
+    if not os.environ.get("AADFF_REFERENCE_ROOT"):
+        with pytest.raises(ImportError, match="AADFF_REFERENCE_ROOT"):
+            ns["AiFDepthNet"](n_stack=5)
+        with pytest.raises(ImportError, match="dff/metrics.py"):
+            ns["mask_abs_rel"](None, None, None)
+
+
+def test_reference_scripts_run_on_this_package_through_the_launcher(tmp_path):
+    """a script inside a checkout that has its OWN deeplens/ and dff/ (like the reference's) runs on this package
+    through `python -m aadff.run_script`; started directly, CPython resolves the checkout's packages first (the reason for the
+    launcher).  The checkout's consumer modules (dff/AiFNet.py, DFV_models/) are still the checkout's."""
+    import subprocess
+    import sys
+    co = tmp_path / "checkout"
+    (co / "deeplens").mkdir(parents=True)
+    (co / "dff").mkdir()
+    (co / "DFV_models").mkdir()
+    (co / "configs").mkdir()
+    (co / "deeplens" / "__init__.py").write_text("")
+    (co / "deeplens" / "psfnet.py").write_text("WHO = 'checkout'\n")
+    (co / "deeplens" / "utils.py").write_text("def set_seed(s): pass\ndef set_logger(d): pass\n")
+    (co / "dff" / "__init__.py").write_text("WHO_DFF = 'checkout'\n")
+    (co / "dff" / "AiFNet.py").write_text("class AiFDepthNet:\n    def __init__(self, n_stack): self.n_stack = n_stack\n")
+    (co / "DFV_models" / "__init__.py").write_text("class DFVNet:\n    pass\n")
+    (co / "configs" / "c.yml").write_text("n_stack: 5\n")
+    (co / "script.py").write_text(
+        "import json, os, sys\n"
+        "from deeplens.utils import set_seed, set_logger\n"
+        "from deeplens.psfnet import *\n"
+        "from dff import *\n"
+        "from DFV_models import DFVNet\n"
+        "import deeplens, dff, DFV_models\n"
+        "g = globals()\n"
+        "json.dump({'deeplens': deeplens.__file__, 'dff': dff.__file__, 'dfv': DFV_models.__file__, 'who': g.get('WHO'),\n"
+        "           'names': [k for k in ('PSFNet', 'get_lens', 'get_dataset', 'select_focus_dist', 'nn', 'AiFDepthNet', 'DFVNet') if k in g],\n"
+        "           'net': (AiFDepthNet(n_stack=5).n_stack if 'AiFDepthNet' in g else None), 'cfg': os.path.exists('configs/c.yml'),\n"
+        "           'argv': sys.argv[1:]}, open(sys.argv[1], 'w'))\n")
+    from conftest import PKG
+    env = {k: v for k, v in os.environ.items() if k != "AADFF_REFERENCE_ROOT"}
+    env["PYTHONPATH"] = PKG
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
+    out = tmp_path / "via_launcher.json"
+    subprocess.run([sys.executable, "-m", "aadff.run_script", str(co / "script.py"), str(out), "--flag"], check=True, env=env,
+                   cwd=str(tmp_path), timeout=300)
+    r = json.load(open(out))
+    assert r["deeplens"].startswith(PKG) and r["dff"].startswith(PKG) and r["dfv"].startswith(str(co)), r
+    assert r["names"] == ["PSFNet", "get_lens", "get_dataset", "select_focus_dist", "nn", "AiFDepthNet", "DFVNet"] and r["who"] is None
+    assert r["net"] == 5 and r["cfg"] is True and r["argv"] == [str(out), "--flag"]
+    out2 = tmp_path / "direct.json"                      # the recipe INTEGRATION.md used to give: PYTHONPATH alone does not win
+    subprocess.run([sys.executable, str(co / "script.py"), str(out2)], check=True, env=env, cwd=str(co), timeout=300)
+    r2 = json.load(open(out2))
+    assert r2["deeplens"].startswith(str(co)) and r2["who"] == "checkout"
+
+
 def test_custom_ops_are_registered_with_shape_functions():
     """torch.ops.aadff.* (aadff/ops.py): schemas exist, the fake/meta implementations infer the output shapes, and a CPU
     call fails loudly (no CPU fallback)."""

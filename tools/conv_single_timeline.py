@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-workgroup timeline of a LONE-SLICE render_psf_map launch (Toeplitz MFMA kernel; instrumentation build
+"""Per-workgroup timeline of a LONE-SLICE render_psf_map launch (block-GEMM kernel, or the Toeplitz MFMA kernel with
+AADFF_CONV_PATH=toeplitz; instrumentation build
 csrc/libaadff_sbtrace.so): every workgroup stamps the 100 MHz real-time counter at its start (0), when its image loads have
 arrived (1), when the tile is in LDS (2), when its tap rows are in LDS (3), after its last MFMA (4) and when its stores have
 retired (5).  Prints when workgroups start and how long each phase takes inside the full launch.
@@ -34,7 +35,7 @@ def main():
     rng = np.random.Generator(np.random.PCG64(3))
     maps = torch.from_numpy(rng.random((3, G * KS, G * KS), dtype=np.float32)).to(dev) / 121
     out = torch.empty((1, 3, H, W), device=dev)
-    n_wg = (3 * G) * (3 * G) * 3                      # 3 x 3 tiles of 32 x 32 per 93-pixel patch, 3 channels
+    n_wg = 16384                                      # upper bound: Toeplitz form 3 267 workgroups (32 x 32 tiles), block-GEMM form 1 452 (24 x 96 bands)
     buf = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
     lib.aadff_sb_trace_buffer.argtypes = [C.c_void_p]
     st = _abi.stream_ptr(dev)
