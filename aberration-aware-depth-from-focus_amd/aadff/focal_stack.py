@@ -30,7 +30,10 @@ def select_focus_dist(depth, num, mode="linear", center=True):
     big = torch.where(depth > 0, depth, torch.full_like(depth, float("inf")))
     dmin = torch.amin(big, dim=(1, 2, 3))
     if mode == "linear":
-        f = [dmin + i * (dmax - dmin) / (num - 1) for i in range(num)]
+        # the reference divides a CPU tensor by the Python scalar num - 1: an IEEE division; on the GPU ATen turns tensor / scalar
+        # into tensor * (1 / scalar) (one ulp off for some values) - dividing by a TENSOR keeps the IEEE division on both devices
+        den = torch.full_like(dmax, float(num - 1))
+        f = [dmin + (i * (dmax - dmin)) / den for i in range(num)]
     elif mode == "importance":
         avg = torch.sum(depth, dim=(1, 2, 3)) / torch.sum(depth > 0, dim=(1, 2, 3))
         f = [dmax, dmin]
@@ -221,9 +224,13 @@ def _conv_into_units(x, maps, dest, B, C_, S, H, W, grid, ks, st):
 
 
 def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp):
-    """PSF maps [S,3,g*ks,g*ks] of a strict-parity lens by the reference's loop: refocus(f_k) then psf_map, slice by slice, in
-    the reference's host-RNG order (2_aber_aware_dff_aif.py:104-114 with deeplens/optics.py:779-783)."""
-    return torch.stack([(lens.refocus(f), lens.psf_map(depth=depth_plane_mm, grid=grid, ks=ks, spp=spp))[1] for f in focus])
+    """PSF maps [S,3,g*ks,g*ks] of a strict-parity lens in the reference's host-RNG order (2_aber_aware_dff_aif.py:104-114 with
+    deeplens/optics.py:779-783): three batched traces for the whole stack (aadff/strict_stack.py); AADFF_STRICT_BATCHED=0 runs
+    the reference's loop call by call (refocus(f_k) then psf_map per slice, 72 single traces per slice) - same result."""
+    from . import strict_stack
+    if os.environ.get("AADFF_STRICT_BATCHED", "1") == "0":
+        return strict_stack.strict_psf_maps_loop(lens, depth_plane_mm, focus, grid, ks, spp)
+    return strict_stack.strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp)
 
 
 @torch.no_grad()

@@ -32,7 +32,20 @@ struct PatchBounds {
     // ceil(2^32 / d) for the uniform block-index decompositions: n / d == __umulhi(n, magic) for
     // n < 65536 (integer division has no scalar form on gfx950 and costs ~15 VALU slots each)
     unsigned m_ntx, m_nty, m_nchunk, m_c;
+    // XCD-aware block order (xcd_remap): 1-D launches only.  gx, gy = logical grid extents; N = 8 xcd_q + xcd_r blocks (xcd_q = 0: plain order)
+    unsigned gx, gy, xcd_q, xcd_r;
+    int stagger;        // start delay by residency slot (units of s_sleep 32), 0 = none
 };
+
+// Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8; observed, not promised: speed only), each with an L2 of
+// its own.  Neighbouring bands share halo rows / columns (34 x 108 staged for 24 x 96 rendered: 1.6x), so with the plain order
+// every XCD's L2 fetches its halos from the fabric again (FETCH_SIZE 20 MB for a 12.6 MB image).  Remapped, XCD k works on the
+// k-th CONTIGUOUS eighth of the logical block order, whose neighbours then hit in that XCD's L2.
+// id = k + 8 j  ->  logical index start_k + j,  start_k = k q + min(k, r),  N = 8 q + r.
+__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned q, unsigned r) {
+    const unsigned k = id & 7u, j = id >> 3;
+    return k * q + (k < r ? k : r) + j;
+}
 
 __host__ __device__ inline unsigned magic_of(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }
 __device__ __forceinline__ int udiv_magic(unsigned n, unsigned d, unsigned magic) { return d == 1 ? (int)n : (int)__umulhi(n, magic); }
@@ -860,6 +873,7 @@ constexpr int TCOLS = 96, WCOLS = TCOLS + 12, WDW = WCOLS / 2, RB = 24, THP = RB
 constexpr int RPP = 240, LO = 112;        // row-pair pitch, offset of the lo plane (dwords)
 constexpr int TROWS = 17, TPD = 11;       // padded tap rows (a = -3 .. 13), dwords per row (b = -3 .. 18 as halves)
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));       // 16-byte store at 4-byte alignment
 }  // namespace blk
 
 template <int KS, bool TIMED = false>
@@ -877,9 +891,17 @@ __global__ __launch_bounds__(64 * blk::NW, 5) void conv_psf_map_blk_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pj = udiv_magic(blockIdx.x, ntx, pb.m_ntx), tx = blockIdx.x - pj * ntx;
-    const int pi = udiv_magic(blockIdx.y, nty, pb.m_nty), ty = blockIdx.y - pi * nty;
-    const int bc = udiv_magic(blockIdx.z, S, pb.m_nchunk), s = blockIdx.z - bc * S;
+    if (pb.stagger) {
+        const int slot = (int)((blockIdx.x >> 8) % 6u);       // workgroups ~256 linear ids apart share a CU
+        for (int i = 0; i < slot * pb.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+    // 1-D launch in XCD-aware order: logical index -> (x fastest, then y, then plane / slice)
+    const unsigned lin = pb.xcd_q ? xcd_remap(blockIdx.x, pb.xcd_q, pb.xcd_r) : blockIdx.x;
+    const unsigned lrow = lin / pb.gx, bx = lin - lrow * pb.gx;                     // exact divisions (wave-uniform, twice per workgroup)
+    const unsigned bz = lrow / pb.gy, by = lrow - bz * pb.gy;
+    const int pj = udiv_magic(bx, ntx, pb.m_ntx), tx = bx - pj * ntx;
+    const int pi = udiv_magic(by, nty, pb.m_nty), ty = by - pi * nty;
+    const int bc = udiv_magic(bz, S, pb.m_nchunk), s = bz - bc * S;
     const int c = bc - udiv_magic(bc, C, pb.m_c) * C;
     const int x_hi = pb.wb[pj + 1], y_hi = pb.hb[pi + 1];
     const int x0 = pb.wb[pj] + tx * TCOLS, y0 = pb.hb[pi] + ty * RB;
@@ -902,15 +924,27 @@ __global__ __launch_bounds__(64 * blk::NW, 5) void conv_psf_map_blk_kernel(
     {
         const float* plane = img + (size_t)bc * H * W;
         const int xa = reflect_idx(x0 - PAD + 2 * lane, W), xb = reflect_idx(x0 - PAD + 2 * lane + 1, W);
+        // a lane's pixel pair is one 8-byte load wherever the two pixels are neighbours in memory (everywhere but at the
+        // reflected image borders): half the load instructions and half the cache-line look-ups of the staging
+        const bool adj = xb == xa + 1;
 #pragma unroll
         for (int e = 0; e < NPT; ++e) {
             const int r = wave + e * NW;
             const bool in = lane < WDW && r < THP;
             const float* row = plane + (size_t)reflect_idx(y0 - PAD + r, H) * W;
-            v0[e] = in ? row[xa] : 0.f;
-            v1[e] = in ? row[xb] : 0.f;
-            amax = fmaxf(amax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
+            v0[e] = 0.f; v1[e] = 0.f;
+            if (in) {
+                if (adj) {
+                    const sb::f2u t = *reinterpret_cast<const sb::f2u*>(row + xa);
+                    v0[e] = t.x; v1[e] = t.y;
+                } else {
+                    v0[e] = row[xa];
+                    v1[e] = row[xb];
+                }
+            }
         }
+#pragma unroll
+        for (int e = 0; e < NPT; ++e) amax = fmaxf(amax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
     }
     if (wave == 0) {
         // zero-padded fp16 hi/lo taps: tap (a, b) at half index (a + 3) * 2 TPD + (b + 3)
@@ -984,7 +1018,9 @@ __global__ __launch_bounds__(64 * blk::NW, 5) void conv_psf_map_blk_kernel(
     AADFF_SB_STAMP(2);
     AADFF_SB_STAMP(3);
 
-    // ---- matrix phase: column block `wave` of the band, groups of 8 rows ----
+    // ---- matrix phase: column block `wave` of the band, groups of 8 rows x 7 k-steps.  (Measured, round 4: hand-pipelined
+    //      operand reads - inline asm two steps ahead through three buffers, as in the slice-batched kernel - are SLOWER here,
+    //      15.2 against 14.6 us: with 17 waves per CU the other waves already cover a step's LDS latency.) ----
     const int ry = n >> 3, cx = n & 7;
     const int xw = x0 + 32 * wave;
     if (xw < x_hi) {
@@ -1012,7 +1048,7 @@ __global__ __launch_bounds__(64 * blk::NW, 5) void conv_psf_map_blk_kernel(
                 if (y < y_hi) {
                     float* o = obase + (size_t)y * W;
                     const float a0 = acc[0] * inv, a1 = acc[1] * inv, a2 = acc[2] * inv, a3 = acc[3] * inv;
-                    if (full) *reinterpret_cast<f4u*>(o) = (f4u){a0, a1, a2, a3};
+                    if (full) *reinterpret_cast<float4u*>(o) = (float4u){a0, a1, a2, a3};
                     else {
                         if (x < x_hi) o[0] = a0;
                         if (x + 1 < x_hi) o[1] = a1;
@@ -1160,11 +1196,16 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
                 mw = std::max(mw, pb.wb[i + 1] - pb.wb[i]);
             }
             const int bntx = (mw + blk::TCOLS - 1) / blk::TCOLS, bnty = (mh + blk::RB - 1) / blk::RB;
-            if ((size_t)bnty * grid <= 65535) {
+            const size_t gx = (size_t)bntx * grid, gy = (size_t)bnty * grid, total = gx * gy * B * C * S;
+            if (total < ((size_t)1 << 31)) {
                 PatchBounds pbb = pb;
                 pbb.m_ntx = magic_of(bntx); pbb.m_nty = magic_of(bnty); pbb.m_nchunk = magic_of(S); pbb.m_c = magic_of(C);
-                dim3 gb(bntx * grid, bnty * grid, B * C * S);
-                hipLaunchKernelGGL((conv_psf_map_blk_kernel<KS>), gb, dim3(64 * blk::NW), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, bntx, bnty, pbb);
+                pbb.gx = (unsigned)gx; pbb.gy = (unsigned)gy;
+                static const bool xcd = [] { const char* e = getenv("AADFF_CONV_XCD"); return !(e && e[0] == '0'); }();
+                pbb.xcd_q = xcd && total >= 64 ? (unsigned)(total / 8) : 0u;
+                pbb.xcd_r = (unsigned)(total % 8);
+                pbb.stagger = [] { const char* e = getenv("AADFF_BLK_STAGGER"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
+                hipLaunchKernelGGL((conv_psf_map_blk_kernel<KS>), dim3((unsigned)total), dim3(64 * blk::NW), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, bntx, bnty, pbb);
                 return 0;
             }
         }

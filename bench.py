@@ -57,6 +57,12 @@ def cpu_model():
     return "unknown"
 
 
+def file_sha256(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def cpu_baseline(lens_path, img, dbar, fds, budget_s=30.0):
     """Oracle M1 slices (refocus -> psf_map -> render_psf_map) on the host cores, seed 0 — also the reference
     pixels of the `parity` block.  Returns (record, [slices])."""
@@ -237,6 +243,18 @@ def main():
     from aadff.focal_stack import render_focal_stack_m1
     torch.cuda.synchronize(dev)
     solo, splan = [], pipe.plans[0]
+    # ---- untimed: the same step on ONE stream (round 2's default), so that the line carries both schedules
+    n_one = max(20, min(args.steps, 100))
+    for i in range(4):
+        torch.manual_seed(i)
+        render_focal_stack_m1(lens, img, dbar, fds, GRID, KS, SPP, plan=splan, update_lens=False)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for i in range(n_one):
+        torch.manual_seed(i)
+        render_focal_stack_m1(lens, img, dbar, fds, GRID, KS, SPP, plan=splan, update_lens=False)
+    torch.cuda.synchronize(dev)
+    one_stream_ms = (time.perf_counter() - t1) / n_one * 1e3
     for i in range(4 * max(4, args.solo_steps)):
         torch.manual_seed(i)
         rec = None
@@ -261,15 +279,24 @@ def main():
     conv_ms = float(np.mean(conv_all))
     conv_bracket = [r["bracket"][0].elapsed_time(r["bracket"][1]) for r in solo]
     achieved = ALG_BYTES_PER_SLICE * S / (conv_ms * 1e-3)
-    traffic = unique = None
-    tpath = os.path.join(REPO, "profiles", "conv_traffic.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        traffic, unique = tj.get("hbm_bytes_per_launch"), tj.get("unique_bytes_per_launch")
-    valu = None
-    vpath = os.path.join(REPO, "profiles", "psf_kernel_pmc.json")
-    if os.path.exists(vpath):
-        valu = json.load(open(vpath)).get("valu_busy")
+    # PMC digests (rocprofv3 --pmc passes cannot run inside this process): quoted ONLY when they were collected on the very
+    # sources the loaded library was built from - tools/summarise_profiles.py stamps each digest with the sha256 of the kernel's
+    # source file; a digest of another build is reported as stale (null), not as a measurement
+    def digest(name, source):
+        path = os.path.join(REPO, "profiles", name)
+        if not os.path.exists(path):
+            return None, f"profiles/{name} missing"
+        dj = json.load(open(path))
+        have = file_sha256(os.path.join(REPO, "aberration-aware-depth-from-focus_amd", "csrc", source))
+        if dj.get("code_sha256", {}).get(source) != have:
+            return None, (f"stale: profiles/{name} was collected on another build of csrc/{source} (digest "
+                          f"{str(dj.get('code_sha256', {}).get(source))[:12]}, this tree {have[:12]}); re-run tools/prof_r04.sh + tools/summarise_profiles.py")
+        return dj, f"profiles/{name} (rocprofv3 PMC passes of this command on this build of csrc/{source}, sha256 {have[:12]}; not measured in this run)"
+    tj, traffic_source = digest("conv_traffic.json", "conv.hip")
+    traffic = tj.get("hbm_bytes_per_launch") if tj else None
+    unique = (1 + S) * 3 * H * W * 4                     # bytes that MUST move per launch: the image once + S output slices (13.2 B/pixel/slice)
+    vj, valu_source = digest("psf_kernel_pmc.json", "trace.hip")
+    valu = vj.get("valu_busy") if vj else None
     if rank == 0:
         n_surf = len(lens.surfaces)
         steps_per_stack = 3 * (SPP + 2048) * GRID * GRID * n_surf * S         # rays x surfaces
@@ -282,6 +309,8 @@ def main():
             "latency_ms_p50": round(float(np.median(lat)) * 1e3, 4),
             "latency_ms_p50_render_call_only": round(float(np.median(lat_render)) * 1e3, 4) if lat_render else None,
             "streams": n_streams,
+            "one_stream": {"ms_per_step": round(one_stream_ms, 4), "value": round(S * H * W / 1e6 / (one_stream_ms * 1e-3), 2), "steps": n_one,
+                           "what": "the same step queued on ONE HIP stream (every kernel alone on the device; untimed leg of this rank)"},
             "config": {"workload": "rf50mm, 1024x1024 synthetic RGB + depth plane, 10 focus distances, 11x11 PSF grid, "
                                    "ks 11, spp 2048 (+2048 chief), mode M1 (refocus -> psf_map -> render_psf_map)",
                        "stacks_per_step_per_gpu": 1, "pupil_samples": "device RNG" if args.device_rng else "host torch RNG, reference call order",
@@ -298,24 +327,27 @@ def main():
                                         os.environ.get("AADFF_CONV_PATH", "s")[0],
                                         "conv_psf_map_sbatch_kernel (slice-batched im2col GEMM on MFMA, fp16x3 operand split, "
                                         "fp32 accumulate)") + ", stack-fused S=10",
-                         "bound": "hbm", "achieved": round(achieved / 1e9, 2),
-                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
-                         "traffic_source": "profiles/conv_traffic.json (static: rocprofv3 PMC passes of an earlier run of this command, not measured in this run)",
-                         "frac_stack_fused": round(unique / (conv_ms * 1e-3) / HBM_PEAK, 4) if unique else None,
-                         "stack_fused_bytes_per_launch": unique,
+                         # headline: the bytes that must move per launch - image read ONCE for the S slices + S output slices
+                         "bound": "hbm", "achieved": round(unique / (conv_ms * 1e-3) / 1e9, 2),
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(unique / (conv_ms * 1e-3) / HBM_PEAK, 4),
+                         "basis": "stack-fused bytes: (1 + S) x 3 x H x W x 4 B = 13.2 B/pixel/slice (the image is read once for all slices)",
+                         "bytes_per_launch": unique,
+                         # SURVEY.md 8(d)'s definition beside it: 24 B/pixel/slice (every slice re-reads the image)
+                         "achieved_survey_8d": round(achieved / 1e9, 2), "frac_survey_8d": round(achieved / HBM_PEAK, 4),
+                         "algorithmic_bytes_per_launch_survey_8d": ALG_BYTES_PER_SLICE * S,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(conv_ms, 4), "kernel_ms_median": round(float(np.median(conv_all)), 4),
                          "kernel_ms_bracketed": round(float(np.mean(conv_bracket)), 4) if conv_bracket else None,
                          "kernel_ms_note": "kernel_ms: HIP events attached to the kernel's dispatch (hipExtLaunchKernelGGL start/stop events) in the "
                                            "solo leg = the kernel's own begin-to-end time on its launch stream, what rocprofv3 reports for "
                                            "`bench.py --streams 1`; kernel_ms_bracketed: two stream events around the same launches "
                                            "(adds the two dispatch gaps, the round-1 method)",
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_SLICE * S,
                          "tflops": round(2 * 3 * KS * KS * H * W * S / (conv_ms * 1e-3) / 1e12, 2)},
             "trace": {"kernel": "psf_points_kernel (fused chief-ray centre + ray trace + LDS histogram + normalise)",
                       "us_per_stack": round(psf_ms * 1e3, 2), "ray_surface_steps_per_stack": steps_per_stack,
                       "ray_surface_steps_per_s": round(steps_per_stack / (psf_ms * 1e-3), 0),
-                      "frac_of_step_solo": round(psf_ms / (dt / args.steps * 1e3), 4), "bound": "valu",
-                      "valu_busy": valu, "valu_busy_source": "profiles/psf_kernel_pmc.json (static)" if valu is not None else None},
+                      "frac_of_step_one_stream": round(psf_ms / one_stream_ms, 4), "bound": "valu",
+                      "valu_busy": valu, "valu_busy_source": valu_source},
             "flags": bits,
         }
         if not args.no_cpu_baseline and world == 1:
@@ -329,10 +361,13 @@ def main():
                              "against": "oracle (CPU restatement pinned to the reference by tests/golden), seed 0, "
                                         "same image / depth plane / focus distances as the timed steps"}
             # the same stack through Lensgroup(parity="strict") (reference operation order on the GPU, reference host arithmetic;
-            # ~0.25 s per stack, untimed): every slice must meet the tolerance on its own, no floor widening
+            # ~15 ms per stack, untimed): every slice must meet the tolerance on its own, no floor widening
             try:
                 from aadff.focal_stack import render_focal_stack_m1 as _rfs
                 ls = Lensgroup(lens_path, sensor_res=(H, W), device=dev, parity="strict")
+                torch.manual_seed(0)
+                _rfs(ls, img, dbar, fds, GRID, KS, SPP)          # warm (ray buffers, first launches)
+                torch.cuda.synchronize(dev)
                 torch.manual_seed(0)
                 t_s = time.perf_counter()
                 so = _rfs(ls, img, dbar, fds, GRID, KS, SPP)
@@ -343,7 +378,8 @@ def main():
                 res["parity"]["strict_mode"] = {"rel_l2": float(f"{np.linalg.norm(a2 - b) / np.linalg.norm(b):.3e}"),
                                                 "rel_l2_per_slice": [float(f"{v:.3e}") for v in per2], "worst_slice": float(f"{max(per2):.3e}"),
                                                 "seconds_per_stack": round(t_s, 3),
-                                                "what": "Lensgroup(parity='strict'): aadff_trace_rays_strict + the reference's host arithmetic; DESIGN.md section 2"}
+                                                "what": "Lensgroup(parity='strict'): the reference's float32 operation order on the GPU (three batched traces per stack, "
+                                                        "aadff_trace_rays_strict_batched) + the reference's host arithmetic; DESIGN.md section 2"}
                 if not max(per2) <= 1e-4:
                     print("bench: strict-mode parity above 1e-4 on a slice", file=sys.stderr, flush=True)
             except Exception as e:                       # the contract line must not depend on the verification mode
@@ -557,16 +593,19 @@ def main_m2(args):
 
 def main_fit(args):
     """1_fit_psfnet.py training loop (reference: deeplens/psfnet.py:79-170): per iteration a random focus distance
-    (refocus kernel), bs = 128 random points, their ray-traced PSFs (fused trace/PSF kernel, spp 2048, ks 11) as targets,
+    (refocus kernel), bs = 128 random points, their ray-traced PSFs (fused trace/PSF kernel, spp 4096, ks 11, sensor 480 x 640:
+    the configuration of 1_fit_psfnet.py:18,22) as targets,
     one MLP forward/backward/AdamW step in torch (bf16 autocast on the MLP).  Not the BASELINE.json metric."""
     from aadff.synth import mlp_state_dict
     from deeplens.psfnet import PSFNet
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
-    net = PSFNet(os.path.join(REPO, "lenses", "rf50mm", "lens.json"), sensor_res=(512, 512), kernel_size=KS, device=dev)
+    # the script's own configuration (1_fit_psfnet.py:18,22): sensor 480 x 640, bs 128, spp 4096, lr 1e-4, ks 11
+    fit_res, bs = (480, 640), 128
+    spp = int(os.environ.get("AADFF_FIT_SPP", "4096"))
+    net = PSFNet(os.path.join(REPO, "lenses", "rf50mm", "lens.json"), sensor_res=fit_res, kernel_size=KS, device=dev)
     net.psfnet.load_state_dict({k: torch.from_numpy(v) for k, v in mlp_state_dict(seed=4321).items()})
     from deeplens.psfnet import _TrainStep
-    bs, spp = 128, SPP
     steps = min(args.steps, 100) if args.steps == 200 else args.steps
     step = _TrainStep(net.psfnet, 1e-4, 10000, bs, KS * KS, dev, True, os.environ.get("AADFF_FIT_GRAPH", "1") != "0")
     t_data = [0.0]
@@ -592,11 +631,12 @@ def main_fit(args):
     dt = time.perf_counter() - t0
     plan.check_flags()
     print(json.dumps({
-        "metric": "PSFNet fit iterations/s (bs 128 ray-traced PSF targets, spp 2048, ks 11, bf16 MLP step)",
+        "metric": f"PSFNet fit iterations/s (bs {bs} ray-traced PSF targets, spp {spp}, ks 11, bf16 MLP step)",
         "value": round(steps / dt, 2), "unit": "it/s", "n_gpus": 1, "steps": steps, "warmup": min(args.warmup, 10),
         "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 targets / bf16 MLP", "data": "synthetic",
-        "config": {"workload": "rf50mm, 512x512 sensor, reference sampling of (x, y, z, focus), random-init MLP 4-64-256-8x256-121",
+        "config": {"workload": f"1_fit_psfnet.py:18,22: rf50mm, {fit_res[0]}x{fit_res[1]} sensor, bs {bs}, spp {spp}, lr 1e-4, reference sampling of "
+                               "(x, y, z, focus), random-init MLP 4-64-256-8x256-121",
                    "host_data_ms_per_step": round((t_data[0] - plan.wait_s) / steps * 1e3, 4),
                    "host_wait_for_gpu_ms_per_step": round(plan.wait_s / steps * 1e3, 4),
                    "batches": "pipelined producer (aadff/training.py): pinned block uploaded inside the refocus launch, 2 launches per batch"}}), flush=True)

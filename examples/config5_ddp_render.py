@@ -67,11 +67,15 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--save", default=None, help="directory: every rank writes its consumer's parameters there (tests compare them)")
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--hw", type=int, nargs=2, default=(64, 64), help="image size; configs/aber_aware_dff_dfv.yml:21 is 480 640")
+    ap.add_argument("--n-stack", type=int, default=5, help="focal-stack size; configs/aber_aware_dff_dfv.yml:20 is 8")
+    ap.add_argument("--batch", type=int, default=2, help="mini-batch per rank; configs/aber_aware_dff_dfv.yml:19 is 2")
     a = ap.parse_args()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    rank, world, net, loss = train(hip_render_stack(dev, (64, 64)), dev, steps=a.steps, hw=(64, 64))
+    hw = tuple(a.hw)
+    rank, world, net, loss = train(hip_render_stack(dev, hw), dev, steps=a.steps, n_stack=a.n_stack, hw=hw, batch=a.batch)
     print(f"rank {rank}/{world}: loss {loss:.4f}", flush=True)
     if a.save:
         torch.save({"loss": loss, "params": [p.detach().cpu() for p in net.parameters()]}, os.path.join(a.save, f"config5_rank{rank}.pt"))

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AADFF_ABI_VERSION 5
+#define AADFF_ABI_VERSION 6
 
 #define AADFF_EINVAL      (-1)   /* bad shape / size / NULL pointer                  */
 #define AADFF_EUNSUPPORTED (-2)  /* parameter outside what the kernels were built for */
@@ -185,6 +185,29 @@ int aadff_trace_rays(const float* o_in, const float* d_in, const float* ra_in,
 int aadff_trace_rays_strict(float* o, float* d, float* ra, int n, const aadff_surface_t* surf_host, int first, int last,
                             int forward, int propagate, float z_sensor, unsigned* scratch, int* flags_or_null,
                             aadff_stream_t stream);
+
+/* The same strict trace for B independent Newton batches of n rays each in ONE launch per surface (ABI v6): what a whole focal
+ * stack of Lensgroup(parity="strict") runs on - the S refocus traces (deeplens/optics.py:1155-1180), the S field-of-view traces
+ * (:1187-1217) and the S x 3 x 2 traces of psf_map (main + chief rays per wavelength, :888-1026) are three calls instead of
+ * 72 S.  o, d [B,n,3], ra [B,n] (device), in place.  tables_host: n_tables (<= 4) packed tables of n_surf records (HOST);
+ * batch_table [B] (device): which table (wavelength) batch b traces with.  Every batch keeps its own iteration counts
+ * (`while (|ft| > 5e-5).any()` is per reference call, deeplens/surfaces.py:547).
+ * points_or_null != NULL: the rays are BUILT first, as sample_from_points + Ray.__init__ do (deeplens/optics.py:482-491,
+ * deeplens/basics.py:216-244): ray i of batch b = (sample i / N, point i % N): o = points[point_set[b]][i % N] ([P,N,3] object
+ * points, device), d = F.normalize(pupil[b][i / N] - o) (pupil [B, n / N, 3], device), ra = 1; o / d / ra are outputs then.
+ * z_sensor_or_null [B] (device): Ray.propagate_to(z_sensor[b]) behind the last surface (trace2sensor).
+ * scratch: 2*B*AADFF_MAX_SURF + 1 device words (zeroed by the call); flags_or_null as aadff_trace_rays_strict (any batch). */
+int aadff_trace_rays_strict_batched(float* o, float* d, float* ra, int n, int B, const aadff_surface_t* tables_host, int n_tables,
+                                    int n_surf, const int* batch_table, const float* points_or_null, const int* point_set,
+                                    const float* pupil, int N, int first, int last, int forward, const float* z_sensor_or_null,
+                                    unsigned* scratch, int* flags_or_null, aadff_stream_t stream);
+
+/* Chief-ray PSF centres of B batches: centre[b][p] = -(sum_s o_xy[b,s,p] ra[b,s,p]) / (sum_s ra[b,s,p] + 1e-9), o [B,spp,N,3],
+ * ra [B,spp,N] (device) -> centre [B,N,2]; any_valid [B] = 1 where some ray of the batch has ra == 1 (the reference asserts it:
+ * "No sampled rays is valid.", deeplens/optics.py:901).  The sums run in the ORDER of ATen's CPU `tensor.sum(0)` (cascade
+ * summation of an outer reduction), so the centre has the bits the reference's psf_center (deeplens/optics.py:888-913) computes
+ * on the host; oracle/aten_sum.py is the specification.  For Lensgroup(parity="strict"). */
+int aadff_strict_centroid(const float* o, const float* ra, int spp, int N, int B, float* centre, int* any_valid, aadff_stream_t stream);
 
 /* Rays from object points through the entrance pupil to the sensor.  Replaces
  * sample_from_points + trace2sensor, deeplens/optics.py:457-491,635-661.

@@ -122,10 +122,12 @@ def test_config5_ddp_consumer_on_hip_rendered_stacks_two_emulated_ranks(tmp_path
     import torch
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     script = os.path.join(REPO, "examples", "config5_ddp_render.py")
-    assert spawn_ranks([script, "--save", str(tmp_path), "--steps", "3"], 2, emulate=True, env=env, timeout=600) == 0
-    a, b = (torch.load(tmp_path / f"config5_rank{r}.pt") for r in range(2))
-    assert all(torch.equal(x, y) for x, y in zip(a["params"], b["params"])), "DDP ranks ended with different consumer weights"
-    assert np.isfinite(a["loss"]) and np.isfinite(b["loss"]) and a["loss"] != b["loss"]      # different scenes per rank
+    # the miniature (64 x 64, 5 slices) and the configuration's own size: configs/aber_aware_dff_dfv.yml:19-21 = bs 2, n_stack 8, 480 x 640
+    for extra in ([], ["--hw", "480", "640", "--n-stack", "8", "--batch", "2", "--steps", "2"]):
+        assert spawn_ranks([script, "--save", str(tmp_path), "--steps", "3"] + extra, 2, emulate=True, env=env, timeout=600) == 0, extra
+        a, b = (torch.load(tmp_path / f"config5_rank{r}.pt") for r in range(2))
+        assert all(torch.equal(x, y) for x, y in zip(a["params"], b["params"])), "DDP ranks ended with different consumer weights"
+        assert np.isfinite(a["loss"]) and np.isfinite(b["loss"]) and a["loss"] != b["loss"]      # different scenes per rank
 
 
 @pytest.mark.timeout(900)

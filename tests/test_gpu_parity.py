@@ -903,6 +903,32 @@ def test_focal_stack_m2_vs_oracle(psfnet64):
     assert rel_l2(got.cpu().numpy(), want) <= IMG_TOL
 
 
+def test_config5_stack_at_its_size_golden(golden_dir, repo_root):
+    """BASELINE.json config 5's render AT ITS SIZE (the suite ran M2 at 64 x 64 only): configs/aber_aware_dff_dfv.yml:19-21
+    = bs 2, n_stack 8, 480 x 640, ks 11, through the loop of 2_aber_aware_dff_dfv.py:101-107 - `select_focus_dist(depth, 8)` then
+    `PSFNet.render(aif, -depth * 1e3, -foc_dist * 1e3)` per slice - here `render_focal_stack_m2` (ONE fused launch for the
+    [2,3,8,480,640] stack).  Fixture G7b = the reference's own output (focus distances, three 64 x 64 crops, 16 x 16 block means
+    and float64 sums of every (sample, slice)); the per-slice `PSFNet.render` loop must give the same pixels as the stack entry."""
+    g = np.load(os.path.join(golden_dir, "g7b_config5_stack.npz"))
+    H, W, B, S = 480, 640, 2, 8
+    net = PSFNet(lens_path(repo_root), sensor_res=(H, W), kernel_size=11, device=DEV)
+    net.psfnet.load_state_dict({k: tt(v) for k, v in mlp_state_dict(seed=4321).items()})
+    aif = tt(np.stack([synth_rgb(H, W, seed=31 + b) for b in range(B)])).to(DEV)
+    depth = (tt(np.stack([synth_depth_mm(H, W, seed=41 + b) for b in range(B)]))[:, None] / 1e3).to(DEV)
+    got, fds = render_focal_stack_m2(net, aif, depth, S)
+    assert got.shape == (B, 3, S, H, W) and np.array_equal(fds.cpu().numpy(), g["focus_dists"])
+    out = got.cpu().numpy()
+    for name, (ys, xs) in {"a": (slice(0, 64), slice(0, 64)), "b": (slice(208, 272), slice(288, 352)), "c": (slice(416, 480), slice(576, 640))}.items():
+        assert rel_l2(out[:, :, :, ys, xs], g[f"crop_{name}"]) <= IMG_TOL, name
+        assert np.abs(out[:, :, :, ys, xs] - g[f"crop_{name}"]).max() <= 2e-5, name
+    blocks = out.astype(np.float64).reshape(B, 3, S, H // 16, 16, W // 16, 16).mean((4, 6))
+    assert rel_l2(blocks, g["block_means"]) <= 2e-6
+    assert out.astype(np.float64).sum((3, 4)) == pytest.approx(g["sums"], rel=2e-6)
+    for i in (0, 5):                                                            # the reference's own call, slice by slice
+        sl = net.render(aif, -depth * 1e3, -fds[:, i] * 1e3)
+        assert (sl - got[:, :, i]).abs().max().item() <= 2e-6, i
+
+
 def test_config0_warm_up_stack_256_vs_oracle(repo_root, tmp_path):
     """BASELINE.json configs[0] (0_warm_up.py scale: rf50mm, 256x256 RGB-D, 5-slice stack through PSFNet.render) against
     the oracle, and the example script that replays 0_warm_up.py's call sequence runs end to end."""

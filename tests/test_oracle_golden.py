@@ -466,3 +466,20 @@ def test_c_oracle_matches_golden(g5, repo_root):
         B, Cn, H, W = img.shape
         lib.oracle_local_psf_render(img.ctypes.data_as(fp), np.ascontiguousarray(p).ctypes.data_as(fp), out.ctypes.data_as(fp), B, Cn, H, W, ks)
         assert np.abs(out - g5[f"loc_{tag}_out"]).max() <= 3e-6, tag
+
+
+def test_aten_sum_order_program_is_torch_bit_for_bit():
+    """oracle/aten_sum.py (the summation order `aadff_strict_centroid` follows) against torch's own CPU `sum(0)`, bit for bit:
+    the shapes of psf_center (deeplens/optics.py:902-904: [2048, 121, 3]), training batches ([4096, 128, 3]), ragged row counts,
+    fewer columns than one vector - at one, three and all threads."""
+    from oracle import aten_sum
+    keep = torch.get_num_threads()
+    try:
+        for nt in (1, 3, keep):
+            torch.set_num_threads(nt)
+            for spp, N in ((2048, 121), (4096, 128), (3001, 121), (512, 9), (2048, 1), (17, 40)):
+                g = torch.Generator().manual_seed(spp + N)
+                x = torch.randn(spp, N, 3, generator=g) * 3 * (torch.rand(spp, N, 1, generator=g) > 0.3).float()
+                assert np.array_equal(x.sum(0).numpy(), aten_sum.sum0(x.numpy())), (nt, spp, N)
+    finally:
+        torch.set_num_threads(keep)

@@ -9,6 +9,16 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02_a"
 G, P = os.path.join(REPO, "gpurun_out"), os.path.join(REPO, "profiles")
 
 
+def code_sha256(*sources):
+    """sha256 of the kernel sources a digest belongs to: bench.py quotes a digest only while the tree still holds these sources."""
+    import hashlib
+    out = {}
+    for src in sources:
+        with open(os.path.join(REPO, "aberration-aware-depth-from-focus_amd", "csrc", src), "rb") as f:
+            out[src] = hashlib.sha256(f.read()).hexdigest()
+    return out
+
+
 def one(pattern):
     f = glob.glob(os.path.join(G, pattern), recursive=True)
     return f[0] if f else None
@@ -61,7 +71,7 @@ for k, (v, n, meta) in rows.items():
             if "psf_points_kernel" in r["Name"]:
                 us = float(r["AverageNs"]) / 1e3
         simd_cycles = us * 1e-6 * 2.4e9 * 1024 if us else None          # 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
-        json.dump({"kernel": "psf_points_kernel (S=10, N=121, L=3, spp 2048 + 2048 chief)", "source": f"profiles/{tag}_psf_kernel_pmc.csv, profiles/{tag}_kernel_stats.csv",
+        json.dump({"kernel": "psf_points_kernel (S=10, N=121, L=3, spp 2048 + 2048 chief)", "code_sha256": code_sha256("trace.hip"), "source": f"profiles/{tag}_psf_kernel_pmc.csv, profiles/{tag}_kernel_stats.csv",
                    "us_per_launch_rocprof": us, "SQ_INSTS_VALU": v["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU_quadcycles": v.get("SQ_ACTIVE_INST_VALU"),
                    "valu_wave_instructions_per_surface_per_lane": round(v["SQ_INSTS_VALU"] / (178421760 / 128), 1),
                    "note": "a lane carries two rays (packed fp32), so one surface step of a lane = 2 ray-surface steps; 178 421 760 ray-surface steps per launch (SURVEY.md 8d); includes sampling, chief-ray reduction, compaction and splat",
@@ -75,7 +85,7 @@ if f and w:
     for k, (v, n, meta) in rows.items():
         fetch, write = v["FETCH_SIZE"] * 1024, v["WRITE_SIZE"] * 1024
         requested = 1452 * (34 * 108 * 4) + 1452 * 12 * 121 * 4          # what the workgroups ask L2 for: staged rows (with halo) + taps
-        json.dump({"kernel": "conv_psf_map_sbatch_kernel (S=10 stack, 1024x1024x3)",
+        json.dump({"kernel": "conv_psf_map_sbatch_kernel (S=10 stack, 1024x1024x3)", "code_sha256": code_sha256("conv.hip"),
                    "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes on bench.py --streams 1 (tools/prof_r03.sh), profiles/{tag}_conv_traffic_pmc.csv",
                    "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"],
                    "correction": "MI355X_MICROARCH.md (HBM): the x2 FETCH_SIZE rule is calibrated for 16 B/lane streaming reads only; this kernel stages its "
