@@ -104,7 +104,25 @@ def init_from_env(backend=None, device=None):
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(free_port()))
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        if backend == "nccl":
+            # RCCL writes a version banner ("RCCL version : ...", five lines) to STDOUT through C stdio when its first communicator
+            # comes up - behind whatever Python has printed by then, since C stdio is flushed at exit.  bench.py's contract is ONE
+            # JSON line on stdout: bring the communicator up here with fd 1 pointing at stderr, flush C stdio, restore.
+            import ctypes
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+                t = torch.zeros(1, device=device if device is not None else "cuda")
+                dist.all_reduce(t)
+                torch.cuda.synchronize()
+                ctypes.CDLL(None).fflush(None)
+            finally:
+                os.dup2(keep, 1)
+                os.close(keep)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world
 
 

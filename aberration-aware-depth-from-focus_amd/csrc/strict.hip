@@ -13,6 +13,7 @@
 // correctly rounded for 0.7 % of arguments, so about 3.5 % of rays leave the lens one ulp away from the reference's
 // (oracle/scalar_trace.py's test); sin / cos / atan of the sampling and of calc_fov stay on the host with torch itself
 // (deeplens/optics.py, parity="strict").  ~20x the cost of the fused kernels; DESIGN.md section 2.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include "common.h"
@@ -319,12 +320,14 @@ __global__ __launch_bounds__(256) void batched_step_kernel(float* o_io, float* d
 // Second instalment of the count: batches that were still above the tolerance in all of the first kFirstIters iterations.
 __global__ __launch_bounds__(256) void batched_count_more_kernel(const float* __restrict__ o_in, const float* __restrict__ d_in, const float* __restrict__ ra_in,
                                                                  int n, const int* __restrict__ batch_table, SurfSet cur, int cur_idx, unsigned* masks, int B) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    // a fixed, small grid walking the batch (grid-stride): the launch mostly finds nothing to do, and 1.7 M workgroups that
+    // leave at once cost 60 us per launch in dispatch alone (rocprofv3, round 4)
+    const int b = blockIdx.y;
     const Surf& s = cur.s[batch_table[b]];
     constexpr unsigned first = (1u << kFirstIters) - 1u;
     if (s.flat || (masks[(size_t)b * AADFF_MAX_SURF + cur_idx] & first) != first) return;      // block-uniform
     unsigned mine = 0, nans = 0;
-    if (i < n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const size_t idx = (size_t)b * n + i;
         const f3u a = *reinterpret_cast<const f3u*>(o_in + idx * 3), c = *reinterpret_cast<const f3u*>(d_in + idx * 3);
         count_ray(s, {a.x, a.y, a.z}, {c.x, c.y, c.z}, ra_in[idx] > 0.f, mine, nans);
@@ -495,6 +498,7 @@ extern "C" int aadff_trace_rays_strict_batched(float* o, float* d, float* ra, in
     if (n == 0 || first == last) return 0;
     hipStream_t st = (hipStream_t)stream;
     const dim3 g((n + 255) / 256, B), blk(256);
+    const dim3 gm(std::min((n + 255) / 256, std::max(1, 4096 / B)), B);        // count_more: ~4096 workgroups in all
     // scratch: [B][AADFF_MAX_SURF] any-bits, [B][AADFF_MAX_SURF] NaN-bits, one flag word; zeroed here in stream order
     const size_t words = (size_t)2 * B * AADFF_MAX_SURF + 1;
     AADFF_CHECK_HIP(hipMemsetAsync(scratch, 0, words * sizeof(unsigned), st));
@@ -511,13 +515,13 @@ extern "C" int aadff_trace_rays_strict_batched(float* o, float* d, float* ra, in
     else
         hipLaunchKernelGGL(strict::batched_begin_kernel<false>, g, blk, 0, st, o, d, ra, n, batch_table, cur, surf_at(0), (const float*)nullptr, (const int*)nullptr,
                            (const float*)nullptr, 1, scratch, B);
-    hipLaunchKernelGGL(strict::batched_count_more_kernel, g, blk, 0, st, o, d, ra, n, batch_table, cur, surf_at(0), scratch, B);
+    hipLaunchKernelGGL(strict::batched_count_more_kernel, gm, blk, 0, st, o, d, ra, n, batch_table, cur, surf_at(0), scratch, B);
     for (int k = 0; k < nsteps; ++k) {
         const bool has_next = k + 1 < nsteps;
         strict::SurfSet nxt = has_next ? set_of(surf_at(k + 1)) : cur;
         hipLaunchKernelGGL(strict::batched_step_kernel, g, blk, 0, st, o, d, ra, n, batch_table, cur, surf_at(k), nxt, has_next ? surf_at(k + 1) : -1, forward,
                            z_sensor_or_null, scratch, B);
-        if (has_next) hipLaunchKernelGGL(strict::batched_count_more_kernel, g, blk, 0, st, o, d, ra, n, batch_table, nxt, surf_at(k + 1), scratch, B);
+        if (has_next) hipLaunchKernelGGL(strict::batched_count_more_kernel, gm, blk, 0, st, o, d, ra, n, batch_table, nxt, surf_at(k + 1), scratch, B);
         cur = nxt;
     }
     if (flags_or_null)

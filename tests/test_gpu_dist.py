@@ -151,7 +151,9 @@ def test_rccl_branch_on_a_one_rank_group(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gather", "--steps", "6", "--warmup", "2", "--spinup-s", "0.05",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
-    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[:600]            # ONE JSON line: RCCL's version banner must not land on stdout
+    rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["config"]["gather"] is True and not rec["config"]["ranks_emulated_on_one_gpu"] and rec["value"] > 0
     env["AADFF_C3_SCENES"] = "4"
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--mode", "c3", "--steps", "3", "--warmup", "1", "--spinup-s", "0.05"],

@@ -51,12 +51,14 @@ def write_pmc(dst, sources, keep):
     return rows
 
 
-for name, sub in (("kernel_stats", "stats"), ("kernel_stats_1stream", "stats_s1"), ("fit_kernel_stats", "fit_stats"), ("local_psf_kernel_stats", "lp_stats")):
+for name, sub in (("kernel_stats", "stats"), ("kernel_stats_1stream", "stats_s1"), ("fit_kernel_stats", "fit_stats"), ("local_psf_kernel_stats", "lp_stats"),
+                  ("single_kernel_stats", "single_stats"), ("strict_kernel_stats", "strict_stats")):
     src = one(f"{tag}_{sub}/**/*_kernel_stats.csv")
     if src:
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.csv"))
 for name in ("bench", "bench_fit", "bench_m2", "bench_2streams", "bench_refocus_overlap", "bench_1stream", "bench_c3", "bench_under_rocprof",
-             "conv_timeline", "conv_timeline_paired", "parity_per_slice_shipped", "parity_per_slice_literal", "parity_per_slice_strict"):
+             "conv_timeline", "conv_timeline_paired", "parity_per_slice_shipped", "parity_per_slice_literal", "parity_per_slice_strict",
+             "conv_single_timeline", "conv_single_timeline_toeplitz", "bench_rccl1_gather"):
     src = os.path.join(G, f"{tag}_{name}.json")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.json"))
@@ -100,7 +102,11 @@ if f and w:
 cp = one(f"{tag}_conv_pmc/**/*counter_collection.csv")
 if cp:
     write_pmc(os.path.join(P, f"{tag}_conv_kernel_pmc.csv"), [cp], ("conv_psf_map_sbatch",))
-for txt in ("latency_breakdown.txt", "soak.txt"):
+sp = one(f"{tag}_single_pmc/**/*counter_collection.csv")
+if sp:
+    write_pmc(os.path.join(P, f"{tag}_conv_single_kernel_pmc.csv"), [sp, one(f"{tag}_single_fetch/**/*counter_collection.csv"), one(f"{tag}_single_write/**/*counter_collection.csv")],
+              ("conv_psf_map_blk", "conv_psf_map_mfma"))
+for txt in ("latency_breakdown.txt", "soak.txt", "kbench.txt", "kbench_toeplitz.txt", "strict_profile.txt"):
     src = os.path.join(G, f"{tag}_{txt}")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{txt}"))
