@@ -851,7 +851,7 @@ __global__ __launch_bounds__(64 * NC, 5) void conv_psf_map_sbatch_kernel(
 }
 
 // ------------------------------------------------------------------------------------
-// Block-GEMM path for LONE slices (ks 9 / 11, S < 3: `render_psf_map` / `render_psf` themselves, deeplens/render_psf.py:12-73).
+// Block-GEMM path for LONE slices (ks 9 / 11, S = 1: `render_psf_map` / `render_psf` themselves, deeplens/render_psf.py:12-73).
 // With one slice there is nothing to batch on M, so a 4 x 4 block of OUTPUT PIXELS rides there instead:
 //   D[m][n] += sum_k T[m][k] X[k][n]
 //   n = (ry, cx): base pixel (y + 4 ry, X0 + 4 cx) of an 8-row x 32-column group          (2 x 8 = 16)
@@ -1189,7 +1189,10 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
     if constexpr (KS == 9 || KS == 11) {
         // lone slices (render_psf_map / render_psf as the reference calls them) and pairs: block-GEMM form, 21 instead of 33
         // MFMAs per 256 outputs and the slice-batched kernel's staging; AADFF_CONV_PATH = toeplitz / valu force the older paths
-        if (S * B * C <= 65535 && !penv && (size_t)H * W <= ((size_t)1 << 30)) {
+        // S == 1 only - measured (tools/conv_paths_bench.py, 1024^2, us): ks 11: S = 1 14.5-16.6 against 19.3-19.8 Toeplitz, S = 2
+        // 23.2 / 23.0 (re-staging per slice cancels the gain; a form that renders three slices from one staged band was built
+        // and was no faster: 23.0 / 28.9 for S = 2 / 3); ks 9: S = 1 14.5 / 18.5, S = 2 23.8 / 21.0, S = 10 86 / 72-78
+        if (S == 1 && B * C <= 65535 && !penv && (size_t)H * W <= ((size_t)1 << 30)) {
             int mh = 0, mw = 0;
             for (int i = 0; i < grid; ++i) {
                 mh = std::max(mh, pb.hb[i + 1] - pb.hb[i]);

@@ -141,8 +141,8 @@ def test_render_psf_map_stack_slice_batched_path_vs_oracle(B, H, W, g, S):
                                              (1, 3, 201, 97, 2, 1, 9), (1, 4, 120, 120, 11, 1, 11), (1, 3, 25, 300, 2, 2, 9), (1, 3, 203, 203, 2, 1, 11),
                                              (1, 3, 61, 83, 3, 7, 9)])
 def test_render_psf_map_block_gemm_path_vs_oracle_and_toeplitz(B, Cn, H, W, g, S, ks, monkeypatch):
-    """Lone slices and pairs at ks 9 / 11 (round 4: `conv_psf_map_blk_kernel`, a 4 x 4 block of output pixels on the MFMA M
-    dimension): patches wider than one 96-column tile, column blocks cut by the patch border inside a 4-pixel store, bands shorter
+    """Lone slices at ks 9 / 11 (round 4: `conv_psf_map_blk_kernel`, a 4 x 4 block of output pixels on the MFMA M dimension;
+    the S = 1 entry `render_psf_map` takes it, stacks of the same inputs take the Toeplitz / slice-batched forms): patches wider than one 96-column tile, column blocks cut by the patch border inside a 4-pixel store, bands shorter
     than 24 rows and 8-row groups cut by the patch border, odd patch origins (16-byte stores at 4-byte alignment), B > 1, C != 3,
     inputs far from [0, 1] (tile pre-scale) and a 1e-3 PSF (tap pre-scale).  Oracle = the reference's loop; and the Toeplitz
     form (AADFF_CONV_PATH=toeplitz), which carries the same exact operand split, to 1e-6 of the data range."""
@@ -152,8 +152,8 @@ def test_render_psf_map_block_gemm_path_vs_oracle_and_toeplitz(B, Cn, H, W, g, S
     maps[S // 2, 0] *= 1e-3
     got = rp.render_psf_map_stack(img.to(DEV), maps.to(DEV), g)
     assert got.shape == (B, Cn, S, H, W)
-    one = rp.render_psf_map(img.to(DEV), maps[0].to(DEV), g)
-    assert torch.equal(one, got[:, :, 0])                                      # the single-slice entry is the same launch with S = 1
+    one = rp.render_psf_map(img.to(DEV), maps[0].to(DEV), g)                   # S = 1: the block-GEMM kernel (S >= 2: Toeplitz / slice-batched)
+    assert (one - got[:, :, 0]).abs().max().item() <= 4e-6 * 40
     monkeypatch.setenv("AADFF_CONV_PATH", "toeplitz")
     toe = rp.render_psf_map_stack(img.to(DEV), maps.to(DEV), g)
     monkeypatch.delenv("AADFF_CONV_PATH")
@@ -162,6 +162,8 @@ def test_render_psf_map_block_gemm_path_vs_oracle_and_toeplitz(B, Cn, H, W, g, S
     for s in range(S):
         want = oconv.render_psf_map(img, maps[s], g).numpy()
         assert np.abs(gotn[:, :, s] - want).max() <= 4e-6 * 40, f"slice {s}"
+        lone = rp.render_psf_map(img.to(DEV), maps[s].to(DEV), g).cpu().numpy()            # every slice through the block-GEMM kernel
+        assert np.abs(lone - want).max() <= 4e-6 * 40, f"lone slice {s}"
 
 
 @pytest.mark.parametrize("Cn", [1, 2, 4, 6])
