@@ -511,10 +511,8 @@ __device__ __forceinline__ void lds_read16(uint2v& a, uint2v& b, unsigned byte_a
 // ONE round (round 2: 104 VGPRs, 5 per CU, 172 workgroups in a second round that ended 12 us after the first).  What made 96
 // possible without spilling in the loop: two operand buffers instead of three.  Forms measured and dropped in round 3 (three
 // accumulators per row pair, DPP operand sharing, 32/48-row bands, two row groups per chunk): DESIGN.md 4.1; git history has them.
-// PC (round 4, needs PAIR): producer / consumer form - an extra wave stages the SECOND band of the pair (global loads -> registers ->
-// scaled fp16 hi/lo tile in a second LDS buffer) while the NC chunk waves run the first band's matrix phase.
-template <int RB, int NC, bool PAIR, bool TIMED = false, bool PC = false>
-__global__ __launch_bounds__(64 * (NC + (PC ? 1 : 0)), 5) void conv_psf_map_sbatch_kernel(
+template <int RB, int NC, bool PAIR, bool TIMED = false>
+__global__ __launch_bounds__(64 * NC, 5) void conv_psf_map_sbatch_kernel(
     const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
     int grid, int ntx, int nty, int npass, PatchBounds pb, int stagger, int pair_mod) {
     using namespace sb;
@@ -527,16 +525,13 @@ __global__ __launch_bounds__(64 * (NC + (PC ? 1 : 0)), 5) void conv_psf_map_sbat
         const int slot = (int)((lin >> 8) % 6u);
         for (int i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(32);
     }
-    static_assert(!PC || PAIR, "the producer wave stages the second band of a pair");
-    constexpr int NW = NC + (PC ? 1 : 0), THP = RB + KS - 1, NSL = 4 * NC;
+    constexpr int NW = NC, THP = RB + KS - 1, NSL = 4 * NC;
     static_assert(RB % 2 == 0 && THP % 2 == 0, "bands are whole row pairs");
     static_assert(WDW <= 64, "one lane per dword column");
     __shared__ __attribute__((aligned(16))) unsigned tile[(THP / 2) * RPP];
     // [hi | lo] planes of the padded tap rows; PAIR: once the T fragments are built the same memory (and a little more) is
     // the landing zone of the second band's raw fp32 rows (LDS-DMA), THP rows x WCOLS floats
-    constexpr int PROW_DW = 2 * NSL * PSL, STAGE_DW = (PAIR && !PC) ? THP * WCOLS : 0, POOL_DW = PROW_DW > STAGE_DW ? PROW_DW : STAGE_DW;
-    __shared__ __attribute__((aligned(16))) unsigned tile2[PC ? (THP / 2) * RPP : 4];       // PC: the second band's tile
-    __shared__ float s_isx2;
+    constexpr int PROW_DW = 2 * NSL * PSL, STAGE_DW = PAIR ? THP * WCOLS : 0, POOL_DW = PROW_DW > STAGE_DW ? PROW_DW : STAGE_DW;
     __shared__ __attribute__((aligned(16))) unsigned pool[POOL_DW];
     unsigned (*prow)[NSL * PSL] = reinterpret_cast<unsigned (*)[NSL * PSL]>(pool);
     __shared__ float red[NW];
@@ -578,12 +573,11 @@ __global__ __launch_bounds__(64 * (NC + (PC ? 1 : 0)), 5) void conv_psf_map_sbat
     float tw0[4], tw1[4];
     const int t0 = lane, t1 = lane + 64;                                       // taps t0 (< 121 always) and t1 (< 121 for lane < 57)
     const int tu0 = t0 / KS, tc0 = t0 - tu0 * KS, tu1 = t1 / KS, tc1 = t1 - tu1 * KS;
-    const bool chunk_wave = !PC || wave < NC;                                  // PC: the last wave is the producer, it owns no slices
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) {
         const int s = s_base + 4 * chunk + k2;
         tw0[k2] = 0.f; tw1[k2] = 0.f;
-        if (chunk_wave && s < S) {
+        if (s < S) {
             // w(u,v) = psf[KS-1-u][KS-1-v]  (deeplens/render_psf.py:60 flips the kernel before conv2d)
             const float* wp = psf + ((size_t)(s * C + c) * G + pi * KS) * G + pj * KS;
             tw0[k2] = wp[(size_t)(KS - 1 - tu0) * G + (KS - 1 - tc0)];
@@ -608,7 +602,7 @@ __global__ __launch_bounds__(64 * (NC + (PC ? 1 : 0)), 5) void conv_psf_map_sbat
         }
     }
     // ---- padded fp16 hi/lo tap rows of this wave's chunk ----
-    if (chunk_wave) {
+    {
         _Float16* ph = reinterpret_cast<_Float16*>(&prow[0][0]);
         _Float16* pl = reinterpret_cast<_Float16*>(&prow[1][0]);
         for (int e = lane; e < 4 * PSL; e += 64) { prow[0][4 * chunk * PSL + e] = 0u; prow[1][4 * chunk * PSL + e] = 0u; }
@@ -663,7 +657,7 @@ __global__ __launch_bounds__(64 * (NC + (PC ? 1 : 0)), 5) void conv_psf_map_sbat
 
     // ---- T fragments of this wave's chunk: slot q = 2 st + (kg >> 1) -> column pair dd0, row pair up (see header) ----
     uint4v Th[5], Tl[5];
-    if (chunk_wave) {
+    {
         const int sl = lo4 >> 2, du = (lo4 >> 1) & 1, j = lo4 & 1;
         const unsigned* pbh = &prow[0][(chunk * 4 + sl) * PSL];
         const unsigned* pbl = &prow[1][(chunk * 4 + sl) * PSL];
@@ -684,7 +678,7 @@ __global__ __launch_bounds__(64 * (NC + (PC ? 1 : 0)), 5) void conv_psf_map_sbat
                               __builtin_amdgcn_alignbit(a1[2], a1[1], sh), __builtin_amdgcn_alignbit(a1[PRD + 2], a1[PRD + 1], sh)};
         }
     }
-    float inv = chunk_wave ? isx * s_isw[chunk * 4 + kg] : 0.f;               // D rows 4 kg + i belong to slice kg of the chunk
+    float inv = isx * s_isw[chunk * 4 + kg];                                  // D rows 4 kg + i belong to slice kg of the chunk
     __syncthreads();                                                          // the whole band is in LDS
     AADFF_SB_STAMP(3);
 
@@ -694,7 +688,7 @@ __global__ __launch_bounds__(64 * (NC + (PC ? 1 : 0)), 5) void conv_psf_map_sbat
     // workgroups (all resident at once: no second residency round).
     const int y0b = y0 + RB;
     const bool second = PAIR && paired && y0b < y_hi;
-    if constexpr (PAIR && !PC) {
+    if constexpr (PAIR) {
         if (second) {
             const float* plane = img + (size_t)bc * H * W;
             const int xa = reflect_idx(x0 - PAD + lane, W), xb = reflect_idx(x0 - PAD + 64 + lane, W);
@@ -736,10 +730,10 @@ __global__ __launch_bounds__(64 * (NC + (PC ? 1 : 0)), 5) void conv_psf_map_sbat
     }
 
     // ---- matrix phase of one band (rows yb .. yb + RB - 1 of the image, staged in `tile`) ----
-    auto run_band = [&](const int yb, const float inv, const unsigned tile_off) {
+    auto run_band = [&](const int yb, const float inv) {
         int npairs = (y_hi - yb + 1) / 2;                   // row pairs of this band that hold valid rows
         npairs = npairs > RB / 2 ? RB / 2 : npairs;
-        const unsigned rowb0 = tile_off;                     // byte offset of the band's tile from `tile`
+        const unsigned rowb0 = 0u;
         {
             // Two operand buffers, reads ONE step ahead: 8 VGPRs fewer than the three-buffer form - what it takes to fit
             // 96 VGPRs = 5 waves per SIMD = 6 workgroups (18 waves) per CU, i.e. all 1452 workgroups of the bench launch
@@ -805,49 +799,7 @@ __global__ __launch_bounds__(64 * (NC + (PC ? 1 : 0)), 5) void conv_psf_map_sbat
                          :: "memory");
         }
     };
-    if constexpr (PC) {
-        if (wave == NC) {
-            // ---- producer: the whole second band through this wave's registers (THP row loads in flight at once), scaled
-            //      and split into the second tile while the chunk waves are in the first band's matrix phase ----
-            if (second) {
-                const float* plane = img + (size_t)bc * H * W;
-                const int xa = reflect_idx(x0 - PAD + 2 * lane, W), xb = reflect_idx(x0 - PAD + 2 * lane + 1, W);
-                const bool in = lane < WDW;
-                float b0[THP], b1[THP];
-                float bmax = 0.f;
-#pragma unroll
-                for (int r = 0; r < THP; ++r) {
-                    const float* row = plane + (size_t)reflect_idx(y0b - PAD + r, H) * W;
-                    b0[r] = in ? row[xa] : 0.f;
-                    b1[r] = in ? row[xb] : 0.f;
-                }
-#pragma unroll
-                for (int r = 0; r < THP; ++r) bmax = fmaxf(bmax, fmaxf(fabsf(b0[r]), fabsf(b1[r])));
-                bmax = wave_max(bmax);
-                float sx2, isx2;
-                pow2_scale(bmax, sx2, isx2);
-                if (lane == 0) s_isx2 = isx2;
-                if (in) {
-#pragma unroll
-                    for (int r = 0; r < THP; ++r) {
-                        const float a = b0[r] * sx2, b = b1[r] * sx2;
-                        const _Float16 ah = (_Float16)a, bh = (_Float16)b;
-                        const _Float16 al = (_Float16)(a - (float)ah), bl = (_Float16)(b - (float)bh);
-                        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-                        const int d = (r >> 1) * RPP + 2 * lane + (r & 1);
-                        tile2[d] = __builtin_bit_cast(unsigned, (half2v){ah, bh});
-                        tile2[d + LO] = __builtin_bit_cast(unsigned, (half2v){al, bl});
-                    }
-                }
-            }
-        } else {
-            run_band(y0, inv, 0u);
-        }
-        AADFF_SB_STAMP(4);
-        __syncthreads();                                      // second tile written / first band's reads done
-        if (second && wave < NC) run_band(y0b, s_isx2 * s_isw[chunk * 4 + kg], (unsigned)(size_t)tile2 - (unsigned)(size_t)tile);
-    } else {
-    run_band(y0, inv, 0u);
+    run_band(y0, inv);
     AADFF_SB_STAMP(4);
     if constexpr (PAIR) {
         if (second) {
@@ -889,10 +841,9 @@ __global__ __launch_bounds__(64 * (NC + (PC ? 1 : 0)), 5) void conv_psf_map_sbat
             inv = isx2 * s_isw[chunk * 4 + kg];
             }
             __syncthreads();
-            run_band(y0b, inv, 0u);
+            run_band(y0b, inv);
         }
     }
-    }   // !PC
 #ifdef AADFF_SB_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stores retired
     AADFF_SB_STAMP(5);
@@ -1223,10 +1174,7 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
 #define AADFF_LAUNCH_S3(NCV, PR) do { \
                 if (ev0) hipExtLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR, true>), gs, dim3(64 * NCV), 0, st, ev0, ev1, 0, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); \
                 else hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR, false>), gs, dim3(64 * NCV), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); } while (0)
-            // AADFF_CONV_PC=1 (round 4, experiment): producer / consumer form - bands in pairs (pair_mod 1), a fourth wave stages the second
-            static const bool pc = [] { const char* e = getenv("AADFF_CONV_PC"); return e && e[0] == '1'; }();
-#define AADFF_LAUNCH_PC(NCV) hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, true, false, true>), gs, dim3(64 * (NCV + 1)), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, 1)
-#define AADFF_LAUNCH_S(NCV) do { if (pc && !ev0) AADFF_LAUNCH_PC(NCV); else if (pair) AADFF_LAUNCH_S3(NCV, true); else AADFF_LAUNCH_S3(NCV, false); } while (0)
+#define AADFF_LAUNCH_S(NCV) do { if (pair) AADFF_LAUNCH_S3(NCV, true); else AADFF_LAUNCH_S3(NCV, false); } while (0)
             switch (nc) {
                 case 1: AADFF_LAUNCH_S(1); break;
                 case 2: AADFF_LAUNCH_S(2); break;
@@ -1234,7 +1182,6 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
                 default: AADFF_LAUNCH_S(4);
             }
 #undef AADFF_LAUNCH_S
-#undef AADFF_LAUNCH_PC
 #undef AADFF_LAUNCH_S3
             return 0;
         }
