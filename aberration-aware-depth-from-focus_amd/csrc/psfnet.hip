@@ -21,6 +21,16 @@
 namespace aadff {
 namespace pn {
 
+#ifdef AADFF_PN_TRACE
+// Timeline instrumentation (tools/m2_timeline.py, build libaadff_pntrace.so): thread 0 of the first 4096 workgroups stamps the
+// 100 MHz real-time counter at its start, after the input stage and, per layer, after its k-loop, after the barrier behind it,
+// after the write-back and after the second barrier; then at the end of the epilogue.
+__device__ unsigned long long* g_pn_trace = nullptr;
+#define AADFF_PN_STAMP(slot) do { if (g_pn_trace && threadIdx.x == 0 && blockIdx.x < 4096) g_pn_trace[(size_t)blockIdx.x * 64 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AADFF_PN_STAMP(slot) do {} while (0)
+#endif
+
 constexpr int NWV = 8, NTH = 64 * NWV;
 constexpr int AP = 256;                 // activation row pitch in halves; 16-byte slots XOR-swizzled by the pixel (swz)
 constexpr int MAXL = AADFF_PSFNET_MAX_LAYERS;
@@ -84,13 +94,19 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
                                                            float* __restrict__ out, int C, int H, int W, int ks, int out_slices,
                                                            Coord coord, int* __restrict__ flags) {
     constexpr int PLANE = TP * AP;                                              // halves per activation plane
-    constexpr int ACT_HALVES = (SINGLE ? 1 : 2) * PLANE > TP * 132 * 2 ? (SINGLE ? 1 : 2) * PLANE : TP * 132 * 2;
+    // end of the kernel: fp32 PSFs [TP][132] and, behind them, the image window of the gather [3][11][TP + 10] (EPI_FLOATS)
+    constexpr int EPI_FLOATS = TP * 132 + 3 * 11 * (TP + 10);
+    constexpr int ACT_HALVES = (SINGLE ? 1 : 2) * PLANE > EPI_FLOATS * 2 ? (SINGLE ? 1 : 2) * PLANE : EPI_FLOATS * 2;
     __shared__ __attribute__((aligned(16))) _Float16 act_raw[ACT_HALVES];      // [hi | lo] planes; reused for the fp32 PSFs [TP][132] at the end
     _Float16* const act[2] = {act_raw, act_raw + (SINGLE ? 0 : PLANE)};
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = lane >> 4, lo4 = lane & 15;
     const long p0 = (long)blockIdx.x * TP;
+    AADFF_PN_STAMP(0);
+    // gather mode, <= 3 channels, all TP pixels of the workgroup inside one row of one image (workgroup-uniform): the epilogue
+    // stages the image window in LDS
+    const bool row_tile = mode == 1 && C <= 3 && p0 + TP <= P && (int)((p0 % ((long)H * W)) % W) + TP <= W;
 
     // ---- layer-0 input: features 0..3, zero-padded to 32 ----
     for (int e = tid; e < TP * 8; e += NTH) {                                   // 8 groups of 4 halves per pixel and plane
@@ -115,6 +131,7 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
         if (!SINGLE) *reinterpret_cast<half4v*>(&act[1][swz(px, 4 * g4)]) = l;
     }
     __syncthreads();
+    AADFF_PN_STAMP(1);
 
     constexpr int NPT = TP / 16;                                                // pixel tiles
     float4v acc[2][NPT];
@@ -183,7 +200,9 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
         };
         if (t1) kloop(std::integral_constant<int, 2>{});
         else if (t0) kloop(std::integral_constant<int, 1>{});
+        AADFF_PN_STAMP(2 + 4 * l);
         __syncthreads();                                                        // every wave is done reading this layer's input
+        AADFF_PN_STAMP(3 + 4 * l);
         if (!last) {
             // D^T[feat = 16 tile + 4 kg + i][px = 16 p + lo4]: bias, ReLU, split, 8-byte stores
             if (t0) {
@@ -238,7 +257,9 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
                 }
             }
         }
+        AADFF_PN_STAMP(4 + 4 * l);
         __syncthreads();
+        AADFF_PN_STAMP(5 + 4 * l);
     }
 
     // A hidden activation beyond the fp16 range was split into (inf, -inf/NaN): the outputs of this workgroup are garbage.
@@ -262,7 +283,7 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
             if (mode == 0) {
                 float* o = psf_out + gp * nout;
                 for (int t = q; t < nout; t += TPP) o[t] = row[t] * inv;
-            } else {
+            } else if (!row_tile) {
                 const long hw = (long)H * W;
                 const long nimg = gp / hw;                  // image index; with out_slices = S it is (b, slice): b * S + slice
                 const int rem = (int)(gp - nimg * hw);
@@ -292,7 +313,45 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
                 }
             }
         }
+        if (row_tile) {
+            // Round 4: the TP pixels of the workgroup are consecutive pixels of ONE image row, so their ks x (TP + ks - 1) x C
+            // image window is staged in LDS once (coalesced rows, replicate-clamped) instead of every thread fetching its taps'
+            // pixels from global memory (TP x ks^2 x C scattered loads: the epilogue went from 11.8 to 9.1 us of a workgroup's
+            // 86 us, tools/m2_timeline.py; fetched into registers at the kernel's start and parked there: 6.8 us, but the five
+            // extra registers cost the fp16 mode a wave per SIMD and the stack rate did not move - not kept).
+            float* win = reinterpret_cast<float*>(&act[0][0]) + TP * PP;
+            const long hw = (long)H * W;
+            const long nimg = p0 / hw;
+            const int rem0 = (int)(p0 - nimg * hw);
+            const long bimg = out_slices > 0 ? nimg / out_slices : nimg;
+            const long sl = out_slices > 0 ? nimg - bimg * out_slices : 0;
+            const long oslices = out_slices > 0 ? out_slices : 1;
+            const int y = rem0 / W, xs0 = rem0 - y * W;
+            const int pad = ks >> 1, ww = TP + ks - 1;
+            for (int e = tid; e < C * ks * ww; e += NTH) {
+                const int cu = e / ww, col = e - cu * ww;
+                const int c = cu / ks, u = cu - c * ks;
+                const int yy = min(max(y + u - pad, 0), H - 1), xx = min(max(xs0 + col - pad, 0), W - 1);
+                win[e] = img[(bimg * C + c) * hw + (size_t)yy * W + xx];
+            }
+            __syncthreads();
+            float a[3] = {0.f, 0.f, 0.f};
+            for (int t = q; t < nout; t += TPP) {
+                const int u = t / ks, v = t - u * ks;
+                const float wv = row[t];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (c < C) a[c] = fmaf(wv, win[(c * ks + u) * ww + px + v], a[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int m = 1; m < TPP; m <<= 1) a[c] += __shfl_xor(a[c], m, kWave);
+                if (c < C && q == 0) out[((bimg * C + c) * oslices + sl) * hw + rem0 + px] = a[c] * inv;
+            }
+        }
     }
+    AADFF_PN_STAMP(60);
 }
 
 }  // namespace pn
@@ -345,6 +404,13 @@ static int psfnet_launch(const float* inp, long P, const void* wpack, const floa
     AADFF_CHECK_LAUNCH();
     return 0;
 }
+
+#ifdef AADFF_PN_TRACE
+int aadff_pn_trace_buffer(unsigned long long* dev_buf) {      // not part of the ABI: instrumentation builds only
+    AADFF_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(aadff::pn::g_pn_trace), &dev_buf, sizeof(dev_buf)));
+    return 0;
+}
+#endif
 
 int aadff_psfnet_forward(const float* inp, long P, const void* wpack, const float* bias, int n_layers,
                          const int* in_features, const int* out_features, int mode, float* psf_out,
