@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _abi
-from deeplens.basics import DEFAULT_WAVE, EPSILON, GEO_SPP, WAVE_RGB
+from deeplens.basics import DEFAULT_WAVE, GEO_SPP, WAVE_RGB
 
 
 def strict_psf_maps_loop(lens, depth_plane_mm, focus, grid, ks, spp):
@@ -44,11 +44,17 @@ def _pupil_points(theta_u, r_u, radius, z):
 
 
 def _tables(lens, wvlns):
-    n = len(lens.surfaces)
-    arr = (_abi.Surface * (n * len(wvlns)))()
-    for li, w in enumerate(wvlns):
-        for i, s in enumerate(lens.surfaces):
-            arr[li * n + i] = s.pack(w)
+    """HOST copy of the packed surface tables of `wvlns`, cached with the lens's device tables (`Lensgroup.invalidate()` drops both:
+    packing 36 surfaces costs 1.8 ms, an eighth of a strict stack)."""
+    key = ("strict-host", tuple(float(w) for w in wvlns))
+    arr = lens._table_cache.get(key)
+    if arr is None:
+        n = len(lens.surfaces)
+        arr = (_abi.Surface * (n * len(wvlns)))()
+        for li, w in enumerate(wvlns):
+            for i, s in enumerate(lens.surfaces):
+                arr[li * n + i] = s.pack(w)
+        lens._table_cache[key] = arr
     return arr
 
 

@@ -155,6 +155,15 @@ def test_rccl_branch_on_a_one_rank_group(tmp_path):
     assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[:600]            # ONE JSON line: RCCL's version banner must not land on stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["config"]["gather"] is True and not rec["config"]["ranks_emulated_on_one_gpu"] and rec["value"] > 0
+    # the driver's own launch line for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`), here with one process: the
+    # group comes from torchrun's RANK / WORLD_SIZE / MASTER_* and the line must still be the only thing on stdout
+    from aadff.dist import free_port
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(free_port()), os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+                        "--spinup-s", "0.05", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 1, p.stdout[:600]
     env["AADFF_C3_SCENES"] = "4"
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--mode", "c3", "--steps", "3", "--warmup", "1", "--spinup-s", "0.05"],
                        env=env, capture_output=True, text=True, timeout=600)
