@@ -34,7 +34,6 @@ struct PatchBounds {
     unsigned m_ntx, m_nty, m_nchunk, m_c;
     // XCD-aware block order (xcd_remap): 1-D launches only.  gx, gy = logical grid extents; N = 8 xcd_q + xcd_r blocks (xcd_q = 0: plain order)
     unsigned gx, gy, xcd_q, xcd_r;
-    int stagger;        // start delay by residency slot (units of s_sleep 32), 0 = none
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8; observed, not promised: speed only), each with an L2 of
@@ -891,10 +890,6 @@ __global__ __launch_bounds__(64 * blk::NW, 5) void conv_psf_map_blk_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (pb.stagger) {
-        const int slot = (int)((blockIdx.x >> 8) % 6u);       // workgroups ~256 linear ids apart share a CU
-        for (int i = 0; i < slot * pb.stagger; ++i) __builtin_amdgcn_s_sleep(32);
-    }
     // 1-D launch in XCD-aware order: logical index -> (x fastest, then y, then plane / slice)
     const unsigned lin = pb.xcd_q ? xcd_remap(blockIdx.x, pb.xcd_q, pb.xcd_r) : blockIdx.x;
     const unsigned lrow = lin / pb.gx, bx = lin - lrow * pb.gx;                     // exact divisions (wave-uniform, twice per workgroup)
@@ -1204,10 +1199,8 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
                 PatchBounds pbb = pb;
                 pbb.m_ntx = magic_of(bntx); pbb.m_nty = magic_of(bnty); pbb.m_nchunk = magic_of(S); pbb.m_c = magic_of(C);
                 pbb.gx = (unsigned)gx; pbb.gy = (unsigned)gy;
-                static const bool xcd = [] { const char* e = getenv("AADFF_CONV_XCD"); return !(e && e[0] == '0'); }();
-                pbb.xcd_q = xcd && total >= 64 ? (unsigned)(total / 8) : 0u;
+                pbb.xcd_q = total >= 64 ? (unsigned)(total / 8) : 0u;
                 pbb.xcd_r = (unsigned)(total % 8);
-                pbb.stagger = [] { const char* e = getenv("AADFF_BLK_STAGGER"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
                 hipLaunchKernelGGL((conv_psf_map_blk_kernel<KS>), dim3((unsigned)total), dim3(64 * blk::NW), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, bntx, bnty, pbb);
                 return 0;
             }
