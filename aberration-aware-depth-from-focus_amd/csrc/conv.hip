@@ -33,7 +33,7 @@ struct PatchBounds {
     // n < 65536 (integer division has no scalar form on gfx950 and costs ~15 VALU slots each)
     unsigned m_ntx, m_nty, m_nchunk, m_c;
     // XCD-aware block order (xcd_remap): 1-D launches only.  gx, gy = logical grid extents; N = 8 xcd_q + xcd_r blocks (xcd_q = 0: plain order)
-    unsigned gx, gy, xcd_q, xcd_r;
+    unsigned gx, gy, xcd_q, xcd_r, m_gx, m_gy;      // m_gx / m_gy != 0: magic multipliers, valid while the launch has < 65536 blocks
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8; observed, not promised: speed only), each with an L2 of
@@ -873,6 +873,7 @@ constexpr int RPP = 240, LO = 112;        // row-pair pitch, offset of the lo pl
 constexpr int TROWS = 17, TPD = 11;       // padded tap rows (a = -3 .. 13), dwords per row (b = -3 .. 18 as halves)
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));       // 16-byte store at 4-byte alignment
+typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));       // 8-byte load at 4-byte alignment
 }  // namespace blk
 
 template <int KS, bool TIMED = false>
@@ -892,8 +893,10 @@ __global__ __launch_bounds__(64 * blk::NW, 5) void conv_psf_map_blk_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // 1-D launch in XCD-aware order: logical index -> (x fastest, then y, then plane / slice)
     const unsigned lin = pb.xcd_q ? xcd_remap(blockIdx.x, pb.xcd_q, pb.xcd_r) : blockIdx.x;
-    const unsigned lrow = lin / pb.gx, bx = lin - lrow * pb.gx;                     // exact divisions (wave-uniform, twice per workgroup)
-    const unsigned bz = lrow / pb.gy, by = lrow - bz * pb.gy;
+    // (an exact 32-bit division is ~25 instructions on the scalar path of every workgroup; launches below 65536 blocks - a
+    // 1024^2 slice has 1452 - take the magic-multiplier form)
+    const unsigned lrow = pb.m_gx ? (unsigned)udiv_magic(lin, pb.gx, pb.m_gx) : lin / pb.gx, bx = lin - lrow * pb.gx;
+    const unsigned bz = pb.m_gx ? (unsigned)udiv_magic(lrow, pb.gy, pb.m_gy) : lrow / pb.gy, by = lrow - bz * pb.gy;
     const int pj = udiv_magic(bx, ntx, pb.m_ntx), tx = bx - pj * ntx;
     const int pi = udiv_magic(by, nty, pb.m_nty), ty = by - pi * nty;
     const int bc = udiv_magic(bz, S, pb.m_nchunk), s = bz - bc * S;
@@ -918,24 +921,30 @@ __global__ __launch_bounds__(64 * blk::NW, 5) void conv_psf_map_blk_kernel(
     float amax = 0.f;
     {
         const float* plane = img + (size_t)bc * H * W;
-        const int xa = reflect_idx(x0 - PAD + 2 * lane, W), xb = reflect_idx(x0 - PAD + 2 * lane + 1, W);
-        // a lane's pixel pair is one 8-byte load wherever the two pixels are neighbours in memory (everywhere but at the
-        // reflected image borders): half the load instructions and half the cache-line look-ups of the staging
-        const bool adj = xb == xa + 1;
+        // Interior bands (no reflection at an image border: all but the outermost ring of patches) take a branch-free form: one
+        // base pointer, row r at + r W, a lane's pixel pair as ONE 8-byte load.  The staging's scalar address arithmetic is on
+        // every workgroup's critical path: 515 scalar + 264 vector instructions per wave in front of the first barrier in the
+        // general form (12 reflected rows, two loads each), which a wave issues in ~1.5 us.
+        const bool interior = x0 - PAD >= 0 && x0 - PAD + WCOLS <= W && y0 - PAD >= 0 && y0 - PAD + THP <= H;     // workgroup-uniform
+        if (interior) {
+            const float* base = plane + (size_t)(y0 - PAD + wave) * W + (x0 - PAD) + 2 * lane;
 #pragma unroll
-        for (int e = 0; e < NPT; ++e) {
-            const int r = wave + e * NW;
-            const bool in = lane < WDW && r < THP;
-            const float* row = plane + (size_t)reflect_idx(y0 - PAD + r, H) * W;
-            v0[e] = 0.f; v1[e] = 0.f;
-            if (in) {
-                if (adj) {
-                    const sb::f2u t = *reinterpret_cast<const sb::f2u*>(row + xa);
+            for (int e = 0; e < NPT; ++e) {
+                v0[e] = 0.f; v1[e] = 0.f;
+                if (lane < WDW && wave + e * NW < THP) {
+                    const float2u t = *reinterpret_cast<const float2u*>(base + (size_t)(e * NW) * W);
                     v0[e] = t.x; v1[e] = t.y;
-                } else {
-                    v0[e] = row[xa];
-                    v1[e] = row[xb];
                 }
+            }
+        } else {
+            const int xa = reflect_idx(x0 - PAD + 2 * lane, W), xb = reflect_idx(x0 - PAD + 2 * lane + 1, W);
+#pragma unroll
+            for (int e = 0; e < NPT; ++e) {
+                const int r = wave + e * NW;
+                const bool in = lane < WDW && r < THP;
+                const float* row = plane + (size_t)reflect_idx(y0 - PAD + r, H) * W;
+                v0[e] = in ? row[xa] : 0.f;
+                v1[e] = in ? row[xb] : 0.f;
             }
         }
 #pragma unroll
@@ -1199,6 +1208,9 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
                 PatchBounds pbb = pb;
                 pbb.m_ntx = magic_of(bntx); pbb.m_nty = magic_of(bnty); pbb.m_nchunk = magic_of(S); pbb.m_c = magic_of(C);
                 pbb.gx = (unsigned)gx; pbb.gy = (unsigned)gy;
+                const bool magic = total < 65536;
+                pbb.m_gx = magic ? (gx == 1 ? 1u : magic_of((unsigned)gx)) : 0u;           // (udiv_magic returns n for d == 1; the flag is m_gx != 0)
+                pbb.m_gy = magic ? (gy == 1 ? 1u : magic_of((unsigned)gy)) : 0u;
                 pbb.xcd_q = total >= 64 ? (unsigned)(total / 8) : 0u;
                 pbb.xcd_r = (unsigned)(total % 8);
                 hipLaunchKernelGGL((conv_psf_map_blk_kernel<KS>), dim3((unsigned)total), dim3(64 * blk::NW), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, bntx, bnty, pbb);
