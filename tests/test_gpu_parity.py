@@ -139,11 +139,12 @@ def test_render_psf_map_stack_slice_batched_path_vs_oracle(B, H, W, g, S):
 
 @pytest.mark.parametrize("B,Cn,H,W,g,S,ks", [(1, 3, 50, 50, 3, 1, 11), (2, 3, 97, 131, 1, 1, 11), (1, 3, 64, 230, 1, 2, 11), (1, 1, 33, 40, 4, 2, 11),
                                              (1, 3, 201, 97, 2, 1, 9), (1, 4, 120, 120, 11, 1, 11), (1, 3, 25, 300, 2, 2, 9), (1, 3, 203, 203, 2, 1, 11),
-                                             (1, 3, 61, 83, 3, 7, 9)])
+                                             (1, 3, 61, 83, 3, 7, 9), (1, 3, 13, 13, 1, 1, 11), (1, 2, 12, 200, 2, 1, 9), (1, 3, 400, 520, 3, 1, 11)])
 def test_render_psf_map_block_gemm_path_vs_oracle_and_toeplitz(B, Cn, H, W, g, S, ks, monkeypatch):
     """Lone slices at ks 9 / 11 (round 4: `conv_psf_map_blk_kernel`, a 4 x 4 block of output pixels on the MFMA M dimension;
     the S = 1 entry `render_psf_map` takes it, stacks of the same inputs take the Toeplitz / slice-batched forms): patches wider than one 96-column tile, column blocks cut by the patch border inside a 4-pixel store, bands shorter
-    than 24 rows and 8-row groups cut by the patch border, odd patch origins (16-byte stores at 4-byte alignment), B > 1, C != 3,
+    than 24 rows and 8-row groups cut by the patch border, images smaller than one band (every row reflected), interior bands (the
+    branch-free staging) next to border bands, odd patch origins (16-byte stores at 4-byte alignment), B > 1, C != 3,
     inputs far from [0, 1] (tile pre-scale) and a 1e-3 PSF (tap pre-scale).  Oracle = the reference's loop; and the Toeplitz
     form (AADFF_CONV_PATH=toeplitz), which carries the same exact operand split, to 1e-6 of the data range."""
     rng = np.random.Generator(np.random.PCG64(B * 1000 + H * 7 + W + S + ks))
