@@ -21,7 +21,7 @@ def code_sha256(*sources):
 
 def one(pattern):
     f = glob.glob(os.path.join(G, pattern), recursive=True)
-    return f[0] if f else None
+    return max(f, key=os.path.getmtime) if f else None           # a tag collected twice: the latest run
 
 
 def pmc_rows(path):
