@@ -17,7 +17,7 @@ libraries: the pupil sampling (`rand * 2 * pi`, MKL's vector sqrt / cos / sin - 
 element-wise, position independent, checked in tests), the focus and field-of-view reductions.  The host generator is consumed
 in the reference's order (per slice focus theta, focus r, then per wavelength main theta, main r, chief
 theta, chief r).  Result = the slice-by-slice strict loop's (`strict_psf_maps_loop`) to the float atomics of the histogram
-(tests/test_gpu_margins.py), 10-20x faster."""
+(tests/test_gpu_margins.py), 17-20x faster (9.5 ms per 10-slice 1024^2 stack)."""
 import ctypes as C
 import os
 import time
@@ -58,11 +58,14 @@ def _tables(lens, wvlns):
     return arr
 
 
-def _trace(o, d, ra, n, B, tabs, n_tables, n_surf, batch_table, forward, flags, dev, points=None, point_set=None, pupil=None, N=1, z_sensor=None):
+def _trace(o, d, ra, n, B, tabs, n_tables, n_surf, batch_table, forward, flags, dev, points=None, point_set=None, pupil=None, N=1, z_sensor=None,
+           tbuf=None):
     scratch = torch.empty(2 * B * _abi.MAX_SURF + 1, dtype=torch.int32, device=dev)
+    if tbuf is None:
+        tbuf = torch.empty(2 * B * n, dtype=torch.float32, device=dev)
     _abi.call("aadff_trace_rays_strict_batched", _abi.ptr(o), _abi.ptr(d), _abi.ptr(ra), n, B, C.byref(tabs), n_tables, n_surf,
               _abi.ptr(batch_table), _abi.ptr(points), _abi.ptr(point_set), _abi.ptr(pupil), N, 0, n_surf, int(forward), _abi.ptr(z_sensor),
-              _abi.ptr(scratch), _abi.ptr(flags), _abi.stream_ptr(dev))
+              _abi.ptr(scratch), _abi.ptr(tbuf), _abi.ptr(flags), _abi.stream_ptr(dev))
 
 
 @torch.no_grad()
@@ -105,18 +108,19 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp):
         mark("level 1 queued")
         ro, rd, rra = od.cpu(), dd.cpu(), rad.cpu()
         mark("level 1 back on the host")
+        # (element-wise IEEE arithmetic: the same bits for all slices at once as slice by slice; the mean stays per slice)
+        tt = (rd[..., 0] * ro[..., 0] + rd[..., 1] * ro[..., 1]) / (rd[..., 0] ** 2 + rd[..., 1] ** 2)
+        tt = tt * rra
+        fd_all = (ro[..., 2] - rd[..., 2] * tt).numpy()
+        alive = (rra > 0).numpy()
         d_sensor = []
         for k in range(S):
-            t = (rd[k, :, 0] * ro[k, :, 0] + rd[k, :, 1] * ro[k, :, 1]) / (rd[k, :, 0] ** 2 + rd[k, :, 1] ** 2)
-            t = t * rra[k]
-            focus_d = (ro[k, :, 2] - rd[k, :, 2] * t).numpy()
-            focus_d = focus_d[rra[k] > 0]
+            focus_d = fd_all[k][alive[k]]
             focus_d = focus_d[~np.isnan(focus_d) & (focus_d > 0)]
             with np.errstate(all="ignore"):
                 z = float(np.mean(focus_d)) if len(focus_d) else float("nan")
             assert z > 0, "sensor position is negative."
             d_sensor.append(z)
-
         mark("d_sensor")
         # ---- level 2: calc_fov (deeplens/optics.py:1187-1217) - S batches of 100 rays from the sensor corner, backward
         M = 100
@@ -163,19 +167,19 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp):
         centre = torch.empty((B, N, 2), dtype=f32, device=dev)
         any_valid = torch.zeros(B, dtype=torch.int32, device=dev)
         # chief rays (always the default wavelength, shrunk pupil) -> centres; the main rays then reuse their buffers.  The ray
-        # state of a level (B x n x 28 bytes: 208 MB for the bench stack) is kept on the lens between calls: handing it back to
+        # state of a level (B x n x 36 bytes incl. the iterate buffer: 268 MB for the bench stack) is kept on the lens between calls: handing it back to
         # torch's caching allocator made every other call re-allocate it from the driver (65-100 ms instead of 15)
         nmax = max(spp, GEO_SPP) * N
         buf = getattr(lens, "_strict_rays", None)
         if buf is None or buf[0].shape[0] < B * nmax * 3 or buf[0].device != dev:
             buf = lens._strict_rays = (torch.empty(B * nmax * 3, dtype=f32, device=dev), torch.empty(B * nmax * 3, dtype=f32, device=dev),
-                                       torch.empty(B * nmax, dtype=f32, device=dev))
+                                       torch.empty(B * nmax, dtype=f32, device=dev), torch.empty(2 * B * nmax, dtype=f32, device=dev))
         oc, dc, rac = buf[0][:B * GEO_SPP * N * 3].view(B, GEO_SPP * N, 3), buf[1][:B * GEO_SPP * N * 3].view(B, GEO_SPP * N, 3), buf[2][:B * GEO_SPP * N].view(B, GEO_SPP * N)
-        _trace(oc, dc, rac, GEO_SPP * N, B, tabs, len(wv), n_surf, bt_chief, True, flags[2:3], dev, points, pset, pc, N, zs)
+        _trace(oc, dc, rac, GEO_SPP * N, B, tabs, len(wv), n_surf, bt_chief, True, flags[2:3], dev, points, pset, pc, N, zs, buf[3][:2 * B * GEO_SPP * N])
         _abi.call("aadff_strict_centroid", _abi.ptr(oc), _abi.ptr(rac), GEO_SPP, N, B, _abi.ptr(centre), _abi.ptr(any_valid), _abi.stream_ptr(dev))
         om, dm, ram = buf[0][:B * spp * N * 3].view(B, spp * N, 3), buf[1][:B * spp * N * 3].view(B, spp * N, 3), buf[2][:B * spp * N].view(B, spp * N)
         flag_m = torch.zeros(1, dtype=torch.int32, device=dev)
-        _trace(om, dm, ram, spp * N, B, tabs, len(wv), n_surf, bt_main, True, flag_m, dev, points, pset, pm, N, zs)
+        _trace(om, dm, ram, spp * N, B, tabs, len(wv), n_surf, bt_main, True, flag_m, dev, points, pset, pm, N, zs, buf[3][:2 * B * spp * N])
         raw = torch.empty((B, N, ks, ks), dtype=f32, device=dev)
         nrm = torch.empty((N, ks, ks), dtype=f32, device=dev)
         st = _abi.stream_ptr(dev)

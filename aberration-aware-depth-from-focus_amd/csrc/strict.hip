@@ -94,15 +94,18 @@ __device__ __forceinline__ float clamp_step(float v) {                          
 // Counting launch: every ray runs all ten loose iterations from the vertex plane; bit j of `mask` says that some ray of
 // the batch still had |ft| > 5e-5 in iteration j + 1 (dead rays take part with their masked residual, as in the reference).
 // ten loose iterations from the vertex plane for ONE ray: bit j of `mine` = |ft| > 5e-5 in iteration j + 1, of `nans` = NaN residual
-__device__ __forceinline__ void count_ray(const Surf& s, R3 o, R3 d, bool alive, unsigned& mine, unsigned& nans, int iters = kMaxIter) {
-    float t = (s.d - o.z) / d.z;
-    for (int it = 0; it < iters; ++it) {
+__device__ __forceinline__ float count_ray(const Surf& s, R3 o, R3 d, bool alive, unsigned& mine, unsigned& nans, int it0 = 0, int it1 = kMaxIter,
+                                           float t_start = 0.f) {
+    // iterations it0 .. it1 - 1 of the loose loop (it0 > 0: continued from t_start, the value after it0 iterations); returns t after them
+    float t = it0 == 0 ? (s.d - o.z) / d.z : t_start;
+    for (int it = it0; it < it1; ++it) {
         float ft, dfdt;
         residual<false>(s, o, d, alive, t, ft, dfdt);
         if (ft != ft) nans |= 1u << it;
         if (fabsf(ft) > kTolLoose) mine |= 1u << it;
         t = t - clamp_step(ft / (dfdt + kEps));
     }
+    return t;
 }
 
 __global__ __launch_bounds__(256) void newton_count_kernel(const float* __restrict__ o_in, const float* __restrict__ d_in,
@@ -135,7 +138,7 @@ __device__ __forceinline__ int iterations_of(unsigned m) {
 }
 
 // One surface interaction of ONE ray with the batch's iteration count (surfaces.py:391-520).
-__device__ __forceinline__ void react_ray(const Surf& s, R3& o, R3& d, float& ra, int forward, int n_iter) {
+__device__ __forceinline__ void react_ray(const Surf& s, R3& o, R3& d, float& ra, int forward, int n_iter, bool have_t = false, float t_pre = 0.f) {
     const bool alive = ra > 0.f;
     float px, py, pz;
     bool valid;
@@ -146,11 +149,13 @@ __device__ __forceinline__ void react_ray(const Surf& s, R3& o, R3& d, float& ra
     } else {
         const float t0 = (s.d - o.z) / d.z;
         float t = t0;
-        for (int it = 0; it < n_iter; ++it) {
-            float ft, dfdt;
-            residual<false>(s, o, d, alive, t, ft, dfdt);
-            t = t - clamp_step(ft / (dfdt + kEps));
-        }
+        if (have_t) t = t_pre;                                                     // the counting pass already holds t after n_iter iterations
+        else
+            for (int it = 0; it < n_iter; ++it) {
+                float ft, dfdt;
+                residual<false>(s, o, d, alive, t, ft, dfdt);
+                t = t - clamp_step(ft / (dfdt + kEps));
+            }
         const float t1 = t - t0;
         t = t0 + t1;                                                               // surfaces.py:565-569 (not an identity in float32)
         float ft, dfdt;
@@ -225,10 +230,14 @@ __global__ __launch_bounds__(256) void propagate_kernel(float* o_io, const float
 // of surface i + 1 on the state it still holds in registers, and the first kernel builds the rays (sample_from_points +
 // Ray.__init__, deeplens/optics.py:482-491, basics.py:216-244: o2 - o, F.normalize) before it counts.
 // Counting in two instalments: the reference's loop stops at the FIRST iteration in which no ray of the batch is above the
-// tolerance, so only the any-bits up to that iteration matter.  The fused count runs kFirstIters iterations (a batch needs 3-4
-// everywhere but at the first surface); `batched_count_more_kernel` follows every such launch and runs all ten for the batches
-// whose first kFirstIters bits are all set (the others leave at once) - the same bits as counting ten everywhere, at 40 % of the
-// arithmetic.
+// tolerance, so only the any-bits up to that iteration matter.  The fused count runs kFirstIters iterations; for the batches whose
+// first kFirstIters bits are all set `batched_count_more_kernel` CONTINUES to ten from where the fused count stopped (the others
+// leave at once).  The iterate is handed on through `tbuf` (one float per ray): the fused count leaves t after kFirstIters
+// iterations there (and t after kFirstIters - 1 in its second half), the continuation overwrites it with t after ten - and the
+// launch that applies the surface takes it from there instead of iterating again whenever the batch's count is 3, 4 or ten (the same function on the same state: the same
+// bits).  That matters: the chief-ray batches need 3-5 iterations per surface, but the full-pupil batches of psf_map run all TEN
+// at nine of the eleven curved surfaces of rf50mm (rays outside a surface's clear aperture never converge and keep the batch-wide
+// loop going, tools/strict_iterations.py) - 11 residual evaluations per ray and surface instead of 25.
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int kMaxTables = 4, kFirstIters = 4;
 struct SurfSet { Surf s[kMaxTables]; };
@@ -257,7 +266,7 @@ template <bool FROM_POINTS>
 __global__ __launch_bounds__(256) void batched_begin_kernel(float* o_io, float* d_io, float* ra_io, int n, const int* __restrict__ batch_table,
                                                             SurfSet first, int first_idx, const float* __restrict__ points,
                                                             const int* __restrict__ point_set, const float* __restrict__ pupil, int N,
-                                                            unsigned* masks, int B) {
+                                                            unsigned* masks, int B, float* __restrict__ tbuf) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     const Surf& s = first.s[batch_table[b]];
     unsigned mine = 0, nans = 0;
@@ -281,7 +290,11 @@ __global__ __launch_bounds__(256) void batched_begin_kernel(float* o_io, float* 
             o = {a.x, a.y, a.z}; d = {c.x, c.y, c.z};
             ra = ra_io[idx];
         }
-        if (!s.flat) count_ray(s, o, d, ra > 0.f, mine, nans, kFirstIters);
+        if (!s.flat) {
+            const float t3 = count_ray(s, o, d, ra > 0.f, mine, nans, 0, kFirstIters - 1);
+            const float t4 = count_ray(s, o, d, ra > 0.f, mine, nans, kFirstIters - 1, kFirstIters, t3);
+            if (tbuf) { tbuf[idx] = t4; tbuf[(size_t)B * n + idx] = t3; }
+        }
     }
     publish_bits(mine, nans, masks + (size_t)b * AADFF_MAX_SURF + first_idx, masks + (size_t)(B + b) * AADFF_MAX_SURF + first_idx);
 }
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(256) void batched_begin_kernel(float* o_io, float* 
 // counting iterations of surface nxt_idx or, behind the last surface, Ray.propagate_to(z_sensor[b]) (basics.py:255-273).
 __global__ __launch_bounds__(256) void batched_step_kernel(float* o_io, float* d_io, float* ra_io, int n, const int* __restrict__ batch_table,
                                                            SurfSet cur, int cur_idx, SurfSet nxt, int nxt_idx, int forward,
-                                                           const float* __restrict__ z_sensor, unsigned* masks, int B) {
+                                                           const float* __restrict__ z_sensor, unsigned* masks, int B, float* __restrict__ tbuf) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     const int tb = batch_table[b];
     const Surf& s = cur.s[tb];
@@ -303,7 +316,9 @@ __global__ __launch_bounds__(256) void batched_step_kernel(float* o_io, float* d
         const f3u a = *reinterpret_cast<const f3u*>(o_io + idx * 3), c = *reinterpret_cast<const f3u*>(d_io + idx * 3);
         R3 o = {a.x, a.y, a.z}, d = {c.x, c.y, c.z};
         float ra = ra_io[idx];
-        react_ray(s, o, d, ra, forward, n_iter);
+        // the iterate the counting pass left: t after 4 or 10 iterations in the first half of tbuf, after 3 in the second
+        const bool have_t = tbuf && !s.flat && (n_iter == kFirstIters || n_iter == kMaxIter || n_iter == kFirstIters - 1);
+        react_ray(s, o, d, ra, forward, n_iter, have_t, have_t ? tbuf[(n_iter == kFirstIters - 1 ? (size_t)B * n : (size_t)0) + idx] : 0.f);
         if (nxt_idx < 0 && z_sensor) {
             const float t = (z_sensor[b] - o.z) / d.z;
             o.x = o.x + d.x * t; o.y = o.y + d.y * t; o.z = o.z + d.z * t;
@@ -311,7 +326,11 @@ __global__ __launch_bounds__(256) void batched_step_kernel(float* o_io, float* d
         *reinterpret_cast<f3u*>(o_io + idx * 3) = (f3u){o.x, o.y, o.z};
         *reinterpret_cast<f3u*>(d_io + idx * 3) = (f3u){d.x, d.y, d.z};
         ra_io[idx] = ra;
-        if (nxt_idx >= 0 && !nxt.s[tb].flat) count_ray(nxt.s[tb], o, d, ra > 0.f, mine, nans, kFirstIters);
+        if (nxt_idx >= 0 && !nxt.s[tb].flat) {
+            const float t3 = count_ray(nxt.s[tb], o, d, ra > 0.f, mine, nans, 0, kFirstIters - 1);
+            const float t4 = count_ray(nxt.s[tb], o, d, ra > 0.f, mine, nans, kFirstIters - 1, kFirstIters, t3);
+            if (tbuf) { tbuf[idx] = t4; tbuf[(size_t)B * n + idx] = t3; }
+        }
     }
     if (nxt_idx >= 0)
         publish_bits(mine, nans, masks + (size_t)b * AADFF_MAX_SURF + nxt_idx, masks + (size_t)(B + b) * AADFF_MAX_SURF + nxt_idx);
@@ -319,7 +338,8 @@ __global__ __launch_bounds__(256) void batched_step_kernel(float* o_io, float* d
 
 // Second instalment of the count: batches that were still above the tolerance in all of the first kFirstIters iterations.
 __global__ __launch_bounds__(256) void batched_count_more_kernel(const float* __restrict__ o_in, const float* __restrict__ d_in, const float* __restrict__ ra_in,
-                                                                 int n, const int* __restrict__ batch_table, SurfSet cur, int cur_idx, unsigned* masks, int B) {
+                                                                 int n, const int* __restrict__ batch_table, SurfSet cur, int cur_idx, unsigned* masks, int B,
+                                                                 float* __restrict__ tbuf) {
     // a fixed, small grid walking the batch (grid-stride): the launch mostly finds nothing to do, and 1.7 M workgroups that
     // leave at once cost 60 us per launch in dispatch alone (rocprofv3, round 4)
     const int b = blockIdx.y;
@@ -330,7 +350,8 @@ __global__ __launch_bounds__(256) void batched_count_more_kernel(const float* __
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const size_t idx = (size_t)b * n + i;
         const f3u a = *reinterpret_cast<const f3u*>(o_in + idx * 3), c = *reinterpret_cast<const f3u*>(d_in + idx * 3);
-        count_ray(s, {a.x, a.y, a.z}, {c.x, c.y, c.z}, ra_in[idx] > 0.f, mine, nans);
+        if (tbuf) tbuf[idx] = count_ray(s, {a.x, a.y, a.z}, {c.x, c.y, c.z}, ra_in[idx] > 0.f, mine, nans, kFirstIters, kMaxIter, tbuf[idx]);
+        else count_ray(s, {a.x, a.y, a.z}, {c.x, c.y, c.z}, ra_in[idx] > 0.f, mine, nans);
     }
     publish_bits(mine, nans, masks + (size_t)b * AADFF_MAX_SURF + cur_idx, masks + (size_t)(B + b) * AADFF_MAX_SURF + cur_idx);
 }
@@ -489,7 +510,7 @@ extern "C" int aadff_trace_rays_strict(float* o, float* d, float* ra, int n, con
 extern "C" int aadff_trace_rays_strict_batched(float* o, float* d, float* ra, int n, int B, const aadff_surface_t* tables_host, int n_tables,
                                                int n_surf, const int* batch_table, const float* points_or_null, const int* point_set,
                                                const float* pupil, int N, int first, int last, int forward, const float* z_sensor_or_null,
-                                               unsigned* scratch, int* flags_or_null, aadff_stream_t stream) {
+                                               unsigned* scratch, float* tbuf_or_null, int* flags_or_null, aadff_stream_t stream) {
     AADFF_CHECK_ARG(o && d && ra && tables_host && batch_table && scratch, "trace_rays_strict_batched: NULL pointer");
     AADFF_CHECK_ARG(n >= 0 && B >= 1 && B <= 65535, "trace_rays_strict_batched: n=%d B=%d", n, B);
     AADFF_CHECK_ARG(n_tables >= 1 && n_tables <= strict::kMaxTables, "trace_rays_strict_batched: %d tables (1..%d)", n_tables, strict::kMaxTables);
@@ -511,17 +532,17 @@ extern "C" int aadff_trace_rays_strict_batched(float* o, float* d, float* ra, in
     auto surf_at = [&](int k) { return forward ? first + k : last - 1 - k; };
     strict::SurfSet cur = set_of(surf_at(0));
     if (points_or_null)
-        hipLaunchKernelGGL(strict::batched_begin_kernel<true>, g, blk, 0, st, o, d, ra, n, batch_table, cur, surf_at(0), points_or_null, point_set, pupil, N, scratch, B);
+        hipLaunchKernelGGL(strict::batched_begin_kernel<true>, g, blk, 0, st, o, d, ra, n, batch_table, cur, surf_at(0), points_or_null, point_set, pupil, N, scratch, B, tbuf_or_null);
     else
         hipLaunchKernelGGL(strict::batched_begin_kernel<false>, g, blk, 0, st, o, d, ra, n, batch_table, cur, surf_at(0), (const float*)nullptr, (const int*)nullptr,
-                           (const float*)nullptr, 1, scratch, B);
-    hipLaunchKernelGGL(strict::batched_count_more_kernel, gm, blk, 0, st, o, d, ra, n, batch_table, cur, surf_at(0), scratch, B);
+                           (const float*)nullptr, 1, scratch, B, tbuf_or_null);
+    hipLaunchKernelGGL(strict::batched_count_more_kernel, gm, blk, 0, st, o, d, ra, n, batch_table, cur, surf_at(0), scratch, B, tbuf_or_null);
     for (int k = 0; k < nsteps; ++k) {
         const bool has_next = k + 1 < nsteps;
         strict::SurfSet nxt = has_next ? set_of(surf_at(k + 1)) : cur;
         hipLaunchKernelGGL(strict::batched_step_kernel, g, blk, 0, st, o, d, ra, n, batch_table, cur, surf_at(k), nxt, has_next ? surf_at(k + 1) : -1, forward,
-                           z_sensor_or_null, scratch, B);
-        if (has_next) hipLaunchKernelGGL(strict::batched_count_more_kernel, gm, blk, 0, st, o, d, ra, n, batch_table, nxt, surf_at(k + 1), scratch, B);
+                           z_sensor_or_null, scratch, B, tbuf_or_null);
+        if (has_next) hipLaunchKernelGGL(strict::batched_count_more_kernel, gm, blk, 0, st, o, d, ra, n, batch_table, nxt, surf_at(k + 1), scratch, B, tbuf_or_null);
         cur = nxt;
     }
     if (flags_or_null)

@@ -361,7 +361,7 @@ def main():
                              "against": "oracle (CPU restatement pinned to the reference by tests/golden), seed 0, "
                                         "same image / depth plane / focus distances as the timed steps"}
             # the same stack through Lensgroup(parity="strict") (reference operation order on the GPU, reference host arithmetic;
-            # ~15 ms per stack, untimed): every slice must meet the tolerance on its own, no floor widening
+            # ~10 ms per stack, untimed): every slice must meet the tolerance on its own, no floor widening
             try:
                 from aadff.focal_stack import render_focal_stack_m1 as _rfs
                 ls = Lensgroup(lens_path, sensor_res=(H, W), device=dev, parity="strict")

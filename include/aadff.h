@@ -196,11 +196,14 @@ int aadff_trace_rays_strict(float* o, float* d, float* ra, int n, const aadff_su
  * deeplens/basics.py:216-244): ray i of batch b = (sample i / N, point i % N): o = points[point_set[b]][i % N] ([P,N,3] object
  * points, device), d = F.normalize(pupil[b][i / N] - o) (pupil [B, n / N, 3], device), ra = 1; o / d / ra are outputs then.
  * z_sensor_or_null [B] (device): Ray.propagate_to(z_sensor[b]) behind the last surface (trace2sensor).
- * scratch: 2*B*AADFF_MAX_SURF + 1 device words (zeroed by the call); flags_or_null as aadff_trace_rays_strict (any batch). */
+ * scratch: 2*B*AADFF_MAX_SURF + 1 device words (zeroed by the call); flags_or_null as aadff_trace_rays_strict (any batch).
+ * tbuf_or_null: 2*B*n floats (device, scratch): the Newton iterates handed from the counting pass of a surface to the launch that
+ * applies it, which then does not iterate again when the batch's count is 3, 4 or 10 (same function, same state: same bits); NULL
+ * recomputes. */
 int aadff_trace_rays_strict_batched(float* o, float* d, float* ra, int n, int B, const aadff_surface_t* tables_host, int n_tables,
                                     int n_surf, const int* batch_table, const float* points_or_null, const int* point_set,
                                     const float* pupil, int N, int first, int last, int forward, const float* z_sensor_or_null,
-                                    unsigned* scratch, int* flags_or_null, aadff_stream_t stream);
+                                    unsigned* scratch, float* tbuf_or_null, int* flags_or_null, aadff_stream_t stream);
 
 /* Chief-ray PSF centres of B batches: centre[b][p] = -(sum_s o_xy[b,s,p] ra[b,s,p]) / (sum_s ra[b,s,p] + 1e-9), o [B,spp,N,3],
  * ra [B,spp,N] (device) -> centre [B,N,2]; any_valid [B] = 1 where some ray of the batch has ra == 1 (the reference asserts it:
