@@ -883,7 +883,15 @@ __global__ __launch_bounds__(64 * blk::NW, 5) void conv_psf_map_blk_kernel(
     using namespace blk;
     constexpr int PAD = KS / 2;
     static_assert(KS == 9 || KS == 11, "the 14 x 14 window of a 4 x 4 block holds taps up to 11 x 11");
-    AADFF_SB_STAMP(0);
+#ifdef AADFF_SB_TRACE
+    // (one wave-uniform base pointer for all stamps of this kernel: with the global macro's per-stamp address arithmetic the
+    // instrumented build spilled 68 registers at 96 VGPRs and its timeline meant nothing)
+    unsigned long long* const trace_slot = g_sb_trace ? g_sb_trace + (size_t)blockIdx.x * 8 : nullptr;
+#define AADFF_BLK_STAMP(slot) do { if (trace_slot && threadIdx.x == 0) trace_slot[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AADFF_BLK_STAMP(slot) do {} while (0)
+#endif
+    AADFF_BLK_STAMP(0);
     __shared__ __attribute__((aligned(16))) unsigned tile[(THP / 2) * RPP];
     __shared__ __attribute__((aligned(16))) unsigned ptap[2][TROWS * TPD];       // [hi | lo] planes of the zero-padded taps
     __shared__ float red[NW];
@@ -977,7 +985,7 @@ __global__ __launch_bounds__(64 * blk::NW, 5) void conv_psf_map_blk_kernel(
     }
     amax = wave_max(amax);
     if (lane == 0) red[wave] = amax;
-    AADFF_SB_STAMP(1);                                                        // global loads have arrived (wave 0)
+    AADFF_BLK_STAMP(1);                                                        // global loads have arrived (wave 0)
     __syncthreads();
     float tmax = red[0];
 #pragma unroll
@@ -1019,8 +1027,7 @@ __global__ __launch_bounds__(64 * blk::NW, 5) void conv_psf_map_blk_kernel(
     }
     const float inv = isx * s_isw;
     __syncthreads();                                                          // the whole band is in LDS
-    AADFF_SB_STAMP(2);
-    AADFF_SB_STAMP(3);
+    AADFF_BLK_STAMP(2);
 
     // ---- matrix phase: column block `wave` of the band, groups of 8 rows x 7 k-steps.  (Measured, round 4: hand-pipelined
     //      operand reads - inline asm two steps ahead through three buffers, as in the slice-batched kernel - are SLOWER here,
@@ -1063,11 +1070,12 @@ __global__ __launch_bounds__(64 * blk::NW, 5) void conv_psf_map_blk_kernel(
         }
     }
 #ifdef AADFF_SB_TRACE
-    AADFF_SB_STAMP(4);
+    AADFF_BLK_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stores retired
-    AADFF_SB_STAMP(5);
+    AADFF_BLK_STAMP(5);
 #endif
 }
+#undef AADFF_BLK_STAMP
 
 // ------------------------------------------------------------------------------------
 // Generic path (any odd ks <= AADFF_MAX_KS): same tiling, runtime loops, PSF taps staged

@@ -62,8 +62,8 @@ def main():
         q = lambda v: [round(float(np.percentile(v, p)), 2) for p in (10, 50, 90)]
         res.append({"event_us": round(e0.elapsed_time(e1) * 1e3, 2), "workgroups": int(len(t)), "span_us": round(float(us(5).max()), 2),
                     "start_us_p10_50_90": q(us(0)), "start_max_us": round(float(us(0).max()), 2),
-                    "loads_us": q(us(1) - us(0)), "tile_to_lds_us": q(us(2) - us(1)), "taps_us": q(us(3) - us(2)),
-                    "mfma_us": q(us(4) - us(3)), "stores_us": q(us(5) - us(4)), "life_us": q(us(5) - us(0)), "end_us_p10_50_90": q(us(5))})
+                    "loads_us": q(us(1) - us(0)), "tile_to_lds_us": q(us(2) - us(1)), "taps_us": q(np.maximum(us(3), us(2)) - us(2)),
+                    "mfma_us": q(us(4) - np.maximum(us(3), us(2))), "stores_us": q(us(5) - us(4)), "life_us": q(us(5) - us(0)), "end_us_p10_50_90": q(us(5))})
     assert lib.aadff_sb_trace_buffer(None) == 0
     res.sort(key=lambda d: d["event_us"])
     med = res[len(res) // 2]
