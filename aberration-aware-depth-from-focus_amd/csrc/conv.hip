@@ -1059,7 +1059,9 @@ __global__ __launch_bounds__(64 * blk::NW, 5) void conv_psf_map_blk_kernel(
                 if (y < y_hi) {
                     float* o = obase + (size_t)y * W;
                     const float a0 = acc[0] * inv, a1 = acc[1] * inv, a2 = acc[2] * inv, a3 = acc[3] * inv;
-                    if (full) *reinterpret_cast<float4u*>(o) = (float4u){a0, a1, a2, a3};
+                    // non-temporal: the 12.6 MB of output are not parked in L2 until the kernel's end-of-launch write-back (-5 %:
+                    // 13.1-13.4 against 13.9-14.0 us, same box, tools/kbench.py)
+                    if (full) __builtin_nontemporal_store((float4u){a0, a1, a2, a3}, reinterpret_cast<float4u*>(o));
                     else {
                         if (x < x_hi) o[0] = a0;
                         if (x + 1 < x_hi) o[1] = a1;
