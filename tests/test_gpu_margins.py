@@ -179,9 +179,10 @@ def test_margin_bench_stack_strict_parity_mode(golden_dir, repo_root, margin):
     (aadff_trace_rays_strict: one launch pair per surface, batch-wide Newton iteration counts, IEEE division / sqrt, no fma
     contraction) and the reference's host-side arithmetic done by the same torch / numpy calls.  EVERY slice is held to the
     north-star 1e-4 with NO floor widening (the two wide-PSF slices, 1.5e-4 / 1.1e-4 in the fast build, come out at
-    <= 7e-5; slices whose d_sensor / hfov / pupil reproduce to the bit at < 1e-6).  About 7 s per stack: a verification mode."""
+    <= 7e-5; slices whose d_sensor / hfov / pupil reproduce to the bit at < 1e-6).  10 ms per stack (three batched traces)."""
     import time
     g = np.load(os.path.join(golden_dir, "g9_stack_m1_1024.npz"))
+    fl = np.load(os.path.join(golden_dir, "g13_fp32_floor.npz"))
     H = W = 1024
     S = 10
     lens = Lensgroup(lp(repo_root), sensor_res=(H, W), device=DEV, parity="strict")
@@ -201,7 +202,9 @@ def test_margin_bench_stack_strict_parity_mode(golden_dir, repo_root, margin):
         num += float((dlt * dlt).sum())
         den += float((ref * ref).sum())
         margin(f"strict mode: slice {k} full-image rel-L2 vs reference PSFs (no floor widening)", np.sqrt((dlt * dlt).sum() / (ref * ref).sum()), 1e-4)
-        margin(f"strict mode: slice {k} PSF map rel-L2", rel(maps[k].cpu().numpy(), g["psf_maps"][k]), 2e-3 if k not in (1, 2) else 4e-3)
+        # PSF tolerance 2e-3, or that slice's own fp32-vs-fp64 floor where the floor is above it (G13: slices 1 and 2, 5.0e-3 / 3.3e-3)
+        margin(f"strict mode: slice {k} PSF map rel-L2 (fp32 floor {fl['psf_floor'][k]:.1e})", rel(maps[k].cpu().numpy(), g["psf_maps"][k]),
+               max(2e-3, float(fl["psf_floor"][k])))
     margin("strict mode: whole stack, full-image rel-L2", np.sqrt(num / den), 1e-4)
     crops = {"seam": s[:, :, 61:125, 154:218], "centre": s[:, :, 480:544, 480:544], "corner": s[:, :, 960:1024, 960:1024]}
     for k, v in crops.items():
