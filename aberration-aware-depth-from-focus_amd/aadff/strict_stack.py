@@ -1,23 +1,27 @@
-"""parity="strict" for a whole focal stack in THREE batched traces instead of 72 S single ones.
+"""parity="strict" for a whole focal stack: three LEVELS instead of 72 S single traces, each level ONE launch.
 
 The reference's loop (2_aber_aware_dff_aif.py:104-114 over deeplens/optics.py:1155-1217 refocus / calc_fov and :888-1026 psf_map)
 makes, per slice, one 2048-ray focus trace, one 100-ray field-of-view trace and 3 x 2 traces of spp x N rays; each is its own
 Newton batch (`while (|ft| > 5e-5).any()`, deeplens/surfaces.py:547).  Slices do not depend on each other, and within a slice
-only  focus -> d_sensor -> field of view -> hfov -> object points  is a chain.  So the stack is three LEVELS, each ONE call of
-`aadff_trace_rays_strict_batched` (one launch per surface for all batches of the level, every batch with its own iteration
-counts, wavelength table and sensor plane; csrc/strict.hip):
+only  focus -> d_sensor -> field of view -> hfov -> object points  is a chain.  So the stack is three levels:
 
   level 1   S focus batches (2048 rays)                    host: the reference's focus-distance arithmetic, np.mean per slice
   level 2   S field-of-view batches (100 rays, backward)   host: tan / sum / atan per slice
-  level 3   3 S main batches + 3 S chief batches           rays BUILT on the device (o2 - o, F.normalize), chief-ray centres by
-            (spp x N rays each)                            `aadff_strict_centroid` in ATen's summation order, histogram kernel
+  level 3   3 S main batches + 3 S chief batches           rays BUILT on the device (o2 - o, F.normalize), chief-ray centres in
+            (spp x N rays each)                            ATen's summation order, histogram, normalisation, psf_map tiling
+
+Round 5 (`AADFF_STRICT_FUSED=1`, default): every level is one launch of csrc/strict_fused.hip - a ray crosses all surfaces in
+registers - with the batch-wide Newton counts SPECULATED from a per-lens table (`StrictCounts`) and verified afterwards from the
+any-bits the launch saw: n is the reference's count for (batch, surface) <=> bits 0..n-2 are set and (bit n-1 is clear or n == 10).
+The table is seeded by one run of the round-4 form below (`aadff_trace_rays_strict_batched`: one launch pair per surface, counting
+passes), which also REPLAYS any batch whose prediction failed and corrects its row.  Same rays, same per-ray arithmetic: identical
+d_sensor / hfov, PSF maps equal to the float atomics of the histogram (tests/test_gpu_margins.py).
 
 What stays on the host is what the reference computes there with torch / numpy and what cannot be reproduced off its
 libraries: the pupil sampling (`rand * 2 * pi`, MKL's vector sqrt / cos / sin - evaluated for all slices in one call each:
 element-wise, position independent, checked in tests), the focus and field-of-view reductions.  The host generator is consumed
 in the reference's order (per slice focus theta, focus r, then per wavelength main theta, main r, chief
-theta, chief r).  Result = the slice-by-slice strict loop's (`strict_psf_maps_loop`) to the float atomics of the histogram
-(tests/test_gpu_margins.py), 17-20x faster (9.5 ms per 10-slice 1024^2 stack)."""
+theta, chief r)."""
 import ctypes as C
 import os
 import time
@@ -28,6 +32,8 @@ import torch.nn.functional as F
 
 from . import _abi
 from deeplens.basics import DEFAULT_WAVE, GEO_SPP, WAVE_RGB
+
+MAX_ITER = 10
 
 
 def strict_psf_maps_loop(lens, depth_plane_mm, focus, grid, ks, spp):
@@ -58,30 +64,370 @@ def _tables(lens, wvlns):
     return arr
 
 
+# ---------------------------------------------------------------------------------------------------------------- count table
+def counts_of_masks(any_bits):
+    """any-bits words -> the iterations the reference's loop runs: the first iteration whose bit is clear, at most ten
+    (`iterations_of`, csrc/strict_math.h)."""
+    m = np.asarray(any_bits).astype(np.uint32)
+    n = np.full(m.shape, MAX_ITER, dtype=np.int32)
+    for it in range(MAX_ITER - 1, -1, -1):
+        n = np.where((m >> np.uint32(it)) & 1 == 0, it + 1, n)
+    return n
+
+
+def prediction_holds(any_bits, pred, curved):
+    """[..., n_surf] any-bits seen by a fused launch that ran pred iterations -> [...] bool: every curved surface of the batch
+    shows "bits 0..n-2 set and (bit n-1 clear or n == 10)"."""
+    m = np.asarray(any_bits).astype(np.uint32)
+    n = np.asarray(pred).astype(np.uint32)
+    low = (np.uint32(1) << (n - 1)) - np.uint32(1)
+    ok = ((m & low) == low) & ((n == MAX_ITER) | (((m >> (n - 1)) & 1) == 0))
+    return np.all(ok | ~np.asarray(curved, dtype=bool), axis=-1)
+
+
+def check_counts(any_bits, pred, curved, order):
+    """The any-bits a fused launch saw under the predicted counts -> (ok [...], corrected [..., n_surf]).  Surfaces are examined in the
+    order the rays cross them (`order`); at the FIRST curved surface whose prediction n fails the batch is marked bad and its row
+    corrected there - an earlier iteration without any ray above the tolerance gives the true count (first clear bit + 1); all n
+    bits set with n < 10 means the loop runs on: n + 1 is tried - and nothing behind that surface is looked at (its bits are
+    meaningless)."""
+    m = np.asarray(any_bits).astype(np.uint32)
+    fix = np.array(pred, dtype=np.int32, copy=True)
+    ok = np.ones(m.shape[:-1], dtype=bool)
+    for i in order:
+        if not curved[i]:
+            continue
+        n = fix[..., i].astype(np.uint32)
+        mi = m[..., i]
+        low = (np.uint32(1) << (n - 1)) - np.uint32(1)
+        short = (mi & low) != low
+        more = ~short & (n < MAX_ITER) & (((mi >> (n - 1)) & 1) == 1)
+        bad = (short | more) & ok
+        if bad.any():
+            true_n = counts_of_masks(mi | ~low)
+            fix[..., i] = np.where(bad, np.where(short, true_n, n.astype(np.int32) + 1), fix[..., i])
+            ok &= ~bad
+    return ok, fix
+
+
+class StrictCounts:
+    """Predicted batch-wide Newton counts of one lens, per level: key -> int32 [B, (2,) MAX_SURF].  Lives in the lens's table cache
+    (dropped by `Lensgroup.invalidate()`); `stats` counts seed runs, fused runs and replayed batches."""
+
+    def __init__(self):
+        self.rows = {}
+        self.seen = {}                                    # key -> uint16 [..., MAX_SURF]: bit n set = count n has been the truth
+        self.stats = {"seeded": 0, "fused": 0, "replayed_batches": 0, "fused_replays": 0, "per_surface_replays": 0}
+
+    def learn(self, key, rows):
+        """`rows` are TRUE counts of this call: they become the prediction and join the alternatives seen."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        self.rows[key] = rows
+        bit = (np.uint16(1) << rows.astype(np.uint16)).astype(np.uint16)
+        old = self.seen.get(key)
+        self.seen[key] = bit if old is None or old.shape != bit.shape else (old | bit)
+
+    def candidates(self, key, b, limit=4):
+        """Count rows to try for batch b of a cheap level: the last truth, then single-surface deviations to every other count seen."""
+        row = self.rows[key][b]
+        out = [row]
+        seen = self.seen[key][b]
+        for i in np.nonzero(seen & (seen - 1))[0]:        # surfaces with more than one count on record
+            for n in range(1, MAX_ITER + 1):
+                if (int(seen[i]) >> n) & 1 and n != row[i] and len(out) < limit:
+                    alt = row.copy()
+                    alt[i] = n
+                    out.append(alt)
+        return out
+
+    @staticmethod
+    def of(lens):
+        t = lens._table_cache.get("strict-counts")
+        if t is None:
+            t = lens._table_cache["strict-counts"] = StrictCounts()
+        return t
+
+
+def _curved(lens):
+    c = np.zeros(_abi.MAX_SURF, dtype=bool)
+    for i, s in enumerate(lens.surfaces):
+        c[i] = s.pack(DEFAULT_WAVE).kind != _abi.SURF_STOP
+    return c
+
+
+# ---------------------------------------------------------------------------------------------------------------- launches
 def _trace(o, d, ra, n, B, tabs, n_tables, n_surf, batch_table, forward, flags, dev, points=None, point_set=None, pupil=None, N=1, z_sensor=None,
            tbuf=None):
+    """Round-4 form: one launch pair per surface with counting passes; returns the scratch words ([B][MAX_SURF] any-bits first)."""
     scratch = torch.empty(2 * B * _abi.MAX_SURF + 1, dtype=torch.int32, device=dev)
     if tbuf is None:
         tbuf = torch.empty(2 * B * n, dtype=torch.float32, device=dev)
     _abi.call("aadff_trace_rays_strict_batched", _abi.ptr(o), _abi.ptr(d), _abi.ptr(ra), n, B, C.byref(tabs), n_tables, n_surf,
               _abi.ptr(batch_table), _abi.ptr(points), _abi.ptr(point_set), _abi.ptr(pupil), N, 0, n_surf, int(forward), _abi.ptr(z_sensor),
               _abi.ptr(scratch), _abi.ptr(tbuf), _abi.ptr(flags), _abi.stream_ptr(dev))
+    return scratch
+
+
+def _masks_to_counts(scratch, B):
+    return counts_of_masks(scratch[:B * _abi.MAX_SURF].cpu().numpy().view(np.uint32).reshape(B, _abi.MAX_SURF))
+
+
+def _level1_batched(lens, uf, focus, S, tabs, n_tables, n_surf, bt, dev):
+    """Round-4 form of level 1 (refocus, deeplens/optics.py:1155-1180): rays built on the host, one launch pair per surface, the
+    focus-distance arithmetic on the host.  Returns (fd [S,2048] numpy, alive [S,2048] numpy bool, counts [S,MAX_SURF])."""
+    f32 = torch.float32
+    s0 = lens.surfaces[0]
+    o = _pupil_points(uf[:, 0], uf[:, 1], s0.r, s0.d.item())                                   # [S,2048,3]
+    tgt = torch.zeros(S, 1, 3, dtype=f32)
+    tgt[:, 0, 2] = torch.tensor([float(f) for f in focus], dtype=f32)
+    d = F.normalize((o - tgt).float(), p=2, dim=-1)                                            # Ray.__init__
+    od, dd = o.to(dev).contiguous(), d.to(dev).contiguous()
+    rad = torch.ones(S, GEO_SPP, dtype=f32, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    scratch = _trace(od, dd, rad, GEO_SPP, S, tabs, n_tables, n_surf, bt, True, flag, dev)
+    ro, rd, rra = od.cpu(), dd.cpu(), rad.cpu()
+    if int(flag.item()):
+        raise FloatingPointError("found nan in ft in non-diff newton method.")
+    # (element-wise IEEE arithmetic: the same bits for all slices at once as slice by slice; the mean stays per slice)
+    tt = (rd[..., 0] * ro[..., 0] + rd[..., 1] * ro[..., 1]) / (rd[..., 0] ** 2 + rd[..., 1] ** 2)
+    tt = tt * rra
+    return (ro[..., 2] - rd[..., 2] * tt).numpy(), (rra > 0).numpy(), _masks_to_counts(scratch, S)
+
+
+def _d_sensor_of(fd_all, alive):
+    """np.mean of the valid positive crossing distances per slice (optics.py:1175-1178)."""
+    out = []
+    for k in range(fd_all.shape[0]):
+        focus_d = fd_all[k][alive[k]]
+        focus_d = focus_d[~np.isnan(focus_d) & (focus_d > 0)]
+        with np.errstate(all="ignore"):
+            z = float(np.mean(focus_d)) if len(focus_d) else float("nan")
+        assert z > 0, "sensor position is negative."
+        out.append(z)
+    return out
+
+
+def _fov_geometry(lens, d_sensor):
+    """calc_fov's rays (optics.py:1187-1204): o1 [S,3] sensor corners, o2 [100,3] points across the shrunk exit pupil."""
+    M = 100
+    pupilz, pupilx = lens.exit_pupil(shrink_pupil=True)
+    x2 = torch.linspace(-pupilx, pupilx, M)
+    o2 = torch.stack((x2, torch.full_like(x2, 0), torch.full_like(x2, pupilz)), axis=-1)
+    o1 = torch.stack([torch.tensor([lens.r_last, 0, z]).to(torch.float32) for z in d_sensor])     # [S,3]
+    return o1, o2
+
+
+def _level2_batched(lens, d_sensor, S, tabs, n_tables, n_surf, bt, dev):
+    """Round-4 form of level 2 (calc_fov, optics.py:1187-1217).  Returns (tan_fov [S,100], ra [S,100] host tensors, counts)."""
+    f32 = torch.float32
+    o1, o2 = _fov_geometry(lens, d_sensor)
+    M = o2.shape[0]
+    o1 = o1.unsqueeze(1).repeat(1, M, 1)
+    dfov = F.normalize((o2.unsqueeze(0) - o1).float(), p=2, dim=-1)
+    od, dd = o1.to(dev).contiguous(), dfov.to(dev).contiguous()
+    rad = torch.ones(S, M, dtype=f32, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    scratch = _trace(od, dd, rad, M, S, tabs, n_tables, n_surf, bt, bool(dfov[0, 0, 2] > 0), flag, dev)
+    rd, rra = dd.cpu(), rad.cpu()
+    if int(flag.item()):
+        raise FloatingPointError("found nan in ft in non-diff newton method.")
+    return rd[..., 0] / rd[..., 2], rra, _masks_to_counts(scratch, S)
+
+
+def _fov_of(lens, tan_fov, rra):
+    """hfov / foclen / fnum per slice from the traced tangents (optics.py:1205-1217, 1097-1102, 186-187)."""
+    _, enp_r = lens.entrance_pupil()
+    hfov, foclen, fnum = [], [], []
+    for k in range(tan_fov.shape[0]):
+        fov = torch.atan(torch.sum(tan_fov[k] * rra[k]) / torch.sum(rra[k]))
+        h = 0.5 if torch.isnan(fov) else fov.item()
+        hfov.append(h)
+        foclen.append(lens.r_last / np.tan(h))
+        fnum.append(foclen[-1] / enp_r / 2)
+    return hfov, foclen, fnum
+
+
+def _object_points(lens, pts, hfov):
+    """psf_diff's object points per slice (optics.py:945-950): [S,N,3] float32 on the host."""
+    pobj = []
+    for h in hfov:
+        scale = -pts[:, 2] * np.tan(h) / lens.r_last
+        p = pts.clone()
+        p[..., 0] = pts[..., 0] * scale * lens.sensor_size[1] / 2
+        p[..., 1] = pts[..., 1] * scale * lens.sensor_size[0] / 2
+        pobj.append(p)
+    return torch.stack(pobj)
+
+
+def _level3_batched(lens, sel, points, pset, pc, pm, zs, bt_chief, bt_main, tabs, n_tables, n_surf, N, spp, ks, dev):
+    """Round-4 form of level 3 for the batches `sel` (LongTensor on the device, or None for all): chief trace -> centres -> main trace
+    -> histogram per batch.  Returns (psf [B',N,ks,ks] normalised, counts [B',2,MAX_SURF], any_valid [B'] (host))."""
+    f32 = torch.float32
+    if sel is not None:
+        pset, pc, pm, zs, bt_chief, bt_main = (t[sel].contiguous() for t in (pset, pc, pm, zs, bt_chief, bt_main))
+    B = pset.shape[0]
+    centre = torch.empty((B, N, 2), dtype=f32, device=dev)
+    any_valid = torch.zeros(B, dtype=torch.int32, device=dev)
+    # The ray state of a level (B x n x 36 bytes incl. the iterate buffer: 268 MB for the bench stack) is kept on the lens between
+    # calls: handing it back to torch's caching allocator made every other call re-allocate it from the driver (65-100 ms instead
+    # of 15).  `release_buffers(lens)` / `Lensgroup.invalidate()` drop it.
+    nmax = max(spp, GEO_SPP) * N
+    buf = lens._table_cache.get("strict-rays")
+    if buf is None or buf[0].shape[0] < B * nmax * 3 or buf[0].device != dev:
+        buf = lens._table_cache["strict-rays"] = (torch.empty(B * nmax * 3, dtype=f32, device=dev), torch.empty(B * nmax * 3, dtype=f32, device=dev),
+                                                  torch.empty(B * nmax, dtype=f32, device=dev), torch.empty(2 * B * nmax, dtype=f32, device=dev))
+    flag = torch.zeros(2, dtype=torch.int32, device=dev)
+    oc, dc, rac = buf[0][:B * GEO_SPP * N * 3].view(B, GEO_SPP * N, 3), buf[1][:B * GEO_SPP * N * 3].view(B, GEO_SPP * N, 3), buf[2][:B * GEO_SPP * N].view(B, GEO_SPP * N)
+    sc = _trace(oc, dc, rac, GEO_SPP * N, B, tabs, n_tables, n_surf, bt_chief, True, flag[0:1], dev, points, pset, pc, N, zs, buf[3][:2 * B * GEO_SPP * N])
+    _abi.call("aadff_strict_centroid", _abi.ptr(oc), _abi.ptr(rac), GEO_SPP, N, B, _abi.ptr(centre), _abi.ptr(any_valid), _abi.stream_ptr(dev))
+    om, dm, ram = buf[0][:B * spp * N * 3].view(B, spp * N, 3), buf[1][:B * spp * N * 3].view(B, spp * N, 3), buf[2][:B * spp * N].view(B, spp * N)
+    sm = _trace(om, dm, ram, spp * N, B, tabs, n_tables, n_surf, bt_main, True, flag[1:2], dev, points, pset, pm, N, zs, buf[3][:2 * B * spp * N])
+    raw = torch.empty((B, N, ks, ks), dtype=f32, device=dev)
+    nrm = torch.empty((N, ks, ks), dtype=f32, device=dev)
+    st = _abi.stream_ptr(dev)
+    for b in range(B):                                                                       # forward_integral (monte_carlo.py:9-57)
+        _abi.call("aadff_psf_splat", _abi.ptr(om[b]), _abi.ptr(ram[b]), _abi.ptr(centre[b]), spp, N, float(lens.pixel_size), ks,
+                  _abi.ptr(raw[b]), _abi.ptr(nrm), st)
+    psf = raw / raw.sum(-1).sum(-1).unsqueeze(-1).unsqueeze(-1)                               # optics.py:978 (0/0 -> NaN like the reference)
+    cnt = np.stack((_masks_to_counts(sc, B), _masks_to_counts(sm, B)), 1)
+    if flag.cpu().any():
+        raise FloatingPointError("found nan in ft in non-diff newton method.")
+    return psf, cnt, any_valid.cpu()
+
+
+def _tile(psf, grid, ks):
+    """[B,N,ks,ks] -> [B,g*ks,g*ks]: make_grid with padding 0 (deeplens/optics.py:1025)."""
+    B = psf.shape[0]
+    return psf.reshape(B, grid, grid, ks, ks).permute(0, 1, 3, 2, 4).reshape(B, grid * ks, grid * ks).contiguous()
+
+
+def release_buffers(lens):
+    """Drop the ray-state buffers the round-4 form keeps on the lens (268 MB for the bench stack)."""
+    lens._table_cache.pop("strict-rays", None)
+
+
+JOBS_PER_BATCH = 4          # candidate count rows per batch of a cheap level (levels 1, 2)
+FUSED_ROUNDS = 4            # corrected re-launches before a batch goes back to the per-surface form
+
+
+class _Stage:
+    """Pinned host blocks and their device twins for one stack shape (S, L, N, spp): ONE upload of all pupil points in front of
+    level 1, one small parameter block up and one result block down per launch (every `.to(device)` / `.cpu()` of a small tensor is
+    30-100 us of its own).  Integer and float words share a block (int32 storage, float32 views)."""
+
+    def __init__(self, dev, S, L, N, spp, t_green):
+        B, MS, M = S * L, _abi.MAX_SURF, 100
+        i32, f32 = torch.int32, torch.float32
+        self.key = (S, L, N, spp, t_green)
+        self.J = J = JOBS_PER_BATCH * S
+        self.n_pf, self.n_pm, self.n_pc = S * GEO_SPP * 3, B * spp * 3, B * GEO_SPP * 3
+        self.h_pupil = torch.empty(self.n_pf + self.n_pm + self.n_pc, dtype=f32, pin_memory=True)
+        self.d_pupil = torch.empty(self.n_pf + self.n_pm + self.n_pc, dtype=f32, device=dev)
+        # parameter blocks.  levels 1 / 2: [geometry G | job -> batch J | pred J*MS]  (G = S*3 axis points | S*3 sensor corners + M*3 pupil points)
+        #                   level 3: [z_sensor B | object points S*N*3 | pred B*2*MS];  its replays: [job -> batch B | pred B*2*MS]
+        self.G = [S * 3, S * 3 + M * 3]
+        sizes = [self.G[0] + J + J * MS, self.G[1] + J + J * MS, B + S * N * 3 + B * 2 * MS, B + B * 2 * MS]
+        self.h_par = [torch.empty(n, dtype=i32, pin_memory=True) for n in sizes]
+        self.d_par = [torch.empty(n, dtype=i32, device=dev) for n in sizes]
+        # result blocks: levels 1 / 2 [value J*n | ra J*n | bits J*2*MS], level 3 and its replays [bits B*4*MS | any_valid B]
+        rs = [2 * J * GEO_SPP + J * 2 * MS, 2 * J * M + J * 2 * MS, B * 4 * MS + B, B * 4 * MS + B]
+        self.h_res = [torch.empty(n, dtype=i32, pin_memory=True) for n in rs]
+        self.d_res = [torch.empty(n, dtype=i32, device=dev) for n in rs]
+        self.pset = torch.arange(S, dtype=i32).repeat_interleave(L).to(dev)
+        self.bt_main = torch.arange(L, dtype=i32).repeat(S).to(dev)
+        self.bt_green = torch.full((max(B, J),), t_green, dtype=i32, device=dev)
+        self.zeros = torch.zeros(J, dtype=i32, device=dev)
+
+    @staticmethod
+    def of(lens, dev, S, L, N, spp, t_green):
+        st = lens._table_cache.get("strict-stage")
+        if st is None or st.key != (S, L, N, spp, t_green) or st.d_pupil.device != dev:
+            st = lens._table_cache["strict-stage"] = _Stage(dev, S, L, N, spp, t_green)
+        return st
+
+    def round_trip(self, i, n_up, n_down, launch, stream):
+        """upload the first n_up words of parameter block i, launch, download the first n_down result words and wait for them"""
+        self.d_par[i][:n_up].copy_(self.h_par[i][:n_up], non_blocking=True)
+        launch(self.d_par[i], self.d_res[i])
+        self.h_res[i][:n_down].copy_(self.d_res[i][:n_down], non_blocking=True)
+        stream.synchronize()
+        return self.h_res[i].numpy()
+
+
+def _ptr_at(t, word):
+    return C.c_void_p(t.data_ptr() + 4 * word)
+
+
+def _nan_in_run(nan_bits, pred, curved):
+    """a NaN residual in an iteration the reference runs (it exits there, deeplens/surfaces.py:555-558)"""
+    ran = (np.uint32(1) << np.asarray(pred).astype(np.uint32)) - np.uint32(1)
+    return bool(((np.asarray(nan_bits).astype(np.uint32) & ran) != 0)[..., curved].any())
+
+
+def _speculate_small(counts, key, st, lvl, S, n, curved, order, launch, stream):
+    """A cheap level (S batches of n rays) on speculated counts: every batch is traced under each candidate row of the table at
+    once (`StrictCounts.candidates`: 2048-ray batches cost nothing, a second round trip costs 60-100 us), the first candidate whose
+    any-bits confirm it is the batch's result; batches without one are re-launched with the row `check_counts` corrected.
+    `launch(J, par, res)` enqueues the kernel for J jobs.  Returns (out0 [S,n], out1 [S,n]) float32, or None when some batch is still
+    unconfirmed after FUSED_ROUNDS launches (the caller falls back to the per-surface form)."""
+    MS, G = _abi.MAX_SURF, st.G[lvl]
+    cand = [(b, row) for b in range(S) for row in counts.candidates(key, b, JOBS_PER_BATCH)]
+    out0, out1 = np.empty((S, n), dtype=np.float32), np.empty((S, n), dtype=np.float32)
+    truth = np.empty((S, MS), dtype=np.int32)
+    done = np.zeros(S, dtype=bool)
+    h = st.h_par[lvl].numpy()
+    for rnd in range(FUSED_ROUNDS):
+        J = len(cand)
+        pred = np.stack([row for _, row in cand]).astype(np.int32)
+        h[G:G + J] = [b for b, _ in cand]
+        h[G + st.J:G + st.J + J * MS] = pred.reshape(-1)
+        r = st.round_trip(lvl, G + st.J + J * MS, 2 * J * n + J * 2 * MS, lambda par, res: launch(J, par, res), stream)
+        counts.stats["fused"] += 1
+        bits = r[2 * J * n:2 * J * n + J * 2 * MS].view(np.uint32).reshape(J, 2, MS)
+        ok, fix = check_counts(bits[:, 0], pred, curved, order)
+        if _nan_in_run(bits[ok, 1], pred[ok], curved):
+            raise FloatingPointError("found nan in ft in non-diff newton method.")
+        nxt = {}
+        for j, (b, row) in enumerate(cand):
+            if done[b]:
+                continue
+            if ok[j]:
+                out0[b] = r[j * n:(j + 1) * n].view(np.float32)
+                out1[b] = r[(J + j) * n:(J + j + 1) * n].view(np.float32)
+                truth[b], done[b] = row, True
+                nxt.pop(b, None)
+            elif b not in nxt:
+                nxt[b] = fix[j]
+        if done.all():
+            counts.learn(key, truth)
+            return out0, out1
+        cand = [(b, row) for b, row in nxt.items() if not done[b]]
+        counts.stats["fused_replays"] += 1
+    return None
 
 
 @torch.no_grad()
-def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp):
+def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None):
     """PSF maps [S,3,g*ks,g*ks] (device) of a strict-parity lens for the focus distances `focus`, all field points on the plane
     `depth_plane_mm`; leaves the lens focused at the last distance, like the reference's loop."""
     from .focal_stack import stack_uniform_layout
     if ks > _abi.MAX_KS:
         raise ValueError(f"ks={ks} exceeds the kernels' limit {_abi.MAX_KS}")
+    if fused is None:
+        fused = os.environ.get("AADFF_STRICT_FUSED", "1") != "0"
     S, L, N = len(focus), len(WAVE_RGB), grid * grid
+    B, MS = S * L, _abi.MAX_SURF
     dev = lens._gpu()
     n_surf = len(lens.surfaces)
     wv = list(WAVE_RGB) + ([] if DEFAULT_WAVE in WAVE_RGB else [DEFAULT_WAVE])
     t_green = wv.index(DEFAULT_WAVE)
     tabs = _tables(lens, wv)
+    tab_dev = lens._table(wv)
+    counts = StrictCounts.of(lens)
+    curved = _curved(lens)
     f32 = torch.float32
+    keys = (("focus", S), ("fov", S), ("psf", B, N, spp))
+    fused = fused and all(k in counts.rows for k in keys)      # no table yet: this call is the seed run (round-4 form throughout)
 
     # ---- the stack's draws, in the reference's order (one flat draw = the same generator stream as call by call)
     per, o_main, o_chief, per_l = stack_uniform_layout(spp, L)
@@ -91,111 +437,156 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp):
     um = rest[:, :, :2 * spp].reshape(S, L, 2, spp)
     uc = rest[:, :, 2 * spp:].reshape(S, L, 2, GEO_SPP)
 
-    flags = torch.zeros(3, dtype=torch.int32, device=dev)
     marks = [("start", time.perf_counter())] if os.environ.get("AADFF_STRICT_TIMING") == "1" else None
     mark = (lambda name: marks.append((name, time.perf_counter()))) if marks is not None else (lambda name: None)
     with torch.cuda.device(dev):
-        # ---- level 1: refocus (deeplens/optics.py:1155-1180) - S batches of 2048 rays from the first surface's aperture
+        stream = torch.cuda.current_stream(dev)
+        sp = _abi.stream_ptr(dev)
+        enp_z, enp_rr = lens.entrance_pupil()
         s0 = lens.surfaces[0]
-        o = _pupil_points(uf[:, 0], uf[:, 1], s0.r, s0.d.item())                                   # [S,2048,3]
-        tgt = torch.zeros(S, 1, 3, dtype=f32)
-        tgt[:, 0, 2] = torch.tensor([float(f) for f in focus], dtype=f32)
-        d = F.normalize((o - tgt).float(), p=2, dim=-1)                                            # Ray.__init__
-        od, dd = o.to(dev).contiguous(), d.to(dev).contiguous()
-        rad = torch.ones(S, GEO_SPP, dtype=f32, device=dev)
-        bt = torch.full((S,), t_green, dtype=torch.int32, device=dev)
-        _trace(od, dd, rad, GEO_SPP, S, tabs, len(wv), n_surf, bt, True, flags[0:1], dev)
-        mark("level 1 queued")
-        ro, rd, rra = od.cpu(), dd.cpu(), rad.cpu()
+        pts = lens.point_source_grid(depth=depth_plane_mm, grid=grid, quater=False).reshape(-1, 3).float()
+        fwd_order, bwd_order = list(range(n_surf)), list(range(n_surf - 1, -1, -1))
+        st = None
+        if fused:
+            st = _Stage.of(lens, dev, S, L, N, spp, t_green)
+            # every pupil point of the stack comes from the reference's host calls; the focus ones ride in front of level 1
+            hp = st.h_pupil
+            hp[:st.n_pf].view(S, GEO_SPP, 3).copy_(_pupil_points(uf[:, 0], uf[:, 1], s0.r, s0.d.item()))
+            st.d_pupil[:st.n_pf].copy_(hp[:st.n_pf], non_blocking=True)
+            mark("level 1 rays")
+            # ---- level 1: refocus (deeplens/optics.py:1155-1180) - rays from the first surface's aperture points away from (0, 0, focus)
+            t = st.h_par[0][:S * 3].view(f32).view(S, 3)
+            t.zero_()
+            t[:, 2] = torch.tensor([float(f) for f in focus], dtype=f32)
+            first = [True]
+
+            def launch1(J, par, res):
+                G = st.G[0]
+                _abi.call("aadff_trace_rays_strict_fused", None, None, None, GEO_SPP, J, _abi.ptr(tab_dev), len(wv), n_surf, _abi.ptr(st.bt_green),
+                          _ptr_at(par, 0), _ptr_at(par, G), _abi.ptr(st.d_pupil), 1, 0, n_surf, 1, None, _ptr_at(par, G + st.J),
+                          _ptr_at(res, 2 * J * GEO_SPP), 1, 1, _ptr_at(res, 0), _ptr_at(res, J * GEO_SPP), _ptr_at(par, G), sp)
+                if first[0]:
+                    # the psf_map pupil points are not needed before level 3: computed and uploaded while level 1 runs
+                    first[0] = False
+                    hp[st.n_pf:st.n_pf + st.n_pm].view(B, spp, 3).copy_(_pupil_points(um[:, :, 0], um[:, :, 1], enp_rr, enp_z).reshape(B, spp, 3))
+                    hp[st.n_pf + st.n_pm:].view(B, GEO_SPP, 3).copy_(_pupil_points(uc[:, :, 0], uc[:, :, 1], enp_rr * 0.5, enp_z).reshape(B, GEO_SPP, 3))
+                    st.d_pupil[st.n_pf:].copy_(hp[st.n_pf:], non_blocking=True)
+
+            got = _speculate_small(counts, keys[0], st, 0, S, GEO_SPP, curved, fwd_order, launch1, stream)
+            if got is not None:
+                fd_all, alive = got[0], got[1] > 0
+        if not fused or got is None:
+            if fused:
+                counts.stats["per_surface_replays"] += 1
+            bt_green = st.bt_green if st is not None else torch.full((B,), t_green, dtype=torch.int32, device=dev)
+            fd_all, alive, cnt = _level1_batched(lens, uf, focus, S, tabs, len(wv), n_surf, bt_green[:S], dev)
+            counts.learn(keys[0], cnt)
         mark("level 1 back on the host")
-        # (element-wise IEEE arithmetic: the same bits for all slices at once as slice by slice; the mean stays per slice)
-        tt = (rd[..., 0] * ro[..., 0] + rd[..., 1] * ro[..., 1]) / (rd[..., 0] ** 2 + rd[..., 1] ** 2)
-        tt = tt * rra
-        fd_all = (ro[..., 2] - rd[..., 2] * tt).numpy()
-        alive = (rra > 0).numpy()
-        d_sensor = []
-        for k in range(S):
-            focus_d = fd_all[k][alive[k]]
-            focus_d = focus_d[~np.isnan(focus_d) & (focus_d > 0)]
-            with np.errstate(all="ignore"):
-                z = float(np.mean(focus_d)) if len(focus_d) else float("nan")
-            assert z > 0, "sensor position is negative."
-            d_sensor.append(z)
+        d_sensor = _d_sensor_of(fd_all, alive)
         mark("d_sensor")
         # ---- level 2: calc_fov (deeplens/optics.py:1187-1217) - S batches of 100 rays from the sensor corner, backward
-        M = 100
-        pupilz, pupilx = lens.exit_pupil(shrink_pupil=True)
-        x2 = torch.linspace(-pupilx, pupilx, M)
-        o2 = torch.stack((x2, torch.full_like(x2, 0), torch.full_like(x2, pupilz)), axis=-1)
-        o1 = torch.stack([torch.tensor([lens.r_last, 0, z]).repeat(M, 1).to(f32) for z in d_sensor])        # [S,100,3]
-        dfov = F.normalize((o2.unsqueeze(0) - o1).float(), p=2, dim=-1)
-        od, dd = o1.to(dev).contiguous(), dfov.to(dev).contiguous()
-        rad = torch.ones(S, M, dtype=f32, device=dev)
-        _trace(od, dd, rad, M, S, tabs, len(wv), n_surf, bt, bool(dfov[0, 0, 2] > 0), flags[1:2], dev)
-        mark("level 2 queued")
-        rd, rra = dd.cpu(), rad.cpu()
-        mark("level 2 back on the host")
-        _, enp_r = lens.entrance_pupil()
-        hfov, foclen, fnum = [], [], []
-        for k in range(S):
-            tan_fov = rd[k, :, 0] / rd[k, :, 2]
-            fov = torch.atan(torch.sum(tan_fov * rra[k]) / torch.sum(rra[k]))
-            h = 0.5 if torch.isnan(fov) else fov.item()
-            hfov.append(h)
-            foclen.append(lens.r_last / np.tan(h))
-            fnum.append(foclen[-1] / enp_r / 2)
+        if fused:
+            o1, o2 = _fov_geometry(lens, d_sensor)
+            M = o2.shape[0]
+            backward = not bool(o2[0, 2] - o1[0, 2] > 0)
+            st.h_par[1][:S * 3].view(f32).view(S, 3).copy_(o1)
+            st.h_par[1][S * 3:S * 3 + M * 3].view(f32).view(M, 3).copy_(o2)
 
+            def launch2(J, par, res):
+                G = st.G[1]
+                _abi.call("aadff_trace_rays_strict_fused", None, None, None, M, J, _abi.ptr(tab_dev), len(wv), n_surf, _abi.ptr(st.bt_green),
+                          _ptr_at(par, 0), _ptr_at(par, G), _ptr_at(par, S * 3), 1, 0, n_surf, int(not backward), None, _ptr_at(par, G + st.J),
+                          _ptr_at(res, 2 * J * M), 0, 2, _ptr_at(res, 0), _ptr_at(res, J * M), _abi.ptr(st.zeros), sp)
+
+            mark("level 2 rays")
+            got = _speculate_small(counts, keys[1], st, 1, S, M, curved, bwd_order if backward else fwd_order, launch2, stream)
+            if got is not None:
+                tan_fov, rra = torch.from_numpy(got[0]), torch.from_numpy(got[1])
+        else:
+            mark("level 2 rays")
+        if not fused or got is None:
+            if fused:
+                counts.stats["per_surface_replays"] += 1
+            tan_fov, rra, cnt = _level2_batched(lens, d_sensor, S, tabs, len(wv), n_surf, bt_green[:S] if not fused else st.bt_green[:S], dev)
+            counts.learn(keys[1], cnt)
+        mark("level 2 back on the host")
+        hfov, foclen, fnum = _fov_of(lens, tan_fov, rra)
         mark("hfov")
         # ---- level 3: psf_map (deeplens/optics.py:888-1026) - per slice and wavelength spp x N main rays and 2048 x N chief rays
-        pts = lens.point_source_grid(depth=depth_plane_mm, grid=grid, quater=False).reshape(-1, 3).float()
-        pobj = []
-        for k in range(S):                                                                       # psf_diff's object points (optics.py:945-950)
-            scale = -pts[:, 2] * np.tan(hfov[k]) / lens.r_last
-            p = pts.clone()
-            p[..., 0] = pts[..., 0] * scale * lens.sensor_size[1] / 2
-            p[..., 1] = pts[..., 1] * scale * lens.sensor_size[0] / 2
-            pobj.append(p)
-        points = torch.stack(pobj).to(dev).contiguous()                                          # [S,N,3]
-        enp_z, enp_rr = lens.entrance_pupil()
-        pm = _pupil_points(um[:, :, 0], um[:, :, 1], enp_rr, enp_z).reshape(S * L, spp, 3).to(dev).contiguous()
-        pc = _pupil_points(uc[:, :, 0], uc[:, :, 1], enp_rr * 0.5, enp_z).reshape(S * L, GEO_SPP, 3).to(dev).contiguous()
-        B = S * L
-        pset = torch.arange(S, dtype=torch.int32).repeat_interleave(L).to(dev)
-        zs = torch.tensor(d_sensor, dtype=f32).repeat_interleave(L).to(dev)
-        bt_main = torch.arange(L, dtype=torch.int32).repeat(S).to(dev)
-        bt_chief = torch.full((B,), t_green, dtype=torch.int32, device=dev)
-        centre = torch.empty((B, N, 2), dtype=f32, device=dev)
-        any_valid = torch.zeros(B, dtype=torch.int32, device=dev)
-        # chief rays (always the default wavelength, shrunk pupil) -> centres; the main rays then reuse their buffers.  The ray
-        # state of a level (B x n x 36 bytes incl. the iterate buffer: 268 MB for the bench stack) is kept on the lens between calls: handing it back to
-        # torch's caching allocator made every other call re-allocate it from the driver (65-100 ms instead of 15)
-        nmax = max(spp, GEO_SPP) * N
-        buf = getattr(lens, "_strict_rays", None)
-        if buf is None or buf[0].shape[0] < B * nmax * 3 or buf[0].device != dev:
-            buf = lens._strict_rays = (torch.empty(B * nmax * 3, dtype=f32, device=dev), torch.empty(B * nmax * 3, dtype=f32, device=dev),
-                                       torch.empty(B * nmax, dtype=f32, device=dev), torch.empty(2 * B * nmax, dtype=f32, device=dev))
-        oc, dc, rac = buf[0][:B * GEO_SPP * N * 3].view(B, GEO_SPP * N, 3), buf[1][:B * GEO_SPP * N * 3].view(B, GEO_SPP * N, 3), buf[2][:B * GEO_SPP * N].view(B, GEO_SPP * N)
-        _trace(oc, dc, rac, GEO_SPP * N, B, tabs, len(wv), n_surf, bt_chief, True, flags[2:3], dev, points, pset, pc, N, zs, buf[3][:2 * B * GEO_SPP * N])
-        _abi.call("aadff_strict_centroid", _abi.ptr(oc), _abi.ptr(rac), GEO_SPP, N, B, _abi.ptr(centre), _abi.ptr(any_valid), _abi.stream_ptr(dev))
-        om, dm, ram = buf[0][:B * spp * N * 3].view(B, spp * N, 3), buf[1][:B * spp * N * 3].view(B, spp * N, 3), buf[2][:B * spp * N].view(B, spp * N)
-        flag_m = torch.zeros(1, dtype=torch.int32, device=dev)
-        _trace(om, dm, ram, spp * N, B, tabs, len(wv), n_surf, bt_main, True, flag_m, dev, points, pset, pm, N, zs, buf[3][:2 * B * spp * N])
-        raw = torch.empty((B, N, ks, ks), dtype=f32, device=dev)
-        nrm = torch.empty((N, ks, ks), dtype=f32, device=dev)
-        st = _abi.stream_ptr(dev)
-        for b in range(B):                                                                       # forward_integral (monte_carlo.py:9-57)
-            _abi.call("aadff_psf_splat", _abi.ptr(om[b]), _abi.ptr(ram[b]), _abi.ptr(centre[b]), spp, N, float(lens.pixel_size), ks,
-                      _abi.ptr(raw[b]), _abi.ptr(nrm), st)
-        psf = raw / raw.sum(-1).sum(-1).unsqueeze(-1).unsqueeze(-1)                               # optics.py:978 (0/0 -> NaN like the reference)
-        maps = psf.reshape(S, L, grid, grid, ks, ks).permute(0, 1, 2, 4, 3, 5).reshape(S, L, grid * ks, grid * ks).contiguous()   # make_grid, padding 0
-        mark("level 3 queued")
-        bits = (flags.cpu().tolist(), int(flag_m.item()), any_valid.cpu())
+        pobj = _object_points(lens, pts, hfov)                                                     # [S,N,3]
+        if fused:
+            pred3 = counts.rows[keys[2]]
+            maps = torch.empty((S, L, grid * ks, grid * ks), dtype=f32, device=dev)
+            centre = torch.empty((B, N, 2), dtype=f32, device=dev)
+            h = st.h_par[2]
+            h[:B].view(f32).copy_(torch.tensor(d_sensor, dtype=f32).repeat_interleave(L))
+            h[B:B + S * N * 3].view(f32).view(S, N, 3).copy_(pobj)
+            h[B + S * N * 3:].view(B, 2, MS).copy_(torch.from_numpy(pred3))
+
+            def launch3(J, jobs_ptr, pred_ptr, res):
+                par = st.d_par[2]
+                _abi.call("aadff_strict_psf_points", _ptr_at(par, B), N, J, jobs_ptr, _abi.ptr(st.pset), _abi.ptr(tab_dev), len(wv), n_surf,
+                          _abi.ptr(st.bt_main), _abi.ptr(st.bt_green), _ptr_at(par, 0), _ptr_at(st.d_pupil, st.n_pf), spp,
+                          _ptr_at(st.d_pupil, st.n_pf + st.n_pm), GEO_SPP, pred_ptr, float(lens.pixel_size), ks, grid, _abi.ptr(maps), _abi.ptr(centre),
+                          _ptr_at(res, 0), _ptr_at(res, J * 4 * MS), sp)
+
+            mark("level 3 inputs")
+            r = st.round_trip(2, h.numel(), B * 4 * MS + B, lambda par, res: launch3(B, None, _ptr_at(par, B + S * N * 3), res), stream)
+            counts.stats["fused"] += 1
+            hb = r[:B * 4 * MS].view(np.uint32).reshape(B, 2, 2, MS)
+            any_valid = torch.from_numpy(r[B * 4 * MS:B * 4 * MS + B].copy())
+            ok2, fix = check_counts(hb[:, :, 0], pred3, curved, fwd_order)                        # [B,2]: chief and main of the batch
+            ok = ok2.all(-1)
+            if _nan_in_run(hb[ok][:, :, 1], pred3[ok], curved):
+                raise FloatingPointError("found nan in ft in non-diff newton method.")
+            truth = pred3.copy()
+            bad = np.nonzero(~ok)[0]
+            counts.stats["replayed_batches"] += len(bad)
+            rnd = 0
+            while len(bad) and rnd < FUSED_ROUNDS:          # re-launch the mispredicted batches with their corrected rows
+                rnd += 1
+                J = len(bad)
+                rows = fix[bad] if rnd == 1 else rows_next
+                hr = st.h_par[3].numpy()
+                hr[:J] = bad
+                hr[B:B + J * 2 * MS] = rows.reshape(-1)
+                r = st.round_trip(3, B + J * 2 * MS, J * 4 * MS + J, lambda par, res: launch3(J, _ptr_at(par, 0), _ptr_at(par, B), res), stream)
+                counts.stats["fused_replays"] += 1
+                jb = r[:J * 4 * MS].view(np.uint32).reshape(J, 2, 2, MS)
+                okj2, fixj = check_counts(jb[:, :, 0], rows, curved, fwd_order)
+                okj = okj2.all(-1)
+                if _nan_in_run(jb[okj][:, :, 1], rows[okj], curved):
+                    raise FloatingPointError("found nan in ft in non-diff newton method.")
+                truth[bad[okj]] = rows[okj]
+                any_valid[bad[okj]] = torch.from_numpy(r[J * 4 * MS:J * 4 * MS + J][okj].copy())
+                bad, rows_next = bad[~okj], fixj[~okj]
+            if len(bad):                                    # still unconfirmed: the per-surface form finds the counts itself
+                counts.stats["per_surface_replays"] += 1
+                sel = torch.from_numpy(bad).to(dev)
+                par = st.d_par[2]
+                psf, cnt, av = _level3_batched(lens, sel, par[B:B + S * N * 3].view(f32).view(S, N, 3), st.pset, st.d_pupil[st.n_pf + st.n_pm:].view(B, GEO_SPP, 3),
+                                               st.d_pupil[st.n_pf:st.n_pf + st.n_pm].view(B, spp, 3), par[:B].view(f32), st.bt_green[:B], st.bt_main, tabs,
+                                               len(wv), n_surf, N, spp, ks, dev)
+                maps.view(B, grid * ks, grid * ks)[sel] = _tile(psf, grid, ks)
+                truth[bad] = cnt
+                any_valid[bad] = av
+            counts.learn(keys[2], truth)
+        else:
+            points = pobj.to(dev).contiguous()
+            pm = _pupil_points(um[:, :, 0], um[:, :, 1], enp_rr, enp_z).reshape(B, spp, 3).to(dev).contiguous()
+            pc = _pupil_points(uc[:, :, 0], uc[:, :, 1], enp_rr * 0.5, enp_z).reshape(B, GEO_SPP, 3).to(dev).contiguous()
+            pset = torch.arange(S, dtype=torch.int32).repeat_interleave(L).to(dev)
+            zs = torch.tensor(d_sensor, dtype=f32).repeat_interleave(L).to(dev)
+            bt_main = torch.arange(L, dtype=torch.int32).repeat(S).to(dev)
+            mark("level 3 inputs")
+            psf, cnt, any_valid = _level3_batched(lens, None, points, pset, pc, pm, zs, bt_green, bt_main, tabs, len(wv), n_surf, N, spp, ks, dev)
+            counts.learn(keys[2], cnt)
+            counts.stats["seeded"] += 1
+            maps = _tile(psf, grid, ks).reshape(S, L, grid * ks, grid * ks)
         mark("level 3 done")
         if marks is not None:
             lens._strict_timing = [(b[0], round((b[1] - a[1]) * 1e3, 3)) for a, b in zip(marks, marks[1:])]
-    if any(bits[0]) or bits[1]:
-        raise FloatingPointError("found nan in ft in non-diff newton method.")
-    assert bool(bits[2].all()), "No sampled rays is valid."
+    assert bool(any_valid.bool().all()), "No sampled rays is valid."
     # the lens is left focused at the last distance
     lens._state_sync()
     hs = lens._state_host

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AADFF_ABI_VERSION 6
+#define AADFF_ABI_VERSION 7
 
 #define AADFF_EINVAL      (-1)   /* bad shape / size / NULL pointer                  */
 #define AADFF_EUNSUPPORTED (-2)  /* parameter outside what the kernels were built for */
@@ -204,6 +204,53 @@ int aadff_trace_rays_strict_batched(float* o, float* d, float* ra, int n, int B,
                                     int n_surf, const int* batch_table, const float* points_or_null, const int* point_set,
                                     const float* pupil, int N, int first, int last, int forward, const float* z_sensor_or_null,
                                     unsigned* scratch, float* tbuf_or_null, int* flags_or_null, aadff_stream_t stream);
+
+/* The strict trace of B batches in ONE launch for ALL surfaces, with SPECULATED batch-wide Newton counts (ABI v7; csrc/strict_fused.hip).
+ * Same rays, same per-ray arithmetic and same result as aadff_trace_rays_strict_batched WHEN pred[b][i] - the number of loose
+ * iterations the reference's `while (|ft| > 5e-5).any() and it < 10` loop (deeplens/surfaces.py:547) runs for batch b at surface i -
+ * is right for every curved surface the batch crosses.  The call cannot know that; it reports what it saw:
+ *   bits [B][2][AADFF_MAX_SURF] (device, zeroed by the call): [b][0][i] bit j = some ray of batch b had |ft| > 5e-5 in loose
+ *   iteration j + 1 at surface i (j < pred[b][i]); [b][1][i] the same for a NaN residual (the reference exits, surfaces.py:555-558).
+ * The caller checks, in the order the surfaces are crossed: n = pred[b][i] is the reference's count <=> bits 0..n-2 are set and
+ * (bit n-1 is clear or n == 10).  At the first surface where that fails the batch's result (and its later bits) are meaningless:
+ * replay the batch through aadff_trace_rays_strict_batched, whose any-bits give the true counts (aadff/strict_stack.py keeps the
+ * table).  Rays whose Newton iterate becomes periodic (a fixed point or a two-cycle of the float32 map t -> t - clamp(ft / dfdt))
+ * are not iterated further: the remaining iterates and any-bits follow from the cycle, bit for bit.
+ * tables_dev: n_tables packed tables of n_surf records on the DEVICE; pred [B][AADFF_MAX_SURF] int32 (device), values 1..10 (flat
+ * surfaces ignored); other arguments as aadff_trace_rays_strict_batched.  With points: origin_at_pupil != 0 starts the rays AT the
+ * pupil points (refocus: rays leave the first surface's aperture away from the axis point, deeplens/optics.py:1166-1170).
+ * out_mode 0: o / d / ra in place.  out_mode 1 (needs points; o, d, ra may be NULL): out0[b][i] = the z at which the ray crosses
+ * the axis in the least-squares sense, o.z - d.z * ((d.x o.x + d.y o.y) / (d.x^2 + d.y^2)) * ra, out1[b][i] = ra - refocus's per-ray
+ * arithmetic (optics.py:1171-1174, element-wise IEEE float32).  out_mode 2: out0 = d.x / d.z (calc_fov, optics.py:1205), out1 = ra.
+ * pupil_set_or_null [B]: batch b takes its pupil points from row pupil_set[b] of `pupil` (NULL: row b) - the same rays traced
+ * under several candidate count rows are several batches sharing one row.
+ * Replaces Lensgroup.trace / trace2sensor,
+ * deeplens/optics.py:598-714, for Lensgroup(parity="strict"). */
+int aadff_trace_rays_strict_fused(float* o, float* d, float* ra, int n, int B, const aadff_surface_t* tables_dev, int n_tables, int n_surf,
+                                  const int* batch_table, const float* points_or_null, const int* point_set, const float* pupil, int N,
+                                  int first, int last, int forward, const float* z_sensor_or_null, const int* pred, unsigned* bits,
+                                  int origin_at_pupil, int out_mode, float* out0, float* out1, const int* pupil_set_or_null,
+                                  aadff_stream_t stream);
+
+/* psf_map of a strict-parity lens for B = S x L (focus state, wavelength) batches in ONE launch (ABI v7): per batch and object point
+ * the chief rays (shrunk pupil) -> centre in ATen's summation order (as aadff_strict_centroid), the main rays -> bilinear histogram
+ * (forward_integral, deeplens/monte_carlo.py:9-121, IEEE float32 divisions) -> normalised PSF; no ray state goes through memory.
+ * Replaces Lensgroup.psf_diff / psf_rgb / psf_map, deeplens/optics.py:888-1026, for Lensgroup(parity="strict"), with the batch-wide
+ * Newton counts speculated as in aadff_trace_rays_strict_fused:
+ *   points [P][N][3] object points (optics.py:945-950), point_set [B]; tables_dev [n_tables][n_surf] (device); table_main / table_chief
+ *   [B]: the table each batch's main / chief rays trace with; z_sensor [B]; pupil_main [B][spp][3], pupil_chief [B][spp_chief][3]:
+ *   pupil points (optics.py:480-486, computed by the caller with the reference's own host calls);
+ *   pred [B][2][AADFF_MAX_SURF] int32: predicted counts of the chief ([b][0]) and main ([b][1]) batch;
+ *   psf: map_grid = 0: [B][N][ks][ks]; map_grid = g (N = g*g): [B][g*ks][g*ks] in the psf_map tiling (optics.py:1025);
+ *   centre [B][N][2]; bits [B][2][2][AADFF_MAX_SURF] ([b][phase][any | nan][surface], zeroed by the call); any_valid [B]: 1 where a chief
+ *   ray of the batch is valid (the assert of optics.py:901).  All pointers are device pointers.
+ * job_batch_or_null [B]: the call renders the B JOBS j = 0..B-1, job j being batch job_batch[j] of the arrays above (NULL: batch j):
+ *   inputs, psf and centre are indexed by the batch, pred / bits / any_valid by the job - a caller replays the few batches whose
+ *   prediction failed with corrected counts, overwriting exactly their PSFs. */
+int aadff_strict_psf_points(const float* points, int N, int B, const int* job_batch_or_null, const int* point_set, const aadff_surface_t* tables_dev, int n_tables,
+                            int n_surf, const int* table_main, const int* table_chief, const float* z_sensor, const float* pupil_main,
+                            int spp, const float* pupil_chief, int spp_chief, const int* pred, float pixel_size, int ks, int map_grid,
+                            float* psf, float* centre, unsigned* bits, int* any_valid, aadff_stream_t stream);
 
 /* Chief-ray PSF centres of B batches: centre[b][p] = -(sum_s o_xy[b,s,p] ra[b,s,p]) / (sum_s ra[b,s,p] + 1e-9), o [B,spp,N,3],
  * ra [B,spp,N] (device) -> centre [B,N,2]; any_valid [B] = 1 where some ray of the batch has ra == 1 (the reference asserts it:

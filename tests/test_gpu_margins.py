@@ -296,19 +296,135 @@ def test_strict_stack_batched_equals_call_by_call(repo_root, margin, monkeypatch
         lens = Lensgroup(lp(repo_root), sensor_res=(H, W), device=DEV, parity="strict")
         torch.manual_seed(3)
         if label == "batched":
-            strict_stack.strict_psf_maps(lens, dbar, fds, grid, 11, spp)          # warm the allocator
+            strict_stack.strict_psf_maps(lens, dbar, fds, grid, 11, spp, fused=False)          # warm the allocator
             torch.manual_seed(3)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        fn = strict_stack.strict_psf_maps_loop if label == "loop" else strict_stack.strict_psf_maps
-        maps = fn(lens, dbar, fds, grid, 11, spp)
+        maps = strict_stack.strict_psf_maps_loop(lens, dbar, fds, grid, 11, spp) if label == "loop" else strict_stack.strict_psf_maps(lens, dbar, fds, grid, 11, spp, fused=False)
         torch.cuda.synchronize()
         out[label] = (maps.cpu().numpy(), lens.d_sensor, lens.hfov, lens.foclen, lens.fnum, time.perf_counter() - t0, torch.rand(1).item())
     a, b = out["loop"], out["batched"]
     assert a[1:5] == b[1:5], (a[1:5], b[1:5])                                  # the lens is left in the same state, to the bit
     assert a[6] == b[6]                                                        # and the host generator at the same position
     margin(f"strict stack {H}x{W} S={S}: batched vs call-by-call PSF maps, max |d| / max", np.abs(a[0] - b[0]).max() / np.abs(a[0]).max(), 2e-6)
-    margin(f"strict stack {H}x{W} S={S}: seconds per stack, batched (call by call: {a[5]:.3f} s)", b[5], a[5])
+    print(f"strict stack {H}x{W} S={S}: {b[5]:.4f} s batched, {a[5]:.3f} s call by call")       # informative (no timing assertion)
+
+
+def _psf_level_inputs(lens, S, grid, spp, seed):
+    """Inputs of a strict level-3 call (object points, pupil points, tables) for S focus states, as aadff/strict_stack.py builds them."""
+    from aadff import strict_stack as ss
+    from deeplens.basics import DEFAULT_WAVE, GEO_SPP, WAVE_RGB
+    L, N = len(WAVE_RGB), grid * grid
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(seed)
+    wv = list(WAVE_RGB) + ([] if DEFAULT_WAVE in WAVE_RGB else [DEFAULT_WAVE])
+    enp_z, enp_r = lens.entrance_pupil()
+    pts = lens.point_source_grid(depth=-3000.0, grid=grid, quater=False).reshape(-1, 3).float()
+    pobj = []
+    for k in range(S):
+        scale = -pts[:, 2] * np.tan(lens.hfov * (1 + 0.01 * k)) / lens.r_last
+        p = pts.clone()
+        p[..., 0] = pts[..., 0] * scale * lens.sensor_size[1] / 2
+        p[..., 1] = pts[..., 1] * scale * lens.sensor_size[0] / 2
+        pobj.append(p)
+    B = S * L
+    return dict(points=torch.stack(pobj).to(dev).contiguous(), N=N, B=B, wv=wv, tabs=ss._tables(lens, wv), tab_dev=lens._table(wv),
+                pm=ss._pupil_points(torch.rand(B, spp, generator=g), torch.rand(B, spp, generator=g), enp_r, enp_z).to(dev).contiguous(),
+                pc=ss._pupil_points(torch.rand(B, GEO_SPP, generator=g), torch.rand(B, GEO_SPP, generator=g), enp_r * 0.5, enp_z).to(dev).contiguous(),
+                pset=torch.arange(S, dtype=torch.int32).repeat_interleave(L).to(dev),
+                zs=torch.tensor([lens.d_sensor + 0.01 * k for k in range(S)], dtype=torch.float32).repeat_interleave(L).to(dev),
+                bt_main=torch.arange(L, dtype=torch.int32).repeat(S).to(dev),
+                bt_chief=torch.full((B,), wv.index(DEFAULT_WAVE), dtype=torch.int32, device=dev))
+
+
+def test_strict_fused_trace_is_bit_equal_to_the_per_surface_form(repo_root):
+    """Round 5: `aadff_trace_rays_strict_fused` (one launch, every surface in registers, predicted batch-wide Newton counts, iterates
+    not evaluated past the point where they become periodic) against `aadff_trace_rays_strict_batched` (one launch pair per surface,
+    counting passes) on a psf_map level: with the counts the per-surface form found, every ray's o / d / ra is BIT-identical, the
+    any-bits the fused launch reports reproduce those counts, and `prediction_holds` accepts them; with one count off by one (too
+    low, too high) the check rejects exactly that batch."""
+    from aadff import strict_stack as ss
+    dev = torch.device(DEV)
+    lens = Lensgroup(lp(repo_root), sensor_res=(512, 512), device=DEV, parity="strict")
+    S, grid, spp = 2, 5, 256
+    a = _psf_level_inputs(lens, S, grid, spp, seed=11)
+    N, B, n_surf = a["N"], a["B"], len(lens.surfaces)
+    n = spp * N
+    o0, d0, r0 = (torch.empty(B, n, 3, device=dev), torch.empty(B, n, 3, device=dev), torch.empty(B, n, device=dev))
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    scratch = ss._trace(o0, d0, r0, n, B, a["tabs"], len(a["wv"]), n_surf, a["bt_main"], True, flag, dev, a["points"], a["pset"], a["pm"], N, a["zs"])
+    cnt = ss._masks_to_counts(scratch, B)
+    curved = ss._curved(lens)
+    assert cnt[:, curved].max() == 10 and cnt[:, curved].min() >= 1
+
+    def fused(pred):
+        o1, d1, r1 = torch.empty_like(o0), torch.empty_like(d0), torch.empty_like(r0)
+        bits = torch.empty((B, 2, _abi.MAX_SURF), dtype=torch.int32, device=dev)
+        _abi.call("aadff_trace_rays_strict_fused", _abi.ptr(o1), _abi.ptr(d1), _abi.ptr(r1), n, B, _abi.ptr(a["tab_dev"]), len(a["wv"]), n_surf,
+                  _abi.ptr(a["bt_main"]), _abi.ptr(a["points"]), _abi.ptr(a["pset"]), _abi.ptr(a["pm"]), N, 0, n_surf, 1, _abi.ptr(a["zs"]),
+                  _abi.ptr(torch.from_numpy(np.ascontiguousarray(pred, dtype=np.int32)).to(dev)), _abi.ptr(bits), 0, 0, None, None, None, _abi.stream_ptr(dev))
+        return o1, d1, r1, bits.cpu().numpy().view(np.uint32)
+
+    o1, d1, r1, hb = fused(cnt)
+    for x, y, name in ((o0, o1, "o"), (d0, d1, "d"), (r0, r1, "ra")):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32)), f"{name}: {int((x.view(torch.int32) != y.view(torch.int32)).sum())} words differ"
+    assert ss.prediction_holds(hb[:, 0], cnt, curved).all()
+    full = scratch[:B * _abi.MAX_SURF].cpu().numpy().view(np.uint32).reshape(B, _abi.MAX_SURF)
+    ran = (np.uint32(1) << cnt.astype(np.uint32)) - np.uint32(1)
+    assert np.array_equal(hb[:, 0] & ran, full & ran)                          # the bits of the iterations that ran are the counting pass's
+    assert not hb[:, 1].any()
+    # mispredictions: batch 1 one iteration short at a surface that needs ten, batch 2 one too many at a surface that needs fewer
+    s10 = int(np.nonzero(curved & (cnt[1] == 10))[0][0])
+    few = np.nonzero(curved & (cnt[2] < 10))[0]
+    bad = cnt.copy()
+    bad[1, s10] = 9
+    bad[2, few[0]] += 1
+    _, _, _, hb2 = fused(bad)
+    assert ss.prediction_holds(hb2[:, 0], bad, curved).tolist() == [b not in (1, 2) for b in range(B)]
+
+
+@pytest.mark.parametrize("res,S,grid,spp", [((256, 256), 4, 5, 512), ((1024, 1024), 10, 11, 2048)])
+def test_strict_stack_fused_equals_batched(repo_root, margin, res, S, grid, spp):
+    """Round 5: a strict stack with every level in ONE launch on speculated Newton counts (aadff/strict_stack.py, csrc/strict_fused.hip)
+    against the round-4 form (one launch pair per surface): identical d_sensor / hfov / foclen / fnum and host generator position,
+    PSF maps equal to the float atomics of the histogram; the first call seeds the count table, the second runs fused with no replay;
+    a POISONED table (one count wrong per level) is detected, the batches are replayed, the rows corrected, and the maps are the same."""
+    import time
+    from aadff import strict_stack as ss
+    H, W = res
+    depth = synth_depth_mm(H, W, seed=5678)
+    dbar, fds = -float(depth.mean()), [float(f) for f in -np.linspace(depth.min(), depth.max(), S)]
+    out = {}
+    for label in ("batched", "fused"):
+        lens = Lensgroup(lp(repo_root), sensor_res=(H, W), device=DEV, parity="strict")
+        torch.manual_seed(3)
+        ss.strict_psf_maps(lens, dbar, fds, grid, 11, spp, fused=label == "fused")          # seeds the table / warms the allocator
+        torch.manual_seed(3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        maps = ss.strict_psf_maps(lens, dbar, fds, grid, 11, spp, fused=label == "fused")
+        torch.cuda.synchronize()
+        out[label] = (maps.cpu().numpy(), lens.d_sensor, lens.hfov, lens.foclen, lens.fnum, time.perf_counter() - t0, torch.rand(1).item())
+        if label == "fused":
+            counts = ss.StrictCounts.of(lens)
+            assert counts.stats == {"seeded": 1, "fused": 3, "replayed_batches": 0, "fused_replays": 0, "per_surface_replays": 0}, counts.stats
+            good = {k: v.copy() for k, v in counts.rows.items()}
+            curved = ss._curved(lens)
+            for k, v in counts.rows.items():                                     # poison: one curved surface of one batch per level
+                v.reshape(-1, _abi.MAX_SURF)[1, np.nonzero(curved)[0][2]] = 7
+            torch.manual_seed(3)
+            maps2 = ss.strict_psf_maps(lens, dbar, fds, grid, 11, spp, fused=True)
+            assert counts.stats["fused_replays"] + counts.stats["per_surface_replays"] >= 3 and counts.stats["replayed_batches"] >= 1, counts.stats
+            for k in good:
+                assert np.array_equal(counts.rows[k], good[k]), k                # rows repaired
+            assert (lens.d_sensor, lens.hfov) == out[label][1:3]
+            margin(f"strict stack {H}x{W} S={S}: fused after a poisoned table vs fused, max |d| / max",
+                   np.abs(maps2.cpu().numpy() - out[label][0]).max() / np.abs(out[label][0]).max(), 2e-6)
+    a, b = out["batched"], out["fused"]
+    assert a[1:5] == b[1:5], (a[1:5], b[1:5])
+    assert a[6] == b[6]
+    margin(f"strict stack {H}x{W} S={S}: fused vs per-surface PSF maps, max |d| / max", np.abs(a[0] - b[0]).max() / np.abs(a[0]).max(), 2e-6)
+    print(f"strict stack {H}x{W} S={S}: {b[5] * 1e3:.2f} ms fused, {a[5] * 1e3:.2f} ms per-surface form")
 
 
 def test_strict_lens_through_the_sharded_unit_renderer(repo_root):

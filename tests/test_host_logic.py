@@ -673,3 +673,28 @@ def test_pfm_reader(tmp_path):
         read_pfm(str(tmp_path / "bad.pfm"))
     z = disparity_to_depth_mm(np.float32(100.0), 4161.221, 176.252, 209.059)
     assert z == pytest.approx(4161.221 * 176.252 / 309.059)
+
+
+def test_strict_count_table_logic():
+    """aadff/strict_stack.py: any-bits -> the reference's iteration count (`while (|ft| > 5e-5).any() and it < 10`,
+    deeplens/surfaces.py:547) and the acceptance test of a speculated count, against a literal loop."""
+    from aadff.strict_stack import counts_of_masks, prediction_holds
+    rng = np.random.default_rng(0)
+    masks = np.concatenate((rng.integers(0, 1024, 500), [0, 1, 3, 7, 1023, 511, 0b1011, 0b0111111111])).astype(np.uint32)
+
+    def loop_count(m):                      # the reference's loop on the per-iteration any() results
+        it = 0
+        above = True                        # enters with ft = MAXT
+        while above and it < 10:
+            it += 1
+            above = bool((m >> (it - 1)) & 1)
+        return it
+    want = np.array([loop_count(int(m)) for m in masks])
+    assert np.array_equal(counts_of_masks(masks), want)
+    curved = np.ones(1, dtype=bool)
+    for m, n_true in zip(masks, want):
+        for n in range(1, 11):
+            seen = np.uint32(m) & np.uint32((1 << n) - 1)          # a fused launch only sees the iterations it ran
+            assert bool(prediction_holds(np.array([[seen]]), np.array([[n]]), curved)[0]) == (n == n_true), (m, n, n_true)
+    # flat surfaces are ignored
+    assert prediction_holds(np.array([[0, 5]], dtype=np.uint32), np.array([[1, 4]]), np.array([True, False]))[0]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time a strict-parity stack of the bench workload (batched form, aadff/strict_stack.py): wall time per stack and, under
+"""Time a strict-parity stack of the bench workload (aadff/strict_stack.py: fused levels on speculated counts; AADFF_STRICT_FUSED=0: the round-4 per-surface form): wall time per stack and, under
 `rocprofv3 --kernel-trace --stats -- python3 tools/strict_profile.py`, the kernels' share of it."""
 import os
 import sys
@@ -34,5 +34,6 @@ for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
     strict_stack.strict_psf_maps(lens, dbar, fds, 11, 11, 2048)
     torch.cuda.synchronize()
     ts.append(time.perf_counter() - t0)
-print("strict stack, batched: seconds per stack", [round(t, 4) for t in ts])
+print("strict stack: seconds per stack", [round(t, 4) for t in ts])
 print("last stack, ms per segment:", lens._strict_timing)
+print("count table:", strict_stack.StrictCounts.of(lens).stats)
