@@ -78,6 +78,7 @@ PROTOTYPES = {
     "aadff_trace_rays_strict_batched": [_P, _P, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "aadff_trace_rays_strict_fused": [_P, _P, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "aadff_strict_psf_points": [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _F, _I, _I, _P, _P, _P, _P, _P],
+    "aadff_selftest_strict_ops": [_P, _P, _I, _I, _P, _P],
     "aadff_strict_centroid": [_P, _P, _I, _I, _I, _P, _P, _P],
     "aadff_trace_points": [_P, _I, _P, _P, _I, _F, _F, _P, _I, _P, _P, _P, _P, _P],
     "aadff_psf_splat": [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P],

@@ -22,6 +22,7 @@ libraries: the pupil sampling (`rand * 2 * pi`, MKL's vector sqrt / cos / sin - 
 element-wise, position independent, checked in tests), the focus and field-of-view reductions.  The host generator is consumed
 in the reference's order (per slice focus theta, focus r, then per wavelength main theta, main r, chief
 theta, chief r)."""
+import concurrent.futures
 import ctypes as C
 import os
 import time
@@ -306,6 +307,7 @@ def release_buffers(lens):
     lens._table_cache.pop("strict-rays", None)
 
 
+_WORKER = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="aadff-strict-host")   # see strict_psf_maps
 JOBS_PER_BATCH = 4          # candidate count rows per batch of a cheap level (levels 1, 2)
 FUSED_ROUNDS = 4            # corrected re-launches before a batch goes back to the per-surface form
 
@@ -458,19 +460,20 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None):
             t = st.h_par[0][:S * 3].view(f32).view(S, 3)
             t.zero_()
             t[:, 2] = torch.tensor([float(f) for f in focus], dtype=f32)
-            first = [True]
+
+            def psf_pupils():
+                # the psf_map pupil points are not needed before level 3: a worker thread evaluates them (torch releases the GIL in
+                # sqrt / cos / sin) while this thread goes through levels 1 and 2, which are launch and round-trip latency
+                hp[st.n_pf:st.n_pf + st.n_pm].view(B, spp, 3).copy_(_pupil_points(um[:, :, 0], um[:, :, 1], enp_rr, enp_z).reshape(B, spp, 3))
+                hp[st.n_pf + st.n_pm:].view(B, GEO_SPP, 3).copy_(_pupil_points(uc[:, :, 0], uc[:, :, 1], enp_rr * 0.5, enp_z).reshape(B, GEO_SPP, 3))
+
+            pupils_ready = _WORKER.submit(psf_pupils)
 
             def launch1(J, par, res):
                 G = st.G[0]
                 _abi.call("aadff_trace_rays_strict_fused", None, None, None, GEO_SPP, J, _abi.ptr(tab_dev), len(wv), n_surf, _abi.ptr(st.bt_green),
                           _ptr_at(par, 0), _ptr_at(par, G), _abi.ptr(st.d_pupil), 1, 0, n_surf, 1, None, _ptr_at(par, G + st.J),
                           _ptr_at(res, 2 * J * GEO_SPP), 1, 1, _ptr_at(res, 0), _ptr_at(res, J * GEO_SPP), _ptr_at(par, G), sp)
-                if first[0]:
-                    # the psf_map pupil points are not needed before level 3: computed and uploaded while level 1 runs
-                    first[0] = False
-                    hp[st.n_pf:st.n_pf + st.n_pm].view(B, spp, 3).copy_(_pupil_points(um[:, :, 0], um[:, :, 1], enp_rr, enp_z).reshape(B, spp, 3))
-                    hp[st.n_pf + st.n_pm:].view(B, GEO_SPP, 3).copy_(_pupil_points(uc[:, :, 0], uc[:, :, 1], enp_rr * 0.5, enp_z).reshape(B, GEO_SPP, 3))
-                    st.d_pupil[st.n_pf:].copy_(hp[st.n_pf:], non_blocking=True)
 
             got = _speculate_small(counts, keys[0], st, 0, S, GEO_SPP, curved, fwd_order, launch1, stream)
             if got is not None:
@@ -530,6 +533,8 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None):
                           _ptr_at(st.d_pupil, st.n_pf + st.n_pm), GEO_SPP, pred_ptr, float(lens.pixel_size), ks, grid, _abi.ptr(maps), _abi.ptr(centre),
                           _ptr_at(res, 0), _ptr_at(res, J * 4 * MS), sp)
 
+            pupils_ready.result()
+            st.d_pupil[st.n_pf:].copy_(hp[st.n_pf:], non_blocking=True)
             mark("level 3 inputs")
             r = st.round_trip(2, h.numel(), B * 4 * MS + B, lambda par, res: launch3(B, None, _ptr_at(par, B + S * N * 3), res), stream)
             counts.stats["fused"] += 1

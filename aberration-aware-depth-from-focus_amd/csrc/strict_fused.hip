@@ -15,7 +15,7 @@
 // evaluating it.  The reference makes all ten iterations at nine of rf50mm's eleven curved surfaces for the full-pupil batches
 // (dead rays frozen far from a surface keep |ft| above the tolerance for ever), 96 residual evaluations per ray; a ray's iterate is
 // periodic after 3.0 evaluations on average (tools/strict_cycle_stats.py), a wave's slowest after 5.
-#include "strict_math.h"
+#include "strict_math2.h"
 
 #pragma clang fp contract(off)
 
@@ -25,67 +25,33 @@ namespace strict {
 typedef const __attribute__((address_space(4))) aadff_surface_t* csurf_t;      // wave-uniform reads -> scalar loads
 typedef const __attribute__((address_space(4))) int* cpred_t;
 
-__device__ __forceinline__ unsigned fbits(float x) { return __float_as_uint(x); }
-
-// n iterations of the loose loop (deeplens/surfaces.py:547-563) from t0 for ONE ray: returns t after n iterations, ORs bit j - 1 into
-// `mine` / `nans` when |ft| > 5e-5 / ft is NaN in iteration j (1 <= j <= n).  Evaluates only until the iterate repeats with period
-// p <= 3 (t_j == t_{j-p}): then t_{m+p} = t_m and iteration m + p + 1 repeats iteration m + 1 for every m >= j - p.  (Period 3 is
-// not exotic: about 1 % of the live rays end up walking three neighbouring floats, tools/strict_cycle_stats.py - half the waves
-// would otherwise run all ten iterations for one such ray.)
-__device__ __forceinline__ float loose_cycle(const Surf& s, R3 o, R3 d, bool alive, int n, float t0, unsigned& mine, unsigned& nans) {
-    float t = t0, h2 = t0, h3 = t0, tn = t0;            // t = t_{j-1}, h2 = t_{j-2}, h3 = t_{j-3}; tn = t_j
-    unsigned bm = 0, bn = 0;
-    int j = 0, p = 0;
-    // the loop body is the residual and three compares; what a detected cycle implies is worked out ONCE behind the loop
-    while (true) {
-        ++j;
-        float ft, dfdt;
-        residual<false>(s, o, d, alive, t, ft, dfdt);
-        bm |= (fabsf(ft) > kTolLoose ? 1u : 0u) << (j - 1);
-        bn |= (ft != ft ? 1u : 0u) << (j - 1);
-        tn = t - clamp_step(ft / (dfdt + kEps));
-        if (j >= n) break;
-        // at j = 1 (2) the histories still hold t_0, so a "period 2 (3)" match there is the fixed point and is taken as p = 1
-        p = fbits(tn) == fbits(t) ? 1 : (fbits(tn) == fbits(h2) ? 2 : (fbits(tn) == fbits(h3) && j >= 3 ? 3 : 0));
-        if (p) break;
-        h3 = h2; h2 = t; t = tn;
-    }
-    float tfin = tn;
-    if (p) {
-        // bit indices j .. n-1 repeat the window of the last p iterations (bit indices j-p .. j-1)
-        const unsigned all = (1u << n) - 1u;
-        const unsigned rep = p == 1 ? 0x3ffu : (p == 2 ? 0x155u : 0x249u);
-        const unsigned wm = (1u << p) - 1u;
-        bm |= ((((bm >> (j - p)) & wm) * rep) << j) & all;
-        bn |= ((((bn >> (j - p)) & wm) * rep) << j) & all;
-        const int dn = n - j;                            // r = dn mod p without an integer division (dn <= 9)
-        const int r = p == 1 ? 0 : (p == 2 ? (dn & 1) : dn - 3 * ((dn * 11) >> 5));      // t_n = t_{j-p+r}: r = 0 -> t_j (= t_{j-p}), then t_{j-p+1}, ...
-        tfin = r == 0 ? tn : (p - r == 1 ? t : h2);
-    }
-    mine |= bm; nans |= bn;
-    return tfin;
-}
-
 __device__ __forceinline__ Surf load_surf(csurf_t h, int forward) { return make_surf_from(h, forward); }
 
-// One ray through surfaces [first, last) in travel order with the predicted counts pred[surface] (1..10); any-bits / NaN-bits of
-// curved surface i are ORed into sink(i, bits) as (nan << 16 | any).
+// Two rays (the halves of a lane's float2 values, csrc/strict_math2.h) through surfaces [first, last) in travel order with the
+// predicted counts pred[surface] (1..10); any-bits / NaN-bits of curved surface i are ORed into sink(i, bits) as (nan << 16 | any).
 template <typename Sink>
-__device__ __forceinline__ void trace_ray_fused(csurf_t tab, int first, int last, int forward, cpred_t pred, R3& o, R3& d, float& ra, Sink sink) {
+__device__ __forceinline__ void trace_ray_fused2(csurf_t tab, int first, int last, int forward, cpred_t pred, R32& o, R32& d, f2& ra, Sink sink) {
     const int nsteps = last - first;
     for (int k = 0; k < nsteps; ++k) {
         const int i = forward ? first + k : last - 1 - k;
         const Surf s = load_surf(tab + i, forward);
+        const f2 t0 = div2(s.d - o.z, d.z);
         if (s.flat) {
-            react_ray(s, o, d, ra, forward, 0);
+            react_ray2<true>(s, o, d, ra, forward, t0, t0);
         } else {
             int n = pred[i];
             n = n < 1 ? 1 : (n > kMaxIter ? kMaxIter : n);
             unsigned mine = 0, nans = 0;
-            const float t0 = (s.d - o.z) / d.z;
-            const float t = loose_cycle(s, o, d, ra > 0.f, n, t0, mine, nans);
-            sink(i, mine | (nans << 16));
-            react_ray(s, o, d, ra, forward, n, true, t);
+            const f2 alive = sel(ra > 0.f, f2s(1.f), f2s(0.f));
+            if (s.k_gt_m1) {                             // uniform: the usual case (k > -1) and the rest as two instances of the loop
+                const f2 t = loose_cycle2<true>(s, o, d, alive, n, t0, mine, nans);
+                sink(i, mine | (nans << 16));
+                react_ray2<true>(s, o, d, ra, forward, t0, t);
+            } else {
+                const f2 t = loose_cycle2<false>(s, o, d, alive, n, t0, mine, nans);
+                sink(i, mine | (nans << 16));
+                react_ray2<false>(s, o, d, ra, forward, t0, t);
+            }
         }
     }
 }
@@ -109,7 +75,7 @@ __device__ __forceinline__ void flush_bits(const unsigned* lds_w, unsigned* g_an
 
 struct __attribute__((packed, aligned(4))) f3p { float x, y, z; };
 
-// ---- flat form: B batches of n rays, one ray per thread (refocus and field-of-view levels; any caller-built batch) ---------------
+// ---- flat form: B batches of n rays, two rays per thread (refocus and field-of-view levels; any caller-built batch) --------------
 // bits: [B][2][AADFF_MAX_SURF] (any, nan), zeroed by the caller.
 template <bool FROM_POINTS>
 __global__ __launch_bounds__(256) void fused_flat_kernel(float* o_io, float* d_io, float* ra_io, int n, const int* __restrict__ batch_table,
@@ -119,45 +85,60 @@ __global__ __launch_bounds__(256) void fused_flat_kernel(float* o_io, float* d_i
                                                          int origin_at_pupil, int out_mode, float* __restrict__ out0, float* __restrict__ out1,
                                                          const int* __restrict__ pupil_set) {
     __shared__ unsigned w[AADFF_MAX_SURF];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    const int b = blockIdx.y;
+    const int i0 = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
     for (int k = threadIdx.x; k < AADFF_MAX_SURF; k += blockDim.x) w[k] = 0u;
     __syncthreads();
-    if (i < n) {
-        const size_t idx = (size_t)b * n + i;
-        R3 o, d;
-        float ra;
+    if (i0 < n) {
+        const int i1 = i0 + 1 < n ? i0 + 1 : i0;        // a lone last ray is traced in both halves (same bits), stored once
+        const size_t base = (size_t)b * n;
+        R32 o, d;
+        f2 ra;
         if constexpr (FROM_POINTS) {
-            const int sample = i / N, pt = i - sample * N;
-            const f3p po = *reinterpret_cast<const f3p*>(points + ((size_t)point_set[b] * N + pt) * 3);
-            const f3p pp = *reinterpret_cast<const f3p*>(pupil + ((size_t)(pupil_set ? pupil_set[b] : b) * (n / N) + sample) * 3);
-            o = {po.x, po.y, po.z};
-            d = {pp.x - po.x, pp.y - po.y, pp.z - po.z};
-            normalize3(d.x, d.y, d.z);
-            if (origin_at_pupil) o = {pp.x, pp.y, pp.z};                         // refocus: rays leave the aperture points (optics.py:1166-1170)
-            ra = 1.f;
+            const int sa = i0 / N, pa = i0 - sa * N, sb = i1 / N, pb = i1 - sb * N;
+            const float* prow = pupil + (size_t)(pupil_set ? pupil_set[b] : b) * (n / N) * 3;
+            const float* qrow = points + (size_t)point_set[b] * N * 3;
+            const f3p poa = *reinterpret_cast<const f3p*>(qrow + (size_t)pa * 3), pob = *reinterpret_cast<const f3p*>(qrow + (size_t)pb * 3);
+            const f3p ppa = *reinterpret_cast<const f3p*>(prow + (size_t)sa * 3), ppb = *reinterpret_cast<const f3p*>(prow + (size_t)sb * 3);
+            o = {(f2){poa.x, pob.x}, (f2){poa.y, pob.y}, (f2){poa.z, pob.z}};
+            const R32 pp = {(f2){ppa.x, ppb.x}, (f2){ppa.y, ppb.y}, (f2){ppa.z, ppb.z}};
+            d = {pp.x - o.x, pp.y - o.y, pp.z - o.z};
+            normalize32(d.x, d.y, d.z);
+            if (origin_at_pupil) o = pp;                                         // refocus: rays leave the aperture points (optics.py:1166-1170)
+            ra = f2s(1.f);
         } else {
-            const f3p a = *reinterpret_cast<const f3p*>(o_io + idx * 3), c = *reinterpret_cast<const f3p*>(d_io + idx * 3);
-            o = {a.x, a.y, a.z}; d = {c.x, c.y, c.z};
-            ra = ra_io[idx];
+            const f3p oa = *reinterpret_cast<const f3p*>(o_io + (base + i0) * 3), ob = *reinterpret_cast<const f3p*>(o_io + (base + i1) * 3);
+            const f3p da = *reinterpret_cast<const f3p*>(d_io + (base + i0) * 3), db = *reinterpret_cast<const f3p*>(d_io + (base + i1) * 3);
+            o = {(f2){oa.x, ob.x}, (f2){oa.y, ob.y}, (f2){oa.z, ob.z}};
+            d = {(f2){da.x, db.x}, (f2){da.y, db.y}, (f2){da.z, db.z}};
+            ra = (f2){ra_io[base + i0], ra_io[base + i1]};
         }
         const csurf_t tab = (csurf_t)(tables + (size_t)batch_table[b] * n_surf);
-        trace_ray_fused(tab, first, last, forward, (cpred_t)(pred + (size_t)b * AADFF_MAX_SURF), o, d, ra, LdsSink{w});
+        trace_ray_fused2(tab, first, last, forward, (cpred_t)(pred + (size_t)b * AADFF_MAX_SURF), o, d, ra, LdsSink{w});
         if (z_sensor) {                                                          // Ray.propagate_to, basics.py:255-273
-            const float t = (z_sensor[b] - o.z) / d.z;
+            const f2 t = div2(z_sensor[b] - o.z, d.z);
             o.x = o.x + d.x * t; o.y = o.y + d.y * t; o.z = o.z + d.z * t;
         }
+        f2 v0, v1 = ra;
         if (out_mode == 1) {                                                     // refocus: where the ray crosses the axis (optics.py:1171-1174)
-            float tt = (d.x * o.x + d.y * o.y) / (d.x * d.x + d.y * d.y);
+            f2 tt = div2(d.x * o.x + d.y * o.y, d.x * d.x + d.y * d.y);
             tt = tt * ra;
-            out0[idx] = o.z - d.z * tt;
-            out1[idx] = ra;
+            v0 = o.z - d.z * tt;
         } else if (out_mode == 2) {                                              // calc_fov: tan of the ray's angle (optics.py:1205)
-            out0[idx] = d.x / d.z;
-            out1[idx] = ra;
+            v0 = div2(d.x, d.z);
+        }
+        if (out_mode != 0) {
+            out0[base + i0] = v0.x; out1[base + i0] = v1.x;
+            if (i1 != i0) { out0[base + i1] = v0.y; out1[base + i1] = v1.y; }
         } else {
-            *reinterpret_cast<f3p*>(o_io + idx * 3) = (f3p){o.x, o.y, o.z};
-            *reinterpret_cast<f3p*>(d_io + idx * 3) = (f3p){d.x, d.y, d.z};
-            ra_io[idx] = ra;
+            *reinterpret_cast<f3p*>(o_io + (base + i0) * 3) = (f3p){o.x.x, o.y.x, o.z.x};
+            *reinterpret_cast<f3p*>(d_io + (base + i0) * 3) = (f3p){d.x.x, d.y.x, d.z.x};
+            ra_io[base + i0] = ra.x;
+            if (i1 != i0) {
+                *reinterpret_cast<f3p*>(o_io + (base + i1) * 3) = (f3p){o.x.y, o.y.y, o.z.y};
+                *reinterpret_cast<f3p*>(d_io + (base + i1) * 3) = (f3p){d.x.y, d.y.y, d.z.y};
+                ra_io[base + i1] = ra.y;
+            }
         }
     }
     __syncthreads();
@@ -210,7 +191,9 @@ __global__ __launch_bounds__(kPsfThreads) void fused_psf_kernel(PsfArgs a) {
     if (tid == 0) s_valid = 0;
     __syncthreads();
 
-    const f3p po = *reinterpret_cast<const f3p*>(a.points + ((size_t)a.point_set[b] * N + pt) * 3);
+    typedef const __attribute__((address_space(4))) float* cfloat_t;                  // workgroup-uniform: scalar loads
+    const cfloat_t pp0 = (cfloat_t)(a.points + ((size_t)a.point_set[b] * N + pt) * 3);
+    const struct { float x, y, z; } po = {pp0[0], pp0[1], pp0[2]};
     const float zs = a.z_sensor[b];
 
     // ---- phase 1: chief rays
@@ -218,16 +201,22 @@ __global__ __launch_bounds__(kPsfThreads) void fused_psf_kernel(PsfArgs a) {
         const csurf_t tab = (csurf_t)(a.tables + (size_t)a.table_chief[b] * a.n_surf);
         const cpred_t pred = (cpred_t)(a.pred + ((size_t)job * 2 + 0) * AADFF_MAX_SURF);
         bool valid = false;
-        for (int smp = tid; smp < spp_c; smp += kPsfThreads) {
-            const f3p pp = *reinterpret_cast<const f3p*>(a.pupil_chief + ((size_t)b * spp_c + smp) * 3);
-            R3 o = {po.x, po.y, po.z}, d = {pp.x - po.x, pp.y - po.y, pp.z - po.z};
-            normalize3(d.x, d.y, d.z);
-            float ra = 1.f;
-            trace_ray_fused(tab, 0, a.n_surf, 1, pred, o, d, ra, LdsSink{w[0]});
-            const float t = (zs - o.z) / d.z;
+        // two rays per lane: samples smp and smp + kPsfThreads (a lone last sample is traced twice: same bits, stored once)
+        for (int smp = tid; smp < spp_c; smp += 2 * kPsfThreads) {
+            const int smp2 = smp + kPsfThreads < spp_c ? smp + kPsfThreads : smp;
+            const f3p pa = *reinterpret_cast<const f3p*>(a.pupil_chief + ((size_t)b * spp_c + smp) * 3);
+            const f3p pb = *reinterpret_cast<const f3p*>(a.pupil_chief + ((size_t)b * spp_c + smp2) * 3);
+            R32 o = {f2s(po.x), f2s(po.y), f2s(po.z)};
+            R32 d = {(f2){pa.x, pb.x} - o.x, (f2){pa.y, pb.y} - o.y, (f2){pa.z, pb.z} - o.z};
+            normalize32(d.x, d.y, d.z);
+            f2 ra = f2s(1.f);
+            trace_ray_fused2(tab, 0, a.n_surf, 1, pred, o, d, ra, LdsSink{w[0]});
+            const f2 t = div2(zs - o.z, d.z);
             o.x = o.x + d.x * t; o.y = o.y + d.y * t;
-            rows[smp] = o.x * ra; rows[spp_c + smp] = o.y * ra; rows[2 * spp_c + smp] = ra;
-            valid |= ra == 1.f;
+            const f2 wx = o.x * ra, wy = o.y * ra;
+            rows[smp] = wx.x; rows[spp_c + smp] = wy.x; rows[2 * spp_c + smp] = ra.x;
+            if (smp2 != smp) { rows[smp2] = wx.y; rows[spp_c + smp2] = wy.y; rows[2 * spp_c + smp2] = ra.y; }
+            valid |= ra.x == 1.f || ra.y == 1.f;
         }
         if (__any(valid) && (tid & 63) == 0) atomicOr(&s_valid, 1);
     }
@@ -302,16 +291,9 @@ __global__ __launch_bounds__(kPsfThreads) void fused_psf_kernel(PsfArgs a) {
         const cpred_t pred = (cpred_t)(a.pred + ((size_t)job * 2 + 1) * AADFF_MAX_SURF);
         const float cx = cxy[0], cy = cxy[1];
         const float km1 = (float)(ks - 1);
-        for (int smp = tid; smp < a.spp; smp += kPsfThreads) {
-            const f3p pp = *reinterpret_cast<const f3p*>(a.pupil_main + ((size_t)b * a.spp + smp) * 3);
-            R3 o = {po.x, po.y, po.z}, d = {pp.x - po.x, pp.y - po.y, pp.z - po.z};
-            normalize3(d.x, d.y, d.z);
-            float ra = 1.f;
-            trace_ray_fused(tab, 0, a.n_surf, 1, pred, o, d, ra, LdsSink{w[1]});
-            const float t = (zs - o.z) / d.z;
-            o.x = o.x + d.x * t; o.y = o.y + d.y * t;
+        auto splat = [&](float ox, float oy, float ra) {
             // forward_integral: flip, centre, window test (monte_carlo.py:24-38); a ray outside deposits zero weights: skipped
-            const float X = -o.x - cx, Y = -o.y - cy;
+            const float X = -ox - cx, Y = -oy - cy;
             if ((fabsf(X) < a.lim) && (fabsf(Y) < a.lim) && (ra > 0.f)) {
                 const float rowf = ((Y - a.hi) / a.den_row) * km1, colf = ((X - a.lo) / a.den_col) * km1;   // monte_carlo.py:86-92
                 const float fr = floorf(rowf), fc = floorf(colf);
@@ -323,6 +305,20 @@ __global__ __launch_bounds__(kPsfThreads) void fused_psf_kernel(PsfArgs a) {
                 atomicAdd(&hist[r1 * ks + c0], (wb * (1.f - wr)) * ra);
                 atomicAdd(&hist[(r0 + 1) * ks + (c0 + 1)], (wb * wr) * ra);
             }
+        };
+        for (int smp = tid; smp < a.spp; smp += 2 * kPsfThreads) {
+            const int smp2 = smp + kPsfThreads < a.spp ? smp + kPsfThreads : smp;
+            const f3p pa = *reinterpret_cast<const f3p*>(a.pupil_main + ((size_t)b * a.spp + smp) * 3);
+            const f3p pb = *reinterpret_cast<const f3p*>(a.pupil_main + ((size_t)b * a.spp + smp2) * 3);
+            R32 o = {f2s(po.x), f2s(po.y), f2s(po.z)};
+            R32 d = {(f2){pa.x, pb.x} - o.x, (f2){pa.y, pb.y} - o.y, (f2){pa.z, pb.z} - o.z};
+            normalize32(d.x, d.y, d.z);
+            f2 ra = f2s(1.f);
+            trace_ray_fused2(tab, 0, a.n_surf, 1, pred, o, d, ra, LdsSink{w[1]});
+            const f2 t = div2(zs - o.z, d.z);
+            o.x = o.x + d.x * t; o.y = o.y + d.y * t;
+            splat(o.x.x, o.y.x, ra.x);
+            if (smp2 != smp) splat(o.x.y, o.y.y, ra.y);
         }
     }
     __syncthreads();
@@ -350,6 +346,27 @@ __global__ __launch_bounds__(kPsfThreads) void fused_psf_kernel(PsfArgs a) {
     flush_bits(w[1], gb + 2 * AADFF_MAX_SURF, gb + 3 * AADFF_MAX_SURF);
 }
 
+// self test of the packed primitives against the compiler's IEEE forms (tests/test_gpu_parity.py)
+__global__ void selftest_ops_kernel(const float* __restrict__ num, const float* __restrict__ den, int n, int op, unsigned* __restrict__ mism) {
+    const int i = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const int k = i + 1 < n ? i + 1 : i;
+    const f2 a = {num[i], num[k]};
+    f2 q;
+    float r0, r1;
+    if (op == 0) {
+        const f2 b = {den[i], den[k]};
+        q = div2(a, b);
+        r0 = a.x / b.x; r1 = a.y / b.y;
+    } else {
+        q = sqrt2(a);
+        r0 = sqrtf(a.x); r1 = sqrtf(a.y);
+    }
+    auto same = [](float u, float v) { return (u != u && v != v) || __float_as_uint(u) == __float_as_uint(v); };
+    if (!same(q.x, r0)) { const unsigned c = atomicAdd(mism, 1u); if (c < 8) { mism[1 + 2 * c] = i; mism[2 + 2 * c] = __float_as_uint(q.x); } }
+    if (k != i && !same(q.y, r1)) { const unsigned c = atomicAdd(mism, 1u); if (c < 8) { mism[1 + 2 * c] = k; mism[2 + 2 * c] = __float_as_uint(q.y); } }
+}
+
 }  // namespace strict
 }  // namespace aadff
 
@@ -371,7 +388,7 @@ extern "C" int aadff_trace_rays_strict_fused(float* o, float* d, float* ra, int 
     hipStream_t st = (hipStream_t)stream;
     AADFF_CHECK_HIP(hipMemsetAsync(bits, 0, (size_t)B * 2 * AADFF_MAX_SURF * sizeof(unsigned), st));
     if (n == 0 || first == last) return 0;
-    const dim3 g((n + 255) / 256, B), blk(256);
+    const dim3 g(((n + 1) / 2 + 255) / 256, B), blk(256);
     if (points_or_null)
         hipLaunchKernelGGL(strict::fused_flat_kernel<true>, g, blk, 0, st, o, d, ra, n, batch_table, tables_dev, n_surf, points_or_null, point_set, pupil, N,
                            first, last, forward, z_sensor_or_null, pred, bits, origin_at_pupil, out_mode, out0, out1, pupil_set_or_null);
@@ -410,6 +427,16 @@ extern "C" int aadff_strict_psf_points(const float* points, int N, int B, const 
     a.lo = (float)lo; a.hi = (float)hi; a.lim = (float)(hi - 0.01 * ps); a.den_row = (float)(lo - hi); a.den_col = (float)(hi - lo);
     if ((long)N * B >= 1024) hipLaunchKernelGGL(strict::fused_psf_kernel<256>, dim3(N, B), dim3(256), lds, st, a);
     else hipLaunchKernelGGL(strict::fused_psf_kernel<1024>, dim3(N, B), dim3(1024), lds, st, a);
+    AADFF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int aadff_selftest_strict_ops(const float* num, const float* den, int n, int op, unsigned* mismatches, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(num && (den || op == 1) && mismatches && n >= 0 && (op == 0 || op == 1), "selftest_strict_ops: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    AADFF_CHECK_HIP(hipMemsetAsync(mismatches, 0, 17 * sizeof(unsigned), st));
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(strict::selftest_ops_kernel, dim3(((n + 1) / 2 + 255) / 256), dim3(256), 0, st, num, den, n, op, mismatches);
     AADFF_CHECK_LAUNCH();
     return 0;
 }

@@ -35,8 +35,8 @@ struct Surf {                       // constants of one surface as the reference
 
 __device__ __forceinline__ float conic_a(const Surf& s, float r2) { return ((1.f + s.k) * r2) * (s.c * s.c); }
 
-__device__ __forceinline__ float sag(const Surf& s, float r2) {                   // surfaces.py:787-809 (power form)
-    float z = (r2 * s.c) / (1.f + sqrtf(1.f - conic_a(s, r2)));
+// the even-polynomial terms of the sag and of d sag / d r^2 (surfaces.py:799-809, 823-830), added to the conic part z / g
+__device__ __forceinline__ float sag_poly(const Surf& s, float r2, float z) {
     if (s.n_ai > 0) {                                  // one uniform branch: spheres skip the polynomial (and its float64 powers) entirely
 #pragma unroll
         for (int j = 0; j < AADFF_MAX_AI; ++j)         // constant indices: the coefficients stay in (scalar) registers
@@ -45,9 +45,7 @@ __device__ __forceinline__ float sag(const Surf& s, float r2) {                 
     return z;
 }
 
-__device__ __forceinline__ float dsag(const Surf& s, float r2) {                  // surfaces.py:811-830
-    const float sf = sqrtf(1.f - conic_a(s, r2));
-    float g = (((1.f + sf) + (conic_a(s, r2) / 2.f) / sf) * s.c) / ((1.f + sf) * (1.f + sf));
+__device__ __forceinline__ float dsag_poly(const Surf& s, float r2, float g) {
     if (s.n_ai > 0) {
 #pragma unroll
         for (int j = 0; j < AADFF_MAX_AI; ++j) {
@@ -58,6 +56,15 @@ __device__ __forceinline__ float dsag(const Surf& s, float r2) {                
         }
     }
     return g;
+}
+
+__device__ __forceinline__ float sag(const Surf& s, float r2) {                   // surfaces.py:787-809 (power form)
+    return sag_poly(s, r2, (r2 * s.c) / (1.f + sqrtf(1.f - conic_a(s, r2))));
+}
+
+__device__ __forceinline__ float dsag(const Surf& s, float r2) {                  // surfaces.py:811-830
+    const float sf = sqrtf(1.f - conic_a(s, r2));
+    return dsag_poly(s, r2, (((1.f + sf) + (conic_a(s, r2) / 2.f) / sf) * s.c) / ((1.f + sf) * (1.f + sf)));
 }
 
 __device__ __forceinline__ bool valid_strict(const Surf& s, float x, float y) {   // surfaces.py:724-732

@@ -252,6 +252,12 @@ int aadff_strict_psf_points(const float* points, int N, int B, const int* job_ba
                             int spp, const float* pupil_chief, int spp_chief, const int* pred, float pixel_size, int ks, int map_grid,
                             float* psf, float* centre, unsigned* bits, int* any_valid, aadff_stream_t stream);
 
+/* Self test (no reference counterpart) of the packed float32 primitives the two-rays-per-lane strict kernels use (csrc/strict_math2.h)
+ * against the compiler's IEEE forms, bit for bit: op 0: num[i] / den[i] (reciprocal refinement with packed FMAs + v_div_fixup_f32,
+ * no v_div_scale_f32 pre-scaling); op 1: sqrt(num[i]) (v_sqrt_f32 + two-neighbour correction, no pre-scaling of arguments below
+ * 2^-96).  n values (device).  mismatches: 17 device words = count, then (index, bits of the packed result) of the first 8. */
+int aadff_selftest_strict_ops(const float* num, const float* den, int n, int op, unsigned* mismatches, aadff_stream_t stream);
+
 /* Chief-ray PSF centres of B batches: centre[b][p] = -(sum_s o_xy[b,s,p] ra[b,s,p]) / (sum_s ra[b,s,p] + 1e-9), o [B,spp,N,3],
  * ra [B,spp,N] (device) -> centre [B,N,2]; any_valid [B] = 1 where some ray of the batch has ra == 1 (the reference asserts it:
  * "No sampled rays is valid.", deeplens/optics.py:901).  The sums run in the ORDER of ATen's CPU `tensor.sum(0)` (cascade

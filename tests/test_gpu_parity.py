@@ -1557,3 +1557,48 @@ def test_staged_upload_rejects_unpinned_host_block(repo_root):
         _abi.call("aadff_refocus_staged", _abi.ptr(dep), 1, C.c_void_p(u_host.data_ptr()), _abi.ptr(u_dev), 2 * GEO_SPP,
                   GEO_SPP, 2 * GEO_SPP, _abi.ptr(lens._table([0.589])), lens._lens_const(), _abi.ptr(states),
                   _abi.ptr(torch.zeros(16, dtype=torch.int32, device=DEV)), _abi.stream_ptr(torch.device(DEV)))
+
+
+def test_packed_division_and_sqrt_of_the_strict_kernels_are_ieee():
+    """csrc/strict_math2.h `div2` (v_rcp_f32 + packed-FMA refinement + v_div_fixup_f32, no v_div_scale_f32) against the compiler's
+    IEEE float32 division, bit for bit: operands over the ranges a trace produces (|x| in 2^-80 .. 2^80, any signs), exact zeros,
+    infinities, NaNs, numerators down to the edge of what the missing pre-scaling covers (2^-100), quotients near 1 - the mismatch
+    count must be ZERO there.  Outside (numerators below 2^-104, exponent gaps above 96) the pre-scaled form is needed: reported."""
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(7)
+    n = 1 << 22
+
+    def rnd(lo, hi, n):
+        mant = 1 + torch.rand(n, generator=g)
+        e = torch.randint(lo, hi + 1, (n,), generator=g).float()
+        sign = torch.where(torch.rand(n, generator=g) < 0.5, -1.0, 1.0)
+        return (sign * mant * torch.exp2(e)).float()
+
+    cases = {
+        "trace magnitudes": (rnd(-40, 14, n), rnd(-30, 14, n)),
+        "wide": (rnd(-80, 80, n), rnd(-40, 40, n)),
+        "near one": (1 + (torch.rand(n, generator=g) - 0.5) * 1e-3, 1 + (torch.rand(n, generator=g) - 0.5) * 1e-3),
+        "small numerators": (rnd(-100, -60, n), rnd(-4, 4, n)),
+    }
+    special = torch.tensor([0.0, -0.0, float("inf"), -float("inf"), float("nan"), 1.0, -1.0, 3.0, 1e-30, 1e30, 5e-5, 2.0 ** -100])
+    cases["specials"] = (special.repeat_interleave(len(special)), special.repeat(len(special)))
+    for name, (a, b) in cases.items():
+        ad, bd = a.float().to(dev).contiguous(), b.float().to(dev).contiguous()
+        mm = torch.zeros(17, dtype=torch.int32, device=dev)
+        _abi.call("aadff_selftest_strict_ops", _abi.ptr(ad), _abi.ptr(bd), ad.numel(), 0, _abi.ptr(mm), _abi.stream_ptr(dev))
+        m = mm.cpu().numpy().view(np.uint32)
+        first = [(int(m[1 + 2 * k]), float(a[int(m[1 + 2 * k])]), float(b[int(m[1 + 2 * k])])) for k in range(min(int(m[0]), 8))]
+        assert m[0] == 0, (name, int(m[0]), first)
+    a, b = rnd(-126, -100, n), rnd(-4, 100, n)                                  # outside the domain: informative
+    mm = torch.zeros(17, dtype=torch.int32, device=dev)
+    _abi.call("aadff_selftest_strict_ops", _abi.ptr(a.to(dev)), _abi.ptr(b.to(dev)), n, 0, _abi.ptr(mm), _abi.stream_ptr(dev))
+    print(f"packed division outside its domain (numerators 2^-126..2^-100): {int(mm[0])} of {n} quotients differ from IEEE")
+    # square root: the arguments of the trace (1 - a in [2^-24, 1], squared norms, 0, negatives -> NaN, inf, NaN), every float in [1, 4)
+    roots = {"unit interval": torch.rand(n, generator=g), "norms": rnd(-20, 40, n).abs(), "near zero of 1 - a": (torch.arange(1, 4097).float() * 2.0 ** -24),
+             "specials": torch.tensor([0.0, -0.0, float("inf"), float("nan"), -1.0, -1e-30, 1.0, 2.0, 4.0, 2.0 ** -96, 3.0]),
+             "all of [1, 4)": torch.arange(0x3f800000, 0x40800000, dtype=torch.int32).view(torch.float32)}
+    for name, a in roots.items():
+        ad = a.float().to(dev).contiguous()
+        _abi.call("aadff_selftest_strict_ops", _abi.ptr(ad), None, ad.numel(), 1, _abi.ptr(mm), _abi.stream_ptr(dev))
+        m = mm.cpu().numpy().view(np.uint32)
+        assert m[0] == 0, (name, int(m[0]), [float(a[int(m[1 + 2 * k])]) for k in range(min(int(m[0]), 8))])
