@@ -92,22 +92,22 @@ def check_counts(any_bits, pred, curved, order):
     corrected there - an earlier iteration without any ray above the tolerance gives the true count (first clear bit + 1); all n
     bits set with n < 10 means the loop runs on: n + 1 is tried - and nothing behind that surface is looked at (its bits are
     meaningless)."""
-    m = np.asarray(any_bits).astype(np.uint32)
-    fix = np.array(pred, dtype=np.int32, copy=True)
-    ok = np.ones(m.shape[:-1], dtype=bool)
-    for i in order:
-        if not curved[i]:
-            continue
-        n = fix[..., i].astype(np.uint32)
-        mi = m[..., i]
-        low = (np.uint32(1) << (n - 1)) - np.uint32(1)
-        short = (mi & low) != low
-        more = ~short & (n < MAX_ITER) & (((mi >> (n - 1)) & 1) == 1)
-        bad = (short | more) & ok
-        if bad.any():
-            true_n = counts_of_masks(mi | ~low)
-            fix[..., i] = np.where(bad, np.where(short, true_n, n.astype(np.int32) + 1), fix[..., i])
-            ok &= ~bad
+    idx = np.asarray(order, dtype=np.int64)
+    pred = np.asarray(pred, dtype=np.int32)
+    m = np.asarray(any_bits).astype(np.uint32)[..., idx]
+    n = pred[..., idx].astype(np.uint32)
+    low = (np.uint32(1) << (n - 1)) - np.uint32(1)
+    short = (m & low) != low
+    more = ~short & (n < MAX_ITER) & (((m >> (n - 1)) & 1) == 1)
+    bad = (short | more) & np.asarray(curved, dtype=bool)[idx]
+    ok = ~bad.any(-1)
+    fix = pred.copy()
+    if not ok.all():
+        first = bad.argmax(-1)[..., None]                 # the first failing surface in crossing order
+        take = lambda a: np.take_along_axis(a, first, -1)
+        corrected = np.where(take(short), counts_of_masks(take(m | ~low)), take(n).astype(np.int32) + 1)
+        where = idx[first]
+        np.put_along_axis(fix, where, np.where(ok[..., None], np.take_along_axis(pred, where, -1), corrected), -1)
     return ok, fix
 
 
@@ -150,9 +150,12 @@ class StrictCounts:
 
 
 def _curved(lens):
-    c = np.zeros(_abi.MAX_SURF, dtype=bool)
-    for i, s in enumerate(lens.surfaces):
-        c[i] = s.pack(DEFAULT_WAVE).kind != _abi.SURF_STOP
+    c = lens._table_cache.get("strict-curved")
+    if c is None:
+        c = np.zeros(_abi.MAX_SURF, dtype=bool)
+        for i, s in enumerate(lens.surfaces):
+            c[i] = s.pack(DEFAULT_WAVE).kind != _abi.SURF_STOP
+        lens._table_cache["strict-curved"] = c
     return c
 
 
@@ -417,6 +420,7 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None):
         raise ValueError(f"ks={ks} exceeds the kernels' limit {_abi.MAX_KS}")
     if fused is None:
         fused = os.environ.get("AADFF_STRICT_FUSED", "1") != "0"
+    t_enter = time.perf_counter()
     S, L, N = len(focus), len(WAVE_RGB), grid * grid
     B, MS = S * L, _abi.MAX_SURF
     dev = lens._gpu()
@@ -463,9 +467,14 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None):
 
             def psf_pupils():
                 # the psf_map pupil points are not needed before level 3: a worker thread evaluates them (torch releases the GIL in
-                # sqrt / cos / sin) while this thread goes through levels 1 and 2, which are launch and round-trip latency
-                hp[st.n_pf:st.n_pf + st.n_pm].view(B, spp, 3).copy_(_pupil_points(um[:, :, 0], um[:, :, 1], enp_rr, enp_z).reshape(B, spp, 3))
-                hp[st.n_pf + st.n_pm:].view(B, GEO_SPP, 3).copy_(_pupil_points(uc[:, :, 0], uc[:, :, 1], enp_rr * 0.5, enp_z).reshape(B, GEO_SPP, 3))
+                # sqrt / cos / sin) while this thread goes through levels 1 and 2, which are launch and round-trip latency.  Slice by
+                # slice: below ATen's grain size (32768 elements) an element-wise op stays on the calling thread - a second OpenMP
+                # team next to the main thread's oversubscribes a CPU quota (spinning workers: 60-80 ms stalls were measured)
+                pm_h = hp[st.n_pf:st.n_pf + st.n_pm].view(S, L, spp, 3)
+                pc_h = hp[st.n_pf + st.n_pm:].view(S, L, GEO_SPP, 3)
+                for k in range(S):
+                    pm_h[k].copy_(_pupil_points(um[k, :, 0], um[k, :, 1], enp_rr, enp_z))
+                    pc_h[k].copy_(_pupil_points(uc[k, :, 0], uc[k, :, 1], enp_rr * 0.5, enp_z))
 
             pupils_ready = _WORKER.submit(psf_pupils)
 
@@ -590,7 +599,7 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None):
             maps = _tile(psf, grid, ks).reshape(S, L, grid * ks, grid * ks)
         mark("level 3 done")
         if marks is not None:
-            lens._strict_timing = [(b[0], round((b[1] - a[1]) * 1e3, 3)) for a, b in zip(marks, marks[1:])]
+            lens._strict_timing = [("draws and setup", round((marks[0][1] - t_enter) * 1e3, 3))] + [(b[0], round((b[1] - a[1]) * 1e3, 3)) for a, b in zip(marks, marks[1:])]
     assert bool(any_valid.bool().all()), "No sampled rays is valid."
     # the lens is left focused at the last distance
     lens._state_sync()

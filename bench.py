@@ -379,12 +379,20 @@ def main():
                 per2 = [float(np.linalg.norm(a2[:, k] - b[:, k]) / np.linalg.norm(b[:, k])) for k in range(n)]
                 n_strict = max(20, min(args.steps, 50))
                 stats0 = dict(_ss.StrictCounts.of(ls).stats)
-                t_s = time.perf_counter()
+                import gc
+                gc.collect()
+                gc.freeze()                                      # the bench's long-lived objects out of the collector's way: a full collection
+                t_s = time.perf_counter()                        # over them cost 50-90 ms every ~10 steps of this leg
                 for _ in range(n_strict):                        # new draws every step: the generator runs on, as in the reference's loop
                     so = _rfs(ls, img, dbar, fds, GRID, KS, SPP)
+                    if os.environ.get("AADFF_STRICT_TIMING") == "1":
+                        torch.cuda.synchronize(dev)
+                        print("bench: strict step", round((time.perf_counter() - t_s) * 1e3, 2), getattr(ls, "_strict_timing", None), file=sys.stderr, flush=True)
                 torch.cuda.synchronize(dev)
                 t_s = (time.perf_counter() - t_s) / n_strict
                 stats1 = _ss.StrictCounts.of(ls).stats
+                if os.environ.get("AADFF_STRICT_TIMING") == "1":
+                    print("bench: strict segments [ms]", getattr(ls, "_strict_timing", None), file=sys.stderr, flush=True)
                 res["parity"]["strict_mode"] = {"rel_l2": float(f"{np.linalg.norm(a2 - b) / np.linalg.norm(b):.3e}"),
                                                 "rel_l2_per_slice": [float(f"{v:.3e}") for v in per2], "worst_slice": float(f"{max(per2):.3e}"),
                                                 "tolerance_per_slice": 1e-4,

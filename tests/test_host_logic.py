@@ -698,3 +698,18 @@ def test_strict_count_table_logic():
             assert bool(prediction_holds(np.array([[seen]]), np.array([[n]]), curved)[0]) == (n == n_true), (m, n, n_true)
     # flat surfaces are ignored
     assert prediction_holds(np.array([[0, 5]], dtype=np.uint32), np.array([[1, 4]]), np.array([True, False]))[0]
+    # check_counts: the first failing surface IN CROSSING ORDER is corrected (too many iterations: the first clear bit + 1; too few:
+    # n + 1), nothing behind it is touched; rows that hold are returned unchanged
+    from aadff.strict_stack import check_counts
+    true = np.array([0x3ff, 0b0111, 0b01111, 0b011], dtype=np.uint32)          # counts 10, 4, 5, 3
+    cur = np.ones(4, dtype=bool)
+    seen = lambda pred: true & ((np.uint32(1) << np.asarray(pred).astype(np.uint32)) - np.uint32(1))
+    for pred, want_ok, want_fix in (([10, 4, 5, 3], True, [10, 4, 5, 3]), ([9, 4, 5, 3], False, [10, 4, 5, 3]), ([10, 6, 5, 3], False, [10, 4, 5, 3]),
+                                    ([10, 3, 5, 3], False, [10, 4, 5, 3]), ([10, 4, 4, 4], False, [10, 4, 5, 4])):
+        ok, fix = check_counts(seen(pred)[None], np.array([pred]), cur, range(4))
+        assert ok.tolist() == [want_ok] and fix.tolist() == [want_fix], (pred, ok, fix)
+    ok, fix = check_counts(seen([10, 4, 4, 4])[None], np.array([[10, 4, 4, 4]]), cur, [3, 2, 1, 0])      # backward trace: surface 3 comes first
+    assert ok.tolist() == [False] and fix.tolist() == [[10, 4, 4, 3]]
+    both = np.array([[[10, 4, 4, 4], [10, 4, 5, 3]]])                                                    # [batch, phase, surface]
+    ok, fix = check_counts(np.stack([seen(both[0, 0]), seen(both[0, 1])])[None], both, cur, range(4))
+    assert ok.tolist() == [[False, True]] and fix.tolist() == [[[10, 4, 5, 4], [10, 4, 5, 3]]]

@@ -27,11 +27,19 @@ depth = synth_depth_mm(H, W, seed=5678)
 dbar, fds = -float(depth.mean()), [float(f) for f in -np.linspace(depth.min(), depth.max(), S)]
 lens = Lensgroup(os.path.join(REPO, "lenses", "rf50mm", "lens.json"), sensor_res=(H, W), device="cuda:0", parity="strict")
 ts = []
-for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
+render = "--render" in sys.argv                       # the whole stack (PSF maps + convolution) through render_focal_stack_m1
+if render:
+    from aadff.focal_stack import render_focal_stack_m1
+    from aadff.synth import synth_rgb
+    img = torch.from_numpy(synth_rgb(H, W, seed=1234))[None].to("cuda:0")
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 6):
     torch.manual_seed(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    strict_stack.strict_psf_maps(lens, dbar, fds, 11, 11, 2048)
+    if render:
+        render_focal_stack_m1(lens, img, dbar, fds, 11, 11, 2048)
+    else:
+        strict_stack.strict_psf_maps(lens, dbar, fds, 11, 11, 2048)
     torch.cuda.synchronize()
     ts.append(time.perf_counter() - t0)
 print("strict stack: seconds per stack", [round(t, 4) for t in ts])
