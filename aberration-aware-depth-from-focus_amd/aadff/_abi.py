@@ -134,11 +134,19 @@ def load_library(path=None):
     return lib
 
 
+_gpu_ok = False
+
+
 def require_gpu():
+    global _gpu_ok
+    if _gpu_ok:                                       # (torch.cuda.is_available() re-reads the environment on every call: 2.5 us)
+        return _lib if _lib is not None else load_library()
     if not torch.cuda.is_available():
         raise RuntimeError("aadff: no HIP device visible. This package runs its hot path on MI355X only; "
                            "there is no CPU fallback (the CPU restatement under oracle/ is test infrastructure).")
-    return load_library()
+    lib = load_library()
+    _gpu_ok = True
+    return lib
 
 
 def call(name, *args):
@@ -150,6 +158,23 @@ def call(name, *args):
         if rc == -1 and ("should be" in msg or "Input image" in msg):
             raise AssertionError(msg)     # the reference raises AssertionError for these (render_psf.py:43-53)
         raise RuntimeError(f"{name} failed (rc={rc}): {msg}")
+
+
+class on_device:
+    """`with torch.cuda.device(dev)` that does nothing when dev already is the current device (the context manager costs 5-8 us per
+    entry, three entries per slice of the per-call API)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        self.ctx = None if dev.index is None or dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*a)
 
 
 def ptr(t):

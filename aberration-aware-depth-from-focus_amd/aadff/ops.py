@@ -181,6 +181,33 @@ def psf_points(points: torch.Tensor, surf_main: torch.Tensor, surf_chief: torch.
     return out
 
 
+@custom_op("aadff::psf_points_block", mutates_args=("flags",), device_types="cuda")
+def psf_points_block(points: torch.Tensor, surf_main: torch.Tensor, surf_chief: torch.Tensor, lens_const: List[float], states: torch.Tensor,
+                     u_block: torch.Tensor, n_wave: int, spp: int, spp_chief: int, ks: int, map_layout: bool, flags: torch.Tensor) -> torch.Tensor:
+    """psf_points for ONE focus state with the uniforms as the flat block the host generator produced, in the reference's draw order
+    (SURVEY.md Appendix B): per wavelength [main theta spp | main r spp | chief theta spp_chief | chief r spp_chief]; spp_chief = 0:
+    no chief rays (center=False).  points [N,3] -> [N,L,ks,ks] or, with map_layout, [L,g*ks,g*ks].  No re-layout copy: the kernel
+    takes the rows through strides."""
+    N, L = points.shape[0], n_wave
+    per_l = 2 * spp + 2 * spp_chief
+    lc = lens_const_from_list(lens_const)
+    g = int(round(N ** 0.5))
+    out = torch.empty((L, g * ks, g * ks) if map_layout else (N, L, ks, ks), dtype=torch.float32, device=points.device)
+    base = u_block.data_ptr()
+    with torch.cuda.device(points.device):
+        _abi.call("aadff_psf_points", _abi.ptr(points), 1, N, L, _abi.ptr(surf_main), _abi.ptr(surf_chief), lc, _abi.ptr(states),
+                  C.c_void_p(base), spp, L * per_l, per_l, C.c_void_p(base + 8 * spp) if spp_chief else None, spp_chief, L * per_l, per_l, ks,
+                  int(spp_chief > 0), int(map_layout), _abi.ptr(out), None, _abi.ptr(flags), _st(points))
+    return out
+
+
+@psf_points_block.register_fake
+def _(points, surf_main, surf_chief, lens_const, states, u_block, n_wave, spp, spp_chief, ks, map_layout, flags):
+    N = points.shape[0]
+    g = int(round(N ** 0.5))
+    return points.new_empty((n_wave, g * ks, g * ks) if map_layout else (N, n_wave, ks, ks), dtype=torch.float32)
+
+
 @psf_points.register_fake
 def _(points, surf_main, surf_chief, lens_const, states, u_main, u_chief, ks, centre, map_layout, flags):
     S, N, L = points.shape[0], points.shape[1], u_main.shape[1]

@@ -12,6 +12,7 @@ reference's call order so results are comparable sample f
 """
 import ctypes as C
 import json
+import os
 import logging
 import random                    # noqa: F401  (the next five names ride the star-import chain the reference scripts rely on:
 from datetime import datetime    # noqa: F401   `from deeplens.psfnet import *` must provide torch, nn, np, plt, tqdm,
@@ -58,6 +59,37 @@ from .utils import *             # noqa: F401,F403
 from .utils import make_grid, save_image   # noqa: F401
 
 
+class _CallRing:
+    """Pinned host blocks and their device twins for the per-call API (refocus / psf / psf_rgb / psf_map): the host draws of a call go
+    into the next pinned block (one fast MT19937 fill instead of a torch.rand per row), one asynchronous copy takes them to the GPU
+    and the kernel reads the rows through strides - no per-row tensors, no `.to(device)` staging copies, no synchronisation.  A block
+    is handed out again only after the launch that last used it has completed (an event per block, recorded behind the launch)."""
+    SLOTS = 16
+
+    def __init__(self, dev, words):
+        self.words = int(words)
+        self.host = torch.empty((self.SLOTS, self.words), dtype=torch.float32, pin_memory=True)
+        self.dev = torch.empty((self.SLOTS, self.words), dtype=torch.float32, device=dev)
+        self.events = [torch.cuda.Event() for _ in range(self.SLOTS)]
+        self.used = [False] * self.SLOTS
+        self.turn = 0
+
+    def next(self):
+        k = self.turn % self.SLOTS
+        self.turn += 1
+        if self.used[k]:
+            self.events[k].synchronize()
+        return k, self.host[k], self.dev[k]
+
+    def sent(self, k, n, stream):
+        """queue the upload of the first n words of block k"""
+        self.dev[k, :n].copy_(self.host[k, :n], non_blocking=True)
+
+    def launched(self, k, stream):
+        self.events[k].record(stream)
+        self.used[k] = True
+
+
 def raise_psf_flags(bits):
     """Flags word of aadff_psf_points -> the reference's errors (bit 0: NaN in a Newton residual, surfaces.py:555-558;
     bit 2: a focus state without a positive sensor position, i.e. a refocus that found no valid ray, optics.py:1176;
@@ -91,6 +123,10 @@ class Lensgroup(DeepObj):
         self._state_dev = None
         self._state_host = _abi.LensState()
         self._state_stale = False
+        self._ring = None
+        self._flags_mirror = None
+        self._psf_calls = 0
+        self.sync_flags = os.environ.get("AADFF_SYNC_FLAGS", "0") == "1"      # True: every psf call waits for its flags (the round-4 behaviour)
         self.surfaces, self.materials = [], []
         self.sensor_res = sensor_res
         if filename is not None:
@@ -181,12 +217,21 @@ class Lensgroup(DeepObj):
         return self.device
 
     def _state_device(self):
-        """Device copy of the lens state, uploading pending host edits."""
+        """Device copy of the lens state, uploading pending host edits.  The kernels' error-flags word lives in the 8 bytes behind it
+        (`_flags_device`), so one read-back returns both."""
         dev = self._gpu()
         if self._state_dev is None or self._state_dev.device != dev:
-            self._state_dev = torch.empty(C.sizeof(_abi.LensState), dtype=torch.uint8, device=dev)
+            n = C.sizeof(_abi.LensState)
+            self._state_buf = torch.zeros(n + 8, dtype=torch.uint8, device=dev)
+            self._state_dev = self._state_buf[:n]
+            self._flags_dev = self._state_buf[n:n + 4].view(torch.int32)
             self._state_upload()
         return self._state_dev
+
+    def _flags_device(self):
+        """int32 view of the flags word the PSF kernels OR into (bits: raise_psf_flags)."""
+        self._state_device()
+        return self._flags_dev
 
     def _state_upload(self):
         host = torch.frombuffer(bytearray(bytes(self._state_host)), dtype=torch.uint8)
@@ -194,15 +239,44 @@ class Lensgroup(DeepObj):
         self._state_stale = False
 
     def _state_sync(self):
-        """Host view of the state; reads the device copy back if a kernel rewrote it."""
+        """Host view of the state; reads the device copy back if a kernel rewrote it - and with it the flags word of the PSF calls
+        since the last read-back: their errors (the reference asserts inside the call, optics.py:901,1176; here the calls are
+        asynchronous) are raised at this, the next host read-back, with the reference's exception types."""
         if self._state_stale and self._state_dev is not None:
-            raw = bytes(self._state_dev.cpu().numpy().tobytes())
-            self._state_host = _abi.LensState.from_buffer_copy(raw)
+            raw = bytes(self._state_buf.cpu().numpy().tobytes())
+            n = C.sizeof(_abi.LensState)
+            self._state_host = _abi.LensState.from_buffer_copy(raw[:n])
             self._state_stale = False
-            if self._state_host.flags & 1:
+            bits = int.from_bytes(raw[n:n + 4], "little", signed=True)
+            if bits:
+                self._flags_clear()
+            if self._state_host.flags & 1 or bits & 1:
                 raise FloatingPointError("found nan in ft in non-diff newton method.")   # reference exits: surfaces.py:555-558
             assert self._state_host.d_sensor > 0, "sensor position is negative."          # optics.py:1176
+            raise_psf_flags(bits)
         return self._state_host
+
+    def _flags_clear(self):
+        self._flags_device().zero_()
+        if self._flags_mirror is not None:
+            self._flags_mirror[0] = 0
+
+    def check_flags(self):
+        """Raise the reference's errors for anything the kernels of earlier calls flagged (synchronises).  The per-call API is
+        asynchronous: `psf_map` / `psf` / `refocus` return without waiting, their error conditions surface at the next host
+        read-back (`d_sensor`, `hfov`, ...), at a later call through the pinned mirror of the flags word (published every 8 PSF
+        calls), or here.  `lens.sync_flags = True` (or AADFF_SYNC_FLAGS=1) restores the check inside every call."""
+        if self._state_dev is None:
+            return
+        self._state_stale = True
+        self._state_sync()
+
+    def _poll_flags(self):
+        """Flags as of the last published mirror: no synchronisation, the error reaches the host a few calls late instead of never."""
+        if self._flags_mirror is not None and int(self._flags_mirror[0]):
+            bits = int(self._flags_mirror[0])
+            self._flags_clear()
+            raise_psf_flags(bits)
 
     def _state_set(self, name, value):
         self._state_sync()
@@ -224,6 +298,10 @@ class Lensgroup(DeepObj):
         return self._table_cache[key]
 
     def _lens_const(self):
+        key = (tuple(self.sensor_res), float(self.pixel_size), float(self.r_last))
+        hit = self._table_cache.get("lens-const")
+        if hit is not None and hit[0] == key:
+            return hit[1]
         enp_z, enp_r = self.entrance_pupil()
         exp_z, exp_r = self.exit_pupil()
         lc = _abi.LensConst()
@@ -236,6 +314,7 @@ class Lensgroup(DeepObj):
         lc.exp_z, lc.exp_r_shrunk = exp_z, exp_r * 0.5
         lc.first_d = self.surfaces[0].d.item()
         lc.first_r2 = self.surfaces[0].r ** 2
+        self._table_cache["lens-const"] = (key, lc)
         return lc
 
     # ------------------------------------------------------------------ derived quantities
@@ -268,12 +347,29 @@ class Lensgroup(DeepObj):
         if self.parity == "strict":
             return self._refocus_strict(depth)
         st, lc = self._state_device(), self._lens_const()
-        u = torch.stack((self.sampler.rand(GEO_SPP), self.sampler.rand(GEO_SPP))).to(st.device)
-        dep = torch.tensor([float(depth)], dtype=torch.float32).to(st.device)
-        with torch.cuda.device(st.device):
-            _abi.call("aadff_refocus", _abi.ptr(dep), 1, _abi.ptr(u), GEO_SPP, 2 * GEO_SPP, _abi.ptr(self._table([DEFAULT_WAVE])),
-                      lc, _abi.ptr(st), _abi.stream_ptr(st.device))
+        with _abi.on_device(st.device):
+            stream = torch.cuda.current_stream(st.device)
+            if self.sampler.on_device:
+                u = torch.stack((self.sampler.rand(GEO_SPP), self.sampler.rand(GEO_SPP))).to(st.device)
+                dep = torch.tensor([float(depth)], dtype=torch.float32).to(st.device)
+                _abi.call("aadff_refocus", _abi.ptr(dep), 1, _abi.ptr(u), GEO_SPP, 2 * GEO_SPP, _abi.ptr(self._table([DEFAULT_WAVE])),
+                          lc, _abi.ptr(st), C.c_void_p(stream.cuda_stream))
+            else:
+                # host draws (theta row, r row: the reference's two torch.rand calls) + the depth in one pinned block, one async copy
+                ring = self._call_ring(st.device, 2 * GEO_SPP + 4)
+                k, h, d = ring.next()
+                self.sampler.rand_into(h[:2 * GEO_SPP])
+                h[2 * GEO_SPP] = float(depth)
+                ring.sent(k, 2 * GEO_SPP + 4, stream)
+                _abi.call("aadff_refocus", C.c_void_p(d.data_ptr() + 8 * GEO_SPP), 1, C.c_void_p(d.data_ptr()), GEO_SPP, 2 * GEO_SPP,
+                          _abi.ptr(self._table([DEFAULT_WAVE])), lc, _abi.ptr(st), C.c_void_p(stream.cuda_stream))
+                ring.launched(k, stream)
         self._state_stale = True
+
+    def _call_ring(self, dev, words):
+        if self._ring is None or self._ring.words < words or self._ring.dev.device != dev:
+            self._ring = _CallRing(dev, max(words, 3 * (2 * GEO_SPP + 2 * GEO_SPP) + 3 * 128 * 3))
+        return self._ring
 
     def _refocus_strict(self, depth):
         """The reference's refocus line by line (optics.py:1155-1180): host sampling and host reductions are the
@@ -471,25 +567,60 @@ class Lensgroup(DeepObj):
     def _psf_launch(self, points, wvlns, ks, spp, center, map_layout):
         """One fused launch (trace chief + main rays, splat, normalise) for len(wvlns)
         wavelengths.  Host RNG order per wavelength: main theta, main r, chief theta,
-        chief r."""
+        chief r.  Asynchronous: the kernels' error conditions (`raise_psf_flags`) are raised at the next
+        host read-back of the lens state, at `check_flags()`, or a few calls later through the pinned mirror of the flags word
+        (`sync_flags` restores the wait inside the call)."""
         dev = self._gpu()
         L, N = len(wvlns), points.shape[0]
-        mains, chiefs = [], []
-        for _ in wvlns:
-            mains += [self.sampler.rand(spp), self.sampler.rand(spp)]
-            if center:
-                chiefs += [self.sampler.rand(GEO_SPP), self.sampler.rand(GEO_SPP)]
-        u_main = torch.stack(mains).to(dev)
-        u_chief = torch.stack(chiefs).to(dev) if center else None
-        pts = _abi.f32c(points, dev)
-        flags = torch.zeros(1, dtype=torch.int32, device=dev)
         from aadff import ops
-        um = u_main.reshape(1, L, 2, spp)
-        uc = u_chief.reshape(1, L, 2, GEO_SPP) if center else torch.empty((1, L, 2, 0), device=dev)
-        out = torch.ops.aadff.psf_points(pts.unsqueeze(0), self._table(wvlns), self._table([DEFAULT_WAVE]), ops.lens_const_to_list(self._lens_const()),
-                                         self._state_device(), um, uc, ks, bool(center), bool(map_layout), flags)[0]
-        if getattr(self, "check_flags", True):
-            raise_psf_flags(int(flags.item()))          # the reference asserts inside psf_center (optics.py:901): same sync point
+        self._poll_flags()
+        flags = self._flags_device()
+        lcl = self._table_cache.get("lens-const-list")
+        if lcl is None or lcl[0] != (tuple(self.sensor_res), float(self.pixel_size)):
+            lcl = self._table_cache["lens-const-list"] = ((tuple(self.sensor_res), float(self.pixel_size)), ops.lens_const_to_list(self._lens_const()))
+        with _abi.on_device(dev):
+            stream = torch.cuda.current_stream(dev)
+            if self.sampler.on_device:
+                mains, chiefs = [], []
+                for _ in wvlns:
+                    mains += [self.sampler.rand(spp), self.sampler.rand(spp)]
+                    if center:
+                        chiefs += [self.sampler.rand(GEO_SPP), self.sampler.rand(GEO_SPP)]
+                u_main = torch.stack(mains).to(dev)
+                u_chief = torch.stack(chiefs).to(dev) if center else None
+                pts = _abi.f32c(points, dev)
+                um = u_main.reshape(1, L, 2, spp)
+                uc = u_chief.reshape(1, L, 2, GEO_SPP) if center else torch.empty((1, L, 2, 0), device=dev)
+                out = torch.ops.aadff.psf_points(pts.unsqueeze(0), self._table(wvlns), self._table([DEFAULT_WAVE]), lcl[1],
+                                                 self._state_device(), um, uc, ks, bool(center), bool(map_layout), flags)[0]
+            else:
+                spc = GEO_SPP if center else 0
+                n_u = L * (2 * spp + 2 * spc)
+                ring = self._call_ring(dev, n_u + 3 * N)
+                k, h, d = ring.next()
+                self.sampler.rand_into(h[:n_u])              # one fill = the reference's 4 L torch.rand calls, same generator stream
+                h[n_u:n_u + 3 * N].view(N, 3).copy_(points)
+                ring.sent(k, n_u + 3 * N, stream)
+                if torch.compiler.is_compiling():
+                    out = torch.ops.aadff.psf_points_block(d[n_u:n_u + 3 * N].view(N, 3), self._table(wvlns), self._table([DEFAULT_WAVE]), lcl[1],
+                                                           self._state_device(), d[:n_u], L, spp, spc, ks, bool(map_layout), flags)
+                else:       # the same launch without the custom-op dispatcher (~35 us of Python per call: as much as the rest of the call)
+                    g = int(round(N ** 0.5))
+                    out = torch.empty((L, g * ks, g * ks) if map_layout else (N, L, ks, ks), dtype=torch.float32, device=dev)
+                    per_l, base = 2 * spp + 2 * spc, d.data_ptr()
+                    _abi.call("aadff_psf_points", C.c_void_p(base + 4 * n_u), 1, N, L, _abi.ptr(self._table(wvlns)), _abi.ptr(self._table([DEFAULT_WAVE])),
+                              self._lens_const(), _abi.ptr(self._state_device()), C.c_void_p(base), spp, L * per_l, per_l,
+                              C.c_void_p(base + 8 * spp) if spc else None, spc, L * per_l, per_l, ks, int(spc > 0), int(map_layout), _abi.ptr(out), None,
+                              _abi.ptr(flags), C.c_void_p(stream.cuda_stream))
+                ring.launched(k, stream)
+            self._psf_calls += 1
+            if self.sync_flags:
+                self._state_stale = True
+                self._state_sync()
+            elif self._psf_calls % 8 == 0:
+                if self._flags_mirror is None:
+                    self._flags_mirror = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+                _abi.call("aadff_publish_flags", _abi.ptr(flags), C.c_void_p(self._flags_mirror.data_ptr()), C.c_void_p(stream.cuda_stream))
         return out.to(self.device) if self.device.type != "cuda" else out
 
     def psf(self, points, ks=31, wvln=DEFAULT_WAVE, spp=GEO_SPP, center=True):
@@ -545,7 +676,12 @@ class Lensgroup(DeepObj):
         = +y (reference: optics.py:1006-1026)."""
         if ks > _abi.MAX_KS:
             raise ValueError(f"ks={ks} exceeds the kernels' limit {_abi.MAX_KS}")
-        pts = self.point_source_grid(depth=depth, grid=grid, quater=False).reshape(-1, 3)
+        cache = self._table_cache.setdefault("psf-map-points", {})          # the field grid of (depth, grid): a handful of torch ops per call
+        pts = cache.get((float(depth), int(grid)))
+        if pts is None:
+            if len(cache) >= 64:
+                cache.clear()
+            pts = cache[(float(depth), int(grid))] = self.point_source_grid(depth=depth, grid=grid, quater=False).reshape(-1, 3).float().contiguous()
         if self.parity == "strict":
             return make_grid(self.psf_rgb(pts, ks=ks, spp=spp, center=center), nrow=grid, padding=0)
         return self._psf_launch(pts, WAVE_RGB, ks, spp, center, True)

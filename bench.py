@@ -307,6 +307,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "latency_ms_p50": round(float(np.median(lat)) * 1e3, 4),
+            # SURVEY.md 8(d)'s metric as defined there: S x H x W / (first host call -> device idle, one stack, median of 20)
+            "value_survey_8d": round(S * H * W / 1e6 / float(np.median(lat)), 2),
             "latency_ms_p50_render_call_only": round(float(np.median(lat_render)) * 1e3, 4) if lat_render else None,
             "streams": n_streams,
             "one_stream": {"ms_per_step": round(one_stream_ms, 4), "value": round(S * H * W / 1e6 / (one_stream_ms * 1e-3), 2), "steps": n_one,
@@ -350,6 +352,22 @@ def main():
                       "valu_busy": valu, "valu_busy_source": valu_source},
             "flags": bits,
         }
+        if world == 1:
+            # the reference's OWN loops through the drop-in API (no StackPlan / StackPipeline): what a reference script gets
+            try:
+                sys.path.insert(0, os.path.join(REPO, "tools"))
+                import dropin_bench
+                from aadff.synth import mlp_state_dict as _msd, synth_depth_mm as _sdm
+                from deeplens.psfnet import PSFNet as _PSFNet
+                _net = _PSFNet(lens_path, sensor_res=(H, W), kernel_size=KS, device=dev)
+                _net.psfnet.load_state_dict({k: torch.from_numpy(v) for k, v in _msd(seed=4321).items()})
+                _dm = (torch.from_numpy(_sdm(H, W, seed=5678))[None, None] / 1e3).to(dev)
+                torch.manual_seed(0)
+                res["dropin_api"] = dropin_bench.measure(Lensgroup(lens_path, sensor_res=(H, W), device=dev), img, dbar, fds, GRID, KS, SPP,
+                                                         reps=20, psfnet=_net, depth_map=_dm)
+                del _net, _dm
+            except Exception as e:
+                res["dropin_api"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"], want = cpu_baseline(lens_path, img_h, dbar, fds)
             n = len(want)
@@ -380,15 +398,34 @@ def main():
                 n_strict = max(20, min(args.steps, 50))
                 stats0 = dict(_ss.StrictCounts.of(ls).stats)
                 import gc
+                # every host array of this mode is small (<= 20 k elements per op): one CPU thread.  With the 16-thread OpenMP pool the
+                # cpu_baseline leg left behind, each op that crosses ATen's grain size wakes 16 spinning workers and the process runs
+                # into its cgroup CPU quota: a 30-40 ms stall every 100 ms scheduler period was measured
+                torch.set_num_threads(1)
                 gc.collect()
                 gc.freeze()                                      # the bench's long-lived objects out of the collector's way: a full collection
                 t_s = time.perf_counter()                        # over them cost 50-90 ms every ~10 steps of this leg
+                marks_s = [t_s]
+                _pr = None
+                if os.environ.get("AADFF_BENCH_PROFILE") == "strict":
+                    import cProfile
+                    _pr = cProfile.Profile()
+                    _pr.enable()
                 for _ in range(n_strict):                        # new draws every step: the generator runs on, as in the reference's loop
                     so = _rfs(ls, img, dbar, fds, GRID, KS, SPP)
+                    marks_s.append(time.perf_counter())
                     if os.environ.get("AADFF_STRICT_TIMING") == "1":
                         torch.cuda.synchronize(dev)
                         print("bench: strict step", round((time.perf_counter() - t_s) * 1e3, 2), getattr(ls, "_strict_timing", None), file=sys.stderr, flush=True)
                 torch.cuda.synchronize(dev)
+                if os.environ.get("AADFF_BENCH_PROFILE") == "strict-steps":
+                    ms = torch.cuda.memory_stats(dev)
+                    print("bench: strict step times [ms]", [round(v * 1e3, 1) for v in np.diff(marks_s)], "device mallocs", ms.get("num_device_alloc"),
+                          "frees", ms.get("num_device_free"), "retries", ms.get("num_alloc_retries"), file=sys.stderr, flush=True)
+                if _pr is not None:
+                    import pstats
+                    _pr.disable()
+                    pstats.Stats(_pr, stream=sys.stderr).sort_stats("tottime").print_stats(18)
                 t_s = (time.perf_counter() - t_s) / n_strict
                 stats1 = _ss.StrictCounts.of(ls).stats
                 if os.environ.get("AADFF_STRICT_TIMING") == "1":
@@ -397,6 +434,8 @@ def main():
                                                 "rel_l2_per_slice": [float(f"{v:.3e}") for v in per2], "worst_slice": float(f"{max(per2):.3e}"),
                                                 "tolerance_per_slice": 1e-4,
                                                 "timed": {"steps": n_strict, "ms_per_step": round(t_s * 1e3, 3), "value": round(S * H * W / 1e6 / t_s, 1),
+                                                          "ms_per_step_p50": round(float(np.median(np.diff(marks_s))) * 1e3, 3),
+                                                          "ms_per_step_max": round(float(np.max(np.diff(marks_s))) * 1e3, 3),
                                                           "unit": "MP/s", "what": "render_focal_stack_m1 through the strict lens, one stack at a time "
                                                           "(host call to device idle), fresh draws every step",
                                                           "speculation": {k: stats1[k] - stats0[k] for k in stats1}},

@@ -671,13 +671,36 @@ def test_conic_and_hyperbolic_aspheres_vs_oracle(repo_root, tmp_path, variant):
 
 def test_no_valid_chief_ray_raises_like_the_reference(repo_root):
     """A point far outside the field loses every chief ray: the reference asserts "No sampled rays is valid."
-    (optics.py:901); the kernels flag it and the Python mirror raises the same AssertionError."""
+    (optics.py:901); the kernels flag it and the Python mirror raises the same AssertionError - round 5: DEFERRED, the per-call API
+    no longer waits for the GPU inside psf / psf_map (`flags.item()` per call made the reference's own loop host-bound): the error
+    is raised (a) by `check_flags()`, (b) at the next host read-back of the lens state, (c) a few calls later through the pinned
+    mirror of the flags word, without any synchronisation; `sync_flags = True` keeps the round-4 behaviour (raise inside the call)."""
+    bad, good = torch.tensor([[40.0, 40.0, -300.0]]), torch.tensor([[0.1, 0.1, -1500.0]])
     lens = Lensgroup(lens_path(repo_root), sensor_res=(256, 256), device=DEV)
     torch.manual_seed(0)
+    lens.psf(bad, ks=11, spp=256)                                           # returns: asynchronous
     with pytest.raises(AssertionError, match="No sampled rays is valid"):
-        lens.psf(torch.tensor([[40.0, 40.0, -300.0]]), ks=11, spp=256)
+        lens.check_flags()                                                  # (a)
+    lens.check_flags()                                                      # consumed
     torch.manual_seed(0)
-    assert lens.psf(torch.tensor([[0.1, 0.1, -1500.0]]), ks=11, spp=256).shape == (1, 11, 11)      # the lens is still usable
+    assert lens.psf(good, ks=11, spp=256).shape == (1, 11, 11)              # the lens is still usable
+    lens.psf(bad, ks=11, spp=256)
+    lens.refocus(-1500.0)
+    with pytest.raises(AssertionError, match="No sampled rays is valid"):
+        lens.d_sensor                                                       # (b) the read-back that follows a refocus
+    assert lens.d_sensor > 0                                                # the state itself is fine
+    lens.psf(bad, ks=11, spp=256)
+    with pytest.raises(AssertionError, match="No sampled rays is valid"):   # (c) never read back, never checked: the mirror catches up
+        for _ in range(40):
+            lens.psf(good, ks=11, spp=256)
+            torch.cuda.synchronize()                                        # (only to make the test deterministic: the publish launch has run)
+    lens.check_flags()
+    lens.sync_flags = True
+    torch.manual_seed(0)
+    with pytest.raises(AssertionError, match="No sampled rays is valid"):
+        lens.psf(bad, ks=11, spp=256)
+    torch.manual_seed(0)
+    assert lens.psf(good, ks=11, spp=256).shape == (1, 11, 11)
 
 
 def test_psf_rgb_layout_matches_psf_map(repo_root):
