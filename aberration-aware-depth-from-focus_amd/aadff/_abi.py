@@ -69,6 +69,7 @@ PROTOTYPES = {
     "aadff_render_psf_map": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "aadff_render_psf_map_stack": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "aadff_render_psf_map_stack_strided": [_P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P],
+    "aadff_render_psf_map_stack_layered": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "aadff_time_next_launch": [_P, _P],
     "aadff_render_psf": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "aadff_local_psf_render": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

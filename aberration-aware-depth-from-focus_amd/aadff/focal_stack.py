@@ -413,54 +413,65 @@ def depth_layers(depth_mm, layers):
 
 
 @torch.no_grad()
-def render_focal_stack_m1_layered(lens, img, depth_mm, focus_mm, layers=4, grid=11, ks=11, spp=GEO_SPP):
+def render_focal_stack_m1_layered(lens, img, depth_mm, focus_mm, layers=4, grid=11, ks=11, spp=GEO_SPP, fused=True, return_parts=False):
     """RGB-D aware grid rendering ("M1-layered"): the depth map is quantised into `layers`
     planes; for every focus distance and layer one PSF map is ray traced and the slice is the per-pixel
     selection  out[s] = sum_l [layer == l] * render_psf_map(img, psf_map[s, l]).
     Composes reference primitives only (refocus, psf_map, render_psf_map).  Host-RNG order: per focus
     distance the refocus draws, then the psf_map draws of layer 0, 1, ...   img [B,C,H,W], depth_mm
-    [B,1,H,W] (mm, < 0), focus_mm [S] (mm, < 0) -> [B,C,S,H,W]."""
+    [B,1,H,W] (mm, < 0), focus_mm [S] (mm, < 0) -> [B,C,S,H,W].
+    Round 5: three launches - refocus, ONE PSF-grid launch for all S x L (slice, layer) pairs, and (ks 11) a stack convolution that
+    takes the layer-index map and writes [B,C,S,H,W] directly (`aadff_render_psf_map_stack_layered`); `fused=False` (and other ks)
+    renders the S x L candidate slices and gathers, L x the output bytes."""
     focus = [float(f) for f in np.asarray(focus_mm, dtype=np.float64).reshape(-1)]
     S, L = len(focus), int(layers)
     B, C_, H, W = img.shape
     assert tuple(lens.sensor_res) == (H, W), "lens.sensor_res must match the image"
+    assert 1 <= L <= 254, "1..254 depth layers"
     dev = lens._gpu()
     x = _abi.f32c(img, dev)
     idx, centres = depth_layers(_abi.f32c(depth_mm, dev), L)
-    centres_h = centres.cpu().tolist()
     N, nb = grid * grid, C.sizeof(_abi.LensState)
     per, o_main, o_chief, per_l = stack_uniform_layout(spp)              # per-layer block = per - 2*GEO_SPP
     layer_block = per - o_main
-    u = lens.sampler.rand_block([S * (o_main + L * layer_block)]).to(dev)
+    slice_stride = o_main + L * layer_block
+    u = lens.sampler.rand_block([S * slice_stride]).to(dev)
     states = torch.zeros(S * nb, dtype=torch.uint8, device=dev)
     dep = torch.tensor(focus, dtype=torch.float32, device=dev)
     maps = torch.empty((S * L, 3, grid * ks, grid * ks), dtype=torch.float32, device=dev)
     flags = torch.zeros(1, dtype=torch.int32, device=dev)
-    pts = lens.point_source_grid(depth=0.0, grid=grid).reshape(-1, 3).unsqueeze(0).repeat(L, 1, 1)
-    for l in range(L):
-        pts[l, :, 2] = centres_h[l]
-    pts = pts.contiguous().to(dev)
+    # field points of the (slice, layer) pairs, built on the device (no read-back of the layer centres): the grid at z = centre[l]
+    pts = lens.point_source_grid(depth=0.0, grid=grid).reshape(1, -1, 3).to(dev).repeat(L, 1, 1)
+    pts[:, :, 2] = centres.to(torch.float32).reshape(L, 1)
+    pts = pts.repeat(S, 1, 1).contiguous()                               # [S*L, N, 3], pair p = s * L + l
     tab_rgb, tab_green, lc = lens._table(WAVE_RGB), lens._table([DEFAULT_WAVE]), lens._lens_const()
-    slice_stride = o_main + L * layer_block
     with torch.cuda.device(dev):
         st = _abi.stream_ptr(dev)
-        ub = u.data_ptr()
-        _abi.call("aadff_refocus", _abi.ptr(dep), S, C.c_void_p(ub), GEO_SPP, slice_stride, _abi.ptr(tab_green), lc,
+        _abi.call("aadff_refocus", _abi.ptr(dep), S, C.c_void_p(u.data_ptr()), GEO_SPP, slice_stride, _abi.ptr(tab_green), lc,
                   _abi.ptr(states), st)
-        for s in range(S):
-            st_rep = states[s * nb:(s + 1) * nb].repeat(L)                # the L layers share focus state s
-            base = ub + 4 * (s * slice_stride + o_main)
-            _abi.call("aadff_psf_points", _abi.ptr(pts), L, N, 3, _abi.ptr(tab_rgb), _abi.ptr(tab_green), lc,
-                      _abi.ptr(st_rep), C.c_void_p(base), spp, layer_block, per_l,
-                      C.c_void_p(base + 4 * 2 * spp), GEO_SPP, layer_block, per_l, ks, 1, 1,
-                      _abi.ptr(maps[s * L:(s + 1) * L]), None, _abi.ptr(flags), st)
-        tmp = torch.empty((B, C_, S * L, H, W), dtype=torch.float32, device=dev)
-        _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(maps), _abi.ptr(tmp), B, C_, S * L, H, W, grid,
-                  ks, st)
-    sel = idx.reshape(B, 1, 1, 1, H, W).expand(B, C_, S, 1, H, W)
-    out = torch.gather(tmp.view(B, C_, S, L, H, W), 3, sel).squeeze(3)
+        # ONE PSF launch for all S x L pairs: pair p takes focus state p // L (the states repeated L times) and its own block of
+        # draws - the per-slice blocks minus the refocus draws are [S, L * layer_block] = [S * L, layer_block] once made contiguous
+        st_rep = states.view(S, nb).repeat_interleave(L, 0).contiguous()
+        u_pairs = u.view(S, slice_stride)[:, o_main:].contiguous()
+        base = u_pairs.data_ptr()
+        _abi.call("aadff_psf_points", _abi.ptr(pts), S * L, N, 3, _abi.ptr(tab_rgb), _abi.ptr(tab_green), lc, _abi.ptr(st_rep),
+                  C.c_void_p(base), spp, layer_block, per_l, C.c_void_p(base + 4 * 2 * spp), GEO_SPP, layer_block, per_l, ks, 1, 1,
+                  _abi.ptr(maps), None, _abi.ptr(flags), st)
+        if ks == 11 and fused:
+            # the L candidates of a pixel are computed from one staged band and only the pixel's own layer is written: 1 x the output
+            lidx = idx.reshape(B, H, W).to(torch.uint8).contiguous()
+            out = torch.empty((B, C_, S, H, W), dtype=torch.float32, device=dev)
+            _abi.call("aadff_render_psf_map_stack_layered", _abi.ptr(x), _abi.ptr(maps), _abi.ptr(lidx), _abi.ptr(out), B, C_, S, L, H, W, grid, ks, st)
+        else:
+            tmp = torch.empty((B, C_, S * L, H, W), dtype=torch.float32, device=dev)
+            _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(maps), _abi.ptr(tmp), B, C_, S * L, H, W, grid, ks, st)
+            sel = idx.reshape(B, 1, 1, 1, H, W).expand(B, C_, S, 1, H, W)
+            out = torch.gather(tmp.view(B, C_, S, L, H, W), 3, sel).squeeze(3)
     lens._state_device().copy_(states[(S - 1) * nb:S * nb])
     lens._state_stale = True
+    lens._m1l_flags = flags                                               # raise_psf_flags(int(flags.item())) is the caller's (synchronising) check
+    if return_parts:                                                      # (stack, PSF maps [S*L,3,g*ks,g*ks], layer index [B,H,W] uint8)
+        return out, maps, idx.reshape(B, H, W).to(torch.uint8).contiguous()
     return out
 
 

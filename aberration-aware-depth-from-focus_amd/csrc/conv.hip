@@ -510,10 +510,14 @@ __device__ __forceinline__ void lds_read16(uint2v& a, uint2v& b, unsigned byte_a
 // ONE round (round 2: 104 VGPRs, 5 per CU, 172 workgroups in a second round that ended 12 us after the first).  What made 96
 // possible without spilling in the loop: two operand buffers instead of three.  Forms measured and dropped in round 3 (three
 // accumulators per row pair, DPP operand sharing, 32/48-row bands, two row groups per chunk): DESIGN.md 4.1; git history has them.
-template <int RB, int NC, bool PAIR, bool TIMED = false>
-__global__ __launch_bounds__(64 * NC, 5) void conv_psf_map_sbatch_kernel(
+// LAYERED (round 5, the M1-layered mode of SURVEY.md 8(d)): the S maps are (slice, layer) pairs p = slice * L + layer and a per-pixel
+// layer index decides which candidate a pixel keeps: every lane still computes its 2 x 2 block for its map, but stores a pixel of
+// slice p / L only where lidx[b][y][x] == p % L - the L candidates of a pixel sit in L different lanes (or waves), exactly one of
+// them writes it.  Output bytes are those of ONE stack instead of L stacks plus a gather pass.
+template <int RB, int NC, bool PAIR, bool TIMED = false, bool LAYERED = false>
+__global__ __launch_bounds__(64 * NC, LAYERED ? 4 : 5) void conv_psf_map_sbatch_kernel(
     const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
-    int grid, int ntx, int nty, int npass, PatchBounds pb, int stagger, int pair_mod) {
+    int grid, int ntx, int nty, int npass, PatchBounds pb, int stagger, int pair_mod, const unsigned char* __restrict__ lidx = nullptr, int L = 1) {
     using namespace sb;
     AADFF_SB_STAMP(0);
     if (stagger) {
@@ -535,6 +539,7 @@ __global__ __launch_bounds__(64 * NC, 5) void conv_psf_map_sbatch_kernel(
     unsigned (*prow)[NSL * PSL] = reinterpret_cast<unsigned (*)[NSL * PSL]>(pool);
     __shared__ float red[NW];
     __shared__ float s_isw[NSL];
+    __shared__ __attribute__((aligned(4))) unsigned char lband[LAYERED ? RB * TCOLS : 4];     // layer index of the band's pixels (255 outside the patch)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -631,6 +636,13 @@ __global__ __launch_bounds__(64 * NC, 5) void conv_psf_map_sbatch_kernel(
             }
         }
     }
+    if constexpr (LAYERED) {
+        const unsigned char* lp = lidx + (size_t)udiv_magic(bc, C, pb.m_c) * H * W;
+        for (int e = tid; e < RB * TCOLS; e += 64 * NC) {
+            const int r = e / TCOLS, cc = e - r * TCOLS, y = y0 + r, x = x0 + cc;
+            lband[e] = (y < y_hi && x < x_hi) ? lp[(size_t)y * W + x] : (unsigned char)255;
+        }
+    }
     amax = wave_max(amax);
     if (lane == 0) red[wave] = amax;
     AADFF_SB_STAMP(2);                                                        // global loads have arrived (wave 0)
@@ -707,8 +719,11 @@ __global__ __launch_bounds__(64 * NC, 5) void conv_psf_map_sbatch_kernel(
     const int s_out = s_base + chunk * 4 + kg;
     const bool s_ok = s_out < S;
     // stores: wave-uniform 64-bit base (first slice of the chunk) + 32-bit per-lane byte offset (host checks 16 x slice stride + 4 H W < 2^32)
-    char* wbase = reinterpret_cast<char*>(out + (size_t)bc * sbc + (size_t)(s_base + chunk * 4) * ss);
-    const unsigned w4 = (unsigned)W * 4u, koff = (unsigned)kg * (unsigned)(ss * 4);   // slice kg of the chunk
+    // LAYERED: map s_out is (slice s_out / L, layer s_out % L): base = the (b, c) plane stack, offset = the slice (host checks S x stride)
+    const int so_l = LAYERED ? s_out / L : 0;
+    const unsigned lyr = LAYERED ? (unsigned)(s_out - so_l * L) : 0u;
+    char* wbase = reinterpret_cast<char*>(out + (size_t)bc * sbc + (LAYERED ? (size_t)0 : (size_t)(s_base + chunk * 4) * ss));
+    const unsigned w4 = (unsigned)W * 4u, koff = (LAYERED ? (unsigned)so_l : (unsigned)kg) * (unsigned)(ss * 4);   // slice kg of the chunk
     bool pair_ok[3], one_ok[3];
 #pragma unroll
     for (int cb = 0; cb < 3; ++cb) {
@@ -770,6 +785,16 @@ __global__ __launch_bounds__(64 * NC, 5) void conv_psf_map_sbatch_kernel(
                         const float a0 = acc[0] * inv, b0 = acc[1] * inv, a1 = acc[2] * inv, b1 = acc[3] * inv;
                         char* o0 = wbase + loff + cb * 128;
                         char* o1 = wbase + (loff + w4) + cb * 128;
+                        if constexpr (LAYERED) {
+                            if (s_ok) {
+                                const unsigned q0 = *reinterpret_cast<const unsigned short*>(&lband[yl * TCOLS + 32 * cb + 2 * lo4]);
+                                const unsigned q1 = *reinterpret_cast<const unsigned short*>(&lband[(yl + 1) * TCOLS + 32 * cb + 2 * lo4]);
+                                if ((q0 & 255u) == lyr) *reinterpret_cast<float*>(o0) = a0;
+                                if ((q0 >> 8) == lyr) *reinterpret_cast<float*>(o0 + 4) = b0;
+                                if ((q1 & 255u) == lyr) *reinterpret_cast<float*>(o1) = a1;
+                                if ((q1 >> 8) == lyr) *reinterpret_cast<float*>(o1 + 4) = b1;
+                            }
+                        } else
                         if (pair_ok[cb]) {
                             *reinterpret_cast<f2u*>(o0) = (f2u){a0, b0};
                             if (row1) *reinterpret_cast<f2u*>(o1) = (f2u){a1, b1};
@@ -1186,8 +1211,8 @@ static int launch_fast(const float* img, const float* psf, float* out, long sbc,
             hipEvent_t ev0 = g_time_start, ev1 = g_time_stop;
             g_time_start = g_time_stop = nullptr;
 #define AADFF_LAUNCH_S3(NCV, PR) do { \
-                if (ev0) hipExtLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR, true>), gs, dim3(64 * NCV), 0, st, ev0, ev1, 0, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); \
-                else hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR, false>), gs, dim3(64 * NCV), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod); } while (0)
+                if (ev0) hipExtLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR, true>), gs, dim3(64 * NCV), 0, st, ev0, ev1, 0, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod, (const unsigned char*)nullptr, 1); \
+                else hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, PR, false>), gs, dim3(64 * NCV), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, sntx, gny, npass, pbs, stagger, pair_mod, (const unsigned char*)nullptr, 1); } while (0)
 #define AADFF_LAUNCH_S(NCV) do { if (pair) AADFF_LAUNCH_S3(NCV, true); else AADFF_LAUNCH_S3(NCV, false); } while (0)
             switch (nc) {
                 case 1: AADFF_LAUNCH_S(1); break;
@@ -1643,6 +1668,54 @@ static int stack_launch(const float* img, const float* psf_maps, float* out, lon
 int aadff_render_psf_map_stack(const float* img, const float* psf_maps, float* out, int B, int C, int S, int H,
                                int W, int grid, int ks, aadff_stream_t stream) {
     return stack_launch(img, psf_maps, out, (long)S * H * W, (long)H * W, B, C, S, H, W, grid, ks, (hipStream_t)stream);
+}
+
+int aadff_render_psf_map_stack_layered(const float* img, const float* psf_maps, const unsigned char* layer_idx, float* out, int B, int C, int S,
+                                       int L, int H, int W, int grid, int ks, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(img && psf_maps && layer_idx && out, "render_psf_map_stack_layered: NULL pointer");
+    AADFF_CHECK_ARG(B > 0 && C > 0 && S > 0 && L >= 1 && L <= 254 && H > 0 && W > 0, "render_psf_map_stack_layered: B=%d C=%d S=%d L=%d H=%d W=%d", B, C, S, L, H, W);
+    AADFF_CHECK_ARG(grid >= 1 && grid <= AADFF_MAX_GRID && grid <= H && grid <= W, "render_psf_map_stack_layered: grid %d", grid);
+    if (ks != 11) {
+        set_error("render_psf_map_stack_layered: the fused form exists for ks 11 only (ks %d: compose aadff_render_psf_map_stack and a gather)", ks);
+        return AADFF_EUNSUPPORTED;
+    }
+    AADFF_CHECK_ARG(5 < H && 5 < W, "render_psf_map_stack_layered: reflect padding 5 needs H,W > pad");
+    const long ss = (long)H * W, sbc = (long)S * ss;
+    const int maps = S * L;
+    PatchBounds pb;
+    std::memset(&pb, 0, sizeof(pb));
+    fill_bounds(pb.hb, grid, H);
+    fill_bounds(pb.wb, grid, W);
+    int mh = 0, mw = 0;
+    for (int i = 0; i < grid; ++i) {
+        mh = std::max(mh, pb.hb[i + 1] - pb.hb[i]);
+        mw = std::max(mw, pb.wb[i + 1] - pb.wb[i]);
+    }
+    constexpr int RB = 24;
+    const int nc = maps <= 4 ? 1 : (maps <= 8 ? 2 : (maps <= 12 ? 3 : 4));
+    const int npass = (maps + 4 * nc - 1) / (4 * nc);
+    const int sntx = (mw + sb::TCOLS - 1) / sb::TCOLS, snty = (mh + RB - 1) / RB;
+    AADFF_CHECK_ARG((size_t)B * C * npass <= 65535 && (size_t)snty * grid <= 65535, "render_psf_map_stack_layered: grid too large");
+    AADFF_CHECK_ARG((size_t)H * W <= ((size_t)1 << 27) && 4 * ((size_t)S * ss + (size_t)H * W) < ((size_t)1 << 32),
+                    "render_psf_map_stack_layered: a (b, c) plane stack above 2^30 elements is not supported");
+    pb.m_ntx = magic_of(sntx); pb.m_nty = magic_of(snty); pb.m_nchunk = magic_of(npass); pb.m_c = magic_of(C);
+    dim3 gs(sntx * grid, snty * grid, B * C * npass);
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0 = g_time_start, e1 = g_time_stop;                             // aadff_time_next_launch: bracket this launch
+    g_time_start = g_time_stop = nullptr;
+    if (e0) AADFF_CHECK_HIP(hipEventRecord(e0, st));
+#define AADFF_LAUNCH_L(NCV) hipLaunchKernelGGL((conv_psf_map_sbatch_kernel<RB, NCV, false, false, true>), gs, dim3(64 * NCV), 0, st, img, psf_maps, out, sbc, ss, C, \
+                                               maps, H, W, grid, sntx, snty, npass, pb, 0, 0, layer_idx, L)
+    switch (nc) {
+        case 1: AADFF_LAUNCH_L(1); break;
+        case 2: AADFF_LAUNCH_L(2); break;
+        case 3: AADFF_LAUNCH_L(3); break;
+        default: AADFF_LAUNCH_L(4);
+    }
+#undef AADFF_LAUNCH_L
+    if (e0) AADFF_CHECK_HIP(hipEventRecord(e1, st));
+    AADFF_CHECK_LAUNCH();
+    return 0;
 }
 
 int aadff_render_psf_map_stack_strided(const float* img, const float* psf_maps, float* out, long stride_bc, long stride_s,

@@ -109,11 +109,13 @@ def main():
                          "the device in the timed region.  --streams 1: every kernel alone on the device throughout (round-2 default; "
                          "rocprofv3 --stats of that command reproduces the solo-leg durations)")
     ap.add_argument("--solo-steps", type=int, default=40, help="stacks of the untimed solo leg that times the convolution and PSF-grid kernels")
-    ap.add_argument("--mode", choices=("m1", "m2", "fit", "c3"), default="m1",
+    ap.add_argument("--mode", choices=("m1", "m2", "fit", "c3", "m1l"), default="m1",
                     help="m1 (default, BASELINE.json metric): ray-traced PSF grid + patch convolution; "
                          "m2: RGB-D stack through the PSF surrogate network (PSFNet.render, SURVEY.md 8f-1); "
                          "fit: 1_fit_psfnet.py training iterations (ray-traced targets + MLP step, BASELINE config 3); "
-                         "c3: 16 scenes x 10 slices sharded in whole-scene blocks, all-gathered row by row (BASELINE config 3, strong scaling)")
+                         "c3: 16 scenes x 10 slices sharded in whole-scene blocks, all-gathered row by row (BASELINE config 3, strong scaling); "
+                         "m1l: M1-layered (SURVEY.md 8(d)): the depth MAP in 4 layers, one ray-traced PSF map per (slice, layer), per-pixel selection "
+                         "fused into the stack convolution")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -128,6 +130,8 @@ def main():
         return main_fit(args)
     if args.mode == "c3":
         return main_c3(args)
+    if args.mode == "m1l":
+        return main_m1l(args)
 
     import torch.distributed as dist
     from aadff import dist as adist
@@ -655,6 +659,116 @@ def main_m2(args):
                          "peak": 2500.0, "unit": "TFLOP/s", "frac": round(issued / 2500.0, 4), "traffic": None,
                          "kernel_ms": round(kms, 4), "fp32_equivalent_tflops": round(issued / passes, 1)}}), flush=True)
     if world > 1:
+        dist.destroy_process_group()
+
+
+def main_m1l(args):
+    """M1-layered: RGB-D stack, the depth map quantised into L = 4 layers, S x L ray-traced PSF maps, every pixel
+    keeps the candidate of its own layer.  Three launches per stack: refocus, one PSF-grid launch for the S x L pairs, the layered
+    stack convolution (aadff_render_psf_map_stack_layered).  Step = one stack; one rank per GPU renders its own scene (weak scaling)."""
+    import torch.distributed as dist
+    from aadff import _abi
+    from aadff import dist as adist
+    from aadff.focal_stack import render_focal_stack_m1_layered
+    from aadff.synth import synth_depth_mm, synth_rgb
+    from deeplens.optics import Lensgroup, raise_psf_flags
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    adist.init_from_env(backend="nccl", device=dev)
+    L = int(os.environ.get("AADFF_M1L_LAYERS", "4"))
+    lens_path = os.path.join(REPO, "lenses", "rf50mm", "lens.json")
+    lens = Lensgroup(lens_path, sensor_res=(H, W), device=dev)
+    img_h = torch.from_numpy(synth_rgb(H, W, seed=1234 + rank))[None]
+    depth_h = -torch.from_numpy(synth_depth_mm(H, W, seed=5678 + rank))[None, None]
+    img, depth = img_h.to(dev), depth_h.to(dev)
+    fds = [float(f) for f in np.linspace(float(depth_h.max()), float(depth_h.min()), S)]       # nearest .. farthest (mm < 0)
+    steps = min(args.steps, 50) if args.steps == 200 else args.steps
+    warm = min(args.warmup, 5)
+    for i in range(warm):
+        torch.manual_seed(i)
+        render_focal_stack_m1_layered(lens, img, depth, fds, layers=L, grid=GRID, ks=KS, spp=SPP)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        torch.manual_seed(100 + i)
+        out = render_focal_stack_m1_layered(lens, img, depth, fds, layers=L, grid=GRID, ks=KS, spp=SPP)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    raise_psf_flags(int(lens._m1l_flags.item()))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # the convolution launch alone between two stream events (same image / maps / index as a step) and, for comparison, the whole
+    # composition it replaces
+    torch.manual_seed(7)
+    _, maps_d, lidx_d = render_focal_stack_m1_layered(lens, img, depth, fds, layers=L, grid=GRID, ks=KS, spp=SPP, return_parts=True)
+    out_d = torch.empty((1, 3, S, H, W), dtype=torch.float32, device=dev)
+    kms, comp = [], []
+    for i in range(20):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _abi.call("aadff_render_psf_map_stack_layered", _abi.ptr(img), _abi.ptr(maps_d), _abi.ptr(lidx_d), _abi.ptr(out_d), 1, 3, S, L, H, W, GRID, KS,
+                  _abi.stream_ptr(dev))
+        e1.record()
+        torch.cuda.synchronize(dev)
+        kms.append(e0.elapsed_time(e1))
+    for i in range(5):
+        t1 = time.perf_counter()
+        render_focal_stack_m1_layered(lens, img, depth, fds, layers=L, grid=GRID, ks=KS, spp=SPP, fused=False)
+        torch.cuda.synchronize(dev)
+        comp.append(time.perf_counter() - t1)
+    conv_ms = float(np.median(kms))
+    bytes_launch = (1 + S) * 3 * H * W * 4 + H * W                           # image once + S output slices + 1 B / pixel of layer index
+    if rank == 0:
+        res = {
+            "metric": "focal-stack MP/s (M1-layered: RGB-D, depth map in 4 layers, 1024^2 x 10 slices, 11x11 PSF grid)",
+            "value": round(world * S * H * W / 1e6 * steps / dt, 2), "unit": "MP/s", "n_gpus": world, "steps": steps, "warmup": warm,
+            "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"rf50mm, 1024x1024 synthetic RGB + depth MAP quantised into {L} layers, 10 focus distances, 11x11 PSF grid, ks 11, "
+                                   f"spp 2048 (+2048 chief): {S * L} ray-traced PSF maps per stack, per-pixel selection fused into the stack convolution",
+                       "launches_per_stack": 3, "composition_ms_per_stack": round(float(np.median(comp)) * 1e3, 3),
+                       "composition": "the same three launches but S x L candidate slices through the stack convolution + torch.gather (L x the output bytes)"},
+            "roofline": {"kernel": "conv_psf_map_sbatch_kernel<24,4,false,false,LAYERED> (aadff_render_psf_map_stack_layered)", "bound": "hbm",
+                         "achieved": round(bytes_launch / (conv_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(bytes_launch / (conv_ms * 1e-3) / HBM_PEAK, 4), "traffic": None,
+                         "basis": "(1 + S) x 12 B + 1 B of layer index per pixel (SURVEY.md 8(d) M1-layered; the index map is uint8 here)",
+                         "bytes_per_launch": bytes_launch, "kernel_ms": round(conv_ms, 4),
+                         "kernel_ms_note": "two stream events around the launch alone (same image, PSF maps and layer index as a step), median of 20",
+                         "tflops": round(2 * 3 * KS * KS * H * W * S * L / (conv_ms * 1e-3) / 1e12, 2)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            sys.path.insert(0, REPO)
+            from oracle import psfnet as opsf
+            from oracle.lens import OracleLens
+            torch.set_num_threads(usable_cpus())
+            ora = OracleLens(lens_path, sensor_res=(H, W))
+            n = 1                                            # bounded sample: ONE slice = 4 psf_map traces + 4 convolutions of the oracle
+            torch.manual_seed(100 + steps - 1)               # the seed of the last timed step: its first slice consumes the same draws
+            t1 = time.perf_counter()
+            want = opsf.focal_stack_m1_layered(ora, img_h, depth_h, fds[:n], layers=L, grid=GRID, ks=KS, spp=SPP)
+            tc = time.perf_counter() - t1
+            a, b = out[:, :, :n].cpu().numpy().astype(np.float64), want.numpy().astype(np.float64)
+            res["cpu_baseline"] = {"value": round(n * H * W / 1e6 / tc, 4), "unit": "MP/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "cpu_model": cpu_model(), "sample": f"{n} of {S} slices of the same M1-layered stack (oracle composition: refocus + {L} x "
+                                   f"(psf_map + render_psf_map) + per-pixel selection), {tc:.1f} s"}
+            res["parity"] = {"rel_l2": float(f"{np.linalg.norm(a - b) / np.linalg.norm(b):.3e}"), "slices": n, "tolerance": 1e-4,
+                             "against": "oracle composition (oracle/psfnet.py: focal_stack_m1_layered), same seed, first slice of the last timed step"}
+        print(json.dumps(res), flush=True)
+        if res.get("parity", {}).get("rel_l2", 0.0) > 1e-4:
+            print("bench: parity failed", file=sys.stderr, flush=True)
+            raise SystemExit(4)
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -131,6 +131,15 @@ int aadff_render_psf_map_stack_strided(const float* img, const float* psf_maps, 
                                        long stride_bc, long stride_s,
                                        int B, int C, int S, int H, int W, int grid, int ks,
                                        aadff_stream_t stream);
+/* M1-layered stack (SURVEY.md 8(d) "M1-layered": the depth MAP quantised into L layers, one ray-traced PSF map per (slice, layer)):
+ * out[b][c][s][y][x] = render_psf_map(img, psf_maps[s * L + layer_idx[b][y][x]])[b][c][y][x], i.e. the per-pixel selection among the L
+ * candidates of slice s, computed in ONE launch from one staged image band per pass and written once (the composition renders
+ * S * L full slices and gathers: L x the output bytes plus a pass over them).  Composes render_psf_map, deeplens/render_psf.py:31-73,
+ * over the slice loop of 2_aber_aware_dff_aif.py:104-114.  img [B,C,H,W], psf_maps [S*L,C,g*ks,g*ks], layer_idx [B,H,W] uint8 (values
+ * < L), out [B,C,S,H,W]; ks 11 (other sizes: AADFF_EUNSUPPORTED, compose).  Arithmetic contract as aadff_render_psf_map. */
+int aadff_render_psf_map_stack_layered(const float* img, const float* psf_maps, const unsigned char* layer_idx, float* out, int B, int C, int S,
+                                       int L, int H, int W, int grid, int ks, aadff_stream_t stream);
+
 /* Measurement aid (no reference counterpart): arm the NEXT aadff_render_psf_map_stack (slice-batched kernel: ks 11, S >= 3)
  * or aadff_psf_points / aadff_psf_points_staged call made by this host thread so that its kernel is launched with the two
  * HIP events (hipEvent_t, timing enabled) attached to the dispatch (hipExtLaunchKernelGGL): hipEventElapsedTime then gives

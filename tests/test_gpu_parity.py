@@ -1360,6 +1360,43 @@ def test_focal_stack_m1_layered_vs_oracle(repo_root):
     assert torch.equal(idx_g.cpu(), idx_o) and torch.allclose(cen_g.cpu(), cen_o)
 
 
+@pytest.mark.parametrize("hw,S,L,grid", [((1024, 1024), 10, 4, 11), ((200, 328), 5, 3, 4), ((96, 64), 2, 7, 2)])
+def test_focal_stack_m1_layered_fused_equals_composition(repo_root, hw, S, L, grid):
+    """Round 5: the fused M1-layered stack (one PSF launch for all (slice, layer) pairs, `aadff_render_psf_map_stack_layered`: the L
+    candidates of a pixel from one staged band, only the pixel's own layer written) against the composition it replaces (S x L
+    candidate slices through the stack convolution + torch.gather) - at the bench size (1024^2 x 10 x 4 layers), a ragged image
+    whose patches are narrower than a tile, and L = 7 (pairs that straddle the 4-map chunks).  The convolution on the SAME PSF maps
+    is BIT-equal pixel for pixel; the whole function (its PSF histograms are float atomics, run-to-run 1e-7) to 2e-6."""
+    from aadff.focal_stack import depth_layers, render_focal_stack_m1_layered
+    H, W = hw
+    img = tt(synth_rgb(H, W, seed=31))[None].to(DEV)
+    depth = -tt(synth_depth_mm(H, W, seed=32, dmin=600.0, dmax=4000.0))[None, None].to(DEV)
+    depth[0, 0, :5, :7] = 0.0                                      # invalid pixels -> farthest layer
+    fds = -np.linspace(650.0, 3800.0, S)
+    lens = Lensgroup(lens_path(repo_root), sensor_res=(H, W), device=DEV)
+    torch.manual_seed(9)
+    a = render_focal_stack_m1_layered(lens, img, depth, fds, layers=L, grid=grid, ks=11, spp=256)
+    state_a = (lens.d_sensor, lens.hfov)
+    torch.manual_seed(9)
+    b = render_focal_stack_m1_layered(lens, img, depth, fds, layers=L, grid=grid, ks=11, spp=256, fused=False)
+    assert a.shape == b.shape == (1, 3, S, H, W)
+    assert float((a - b).abs().max()) <= 2e-6 and not torch.isnan(a).any()
+    assert state_a == (lens.d_sensor, lens.hfov)
+    # the convolution alone, same maps: bit-equal; two images, so that the (b, c) plane indexing of the layer map is exercised
+    g = torch.Generator().manual_seed(5)
+    maps = torch.rand(S * L, 3, grid * 11, grid * 11, generator=g).to(DEV)
+    maps = maps / maps.reshape(S * L, 3, grid, 11, grid, 11).sum((3, 5), keepdim=True).reshape(S * L, 3, grid, 1, grid, 1).expand(-1, -1, -1, 11, -1, 11).reshape_as(maps)
+    x = torch.stack((img[0], img[0].flip(-1))).contiguous()
+    idx, _ = depth_layers(torch.stack((depth[0], depth[0].flip(-2))), L)
+    lidx = idx.reshape(2, H, W).to(torch.uint8).contiguous()
+    fused = torch.full((2, 3, S, H, W), float("nan"), device=DEV)
+    _abi.call("aadff_render_psf_map_stack_layered", _abi.ptr(x), _abi.ptr(maps), _abi.ptr(lidx), _abi.ptr(fused), 2, 3, S, L, H, W, grid, 11, _abi.stream_ptr(torch.device(DEV)))
+    tmp = torch.empty((2, 3, S * L, H, W), device=DEV)
+    _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(maps), _abi.ptr(tmp), 2, 3, S * L, H, W, grid, 11, _abi.stream_ptr(torch.device(DEV)))
+    want = torch.gather(tmp.view(2, 3, S, L, H, W), 3, idx.reshape(2, 1, 1, 1, H, W).expand(2, 3, S, 1, H, W)).squeeze(3)
+    assert torch.equal(fused, want), (int((fused != want).sum()), int(torch.isnan(fused).sum()))
+
+
 def _staged_vs_copy(repo_root, monkeypatch, steps, lib=None):
     from aadff import focal_stack as fs
     H = W = 64
