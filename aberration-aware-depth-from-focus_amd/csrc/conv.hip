@@ -453,6 +453,237 @@ __global__ __launch_bounds__(64 * NW) void conv_psf_map_mfma_kernel(
 }
 
 // ------------------------------------------------------------------------------------
+// Toeplitz GEMM for the LARGE kernel sizes (round 5: odd ks 13 .. 51 - the reference's own render_single_img(method='psf') uses
+// grid 7, ks 21, deeplens/optics.py:779-783; psf_map's default and analysis() ks 51, optics.py:1006).  The form of
+// conv_psf_map_mfma_kernel with the Toeplitz band of a 16-column block spread over NK k-steps of 32 input columns
+// (16 + ks - 1 <= 32 NK: NK = 1 up to ks 17, 2 up to ks 49, 3 for ks 51) and ks a run-time value:
+//   D[y][x] += sum_u sum_kk sum_k in[y + u][x0 + 32 kk + k] * w(u, 32 kk + k - x)      per tap row u: 3 NK MFMAs (hi/lo split)
+// Image tile as two fp16 planes [32 + ks - 1][P], P = the staged width rounded up to 8 (mod 16) halves: rows P / 2 dwords apart
+// with P / 2 = 4 (mod 8) put the 16 rows of an A-fragment ds_read_b128 on 16 different bank quadruples.  Tap rows zero-padded,
+// flipped, exact fp16 hi/lo, 32 NK + 16 (+2) halves each; a lane's 8 consecutive taps start at any half index (5 dwords +
+// funnel shift).  One slice per wave, NW waves share the staged tile.  LDS is dynamic: tile planes + NW tap-row sets.
+// Useful MACs are ks / (32 NK) of the issued ones (21 / 64 at ks 21), and it is still 3x the packed-FMA kernel: the matrix pipe
+// has 16x the fp32 vector rate.
+// ------------------------------------------------------------------------------------
+// Workgroup = one 32 x 32 tile of one patch and plane, staged ONCE by its 4 waves for the `spw` slices of its chunk.  Every wave
+// renders all four 16 x 16 blocks from one Toeplitz fragment per (tap row, k-step) - 12 MFMAs per fragment pair: a wave per block
+// read the same fragments four times and ran LDS-bound at a quarter of the matrix rate - and the waves split
+//   KSPLIT = false: the SLICES (wave w = slice 4 g + w of the chunk, its own tap rows in LDS; needs 4 tap-row sets: ks <= 31),
+//   KSPLIT = true:  the TAP ROWS of one slice at a time (u = w, w + 4, ...; the four partial tiles meet in LDS): lone slices, ks > 31.
+// MAXR / MAXT: tile rows / taps a thread stages in registers (the size class of ks: sized for ks 51 they cost ks 21 half its occupancy)
+template <int NK, bool KSPLIT, int MAXR, int MAXT>
+__global__ __launch_bounds__(256) void conv_psf_map_toeplitz_wide_kernel(
+    const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
+    int grid, int ks, int P, int spw, int ntx, int nty, PatchBounds pb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    constexpr int RP = 32 * NK + 16, RS = RP + 2;                        // padded tap-row length (halves), its LDS stride
+    const int pad = ks / 2, TWP = TW + ks - 1, THP = TH + ks - 1;
+    _Float16* Ahi = reinterpret_cast<_Float16*>(dyn);
+    _Float16* Alo = Ahi + (size_t)THP * P;
+    _Float16* rows0 = Alo + (size_t)THP * P;                             // KSPLIT: [ks][2][RS] (also the 16 KB reduction area); else [4][ks][2][RS]
+    __shared__ float red[4];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pj = udiv_magic(blockIdx.x, ntx, pb.m_ntx), tx = blockIdx.x - pj * ntx;
+    const int pi = udiv_magic(blockIdx.y, nty, pb.m_nty), ty = blockIdx.y - pi * nty;
+    const int nchunk = (S + spw - 1) / spw;
+    const int bc = udiv_magic(blockIdx.z, nchunk, pb.m_nchunk), chunk = blockIdx.z - bc * nchunk;
+    const int c = bc - udiv_magic(bc, C, pb.m_c) * C;
+    const int x_hi = pb.wb[pj + 1], y_hi = pb.hb[pi + 1];
+    const int x0 = pb.wb[pj] + tx * TW, y0 = pb.hb[pi] + ty * TH;
+    if (x0 >= x_hi || y0 >= y_hi) return;
+    const int G = grid * ks;
+    const float* plane = img + (size_t)bc * H * W;
+
+    // the taps of the first slice are requested FIRST: they are then not a second exposed memory latency behind the tile's
+    const int nthr = KSPLIT ? 256 : 64, me = KSPLIT ? tid : lane;
+    float tw[MAXT];
+    auto load_taps = [&](int s, bool live) {
+        const float* wp = psf + ((size_t)((live ? s : 0) * C + c) * G + pi * ks) * G + pj * ks;
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j) {
+            const int e = me + nthr * j;
+            const int u = e / ks, v = e - u * ks;
+            tw[j] = (live && e < ks * ks) ? wp[(size_t)u * G + v] : 0.f;
+        }
+    };
+    {
+        const int s = KSPLIT ? chunk * spw : chunk * spw + wave;
+        load_taps(s, s < S && (KSPLIT || wave < spw));
+    }
+    // ---- image tile: lane = columns (lane, lane + 64), rows strided over the 4 waves; every load in flight before the first use ----
+    {
+        float va[MAXR], vb[MAXR];
+        float amax = 0.f;
+        const int xa = reflect_idx(x0 - pad + lane, W), xb = reflect_idx(x0 - pad + 64 + lane, W);
+        const bool ca = lane < TWP, cb = lane + 64 < TWP;
+#pragma unroll
+        for (int j = 0; j < MAXR; ++j) {
+            const int r = wave + 4 * j;
+            const float* row = plane + (size_t)reflect_idx(y0 - pad + (r < THP ? r : 0), H) * W;
+            va[j] = (ca && r < THP) ? row[xa] : 0.f;
+            vb[j] = (cb && r < THP) ? row[xb] : 0.f;
+            amax = fmaxf(amax, fmaxf(fabsf(va[j]), fabsf(vb[j])));
+        }
+        amax = wave_max(amax);
+        if (lane == 0) red[wave] = amax;
+        __syncthreads();
+        const float tmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float sx, isx0;
+        pow2_scale(tmax, sx, isx0);
+#pragma unroll
+        for (int j = 0; j < MAXR; ++j) {
+            const int r = wave + 4 * j;
+            if (r < THP) {
+                if (lane < P) {
+                    const float xs = va[j] * sx;
+                    const _Float16 h = (_Float16)xs;
+                    Ahi[r * P + lane] = h;
+                    Alo[r * P + lane] = (_Float16)(xs - (float)h);
+                }
+                if (lane + 64 < P) {
+                    const float xs = vb[j] * sx;
+                    const _Float16 h = (_Float16)xs;
+                    Ahi[r * P + lane + 64] = h;
+                    Alo[r * P + lane + 64] = (_Float16)(xs - (float)h);
+                }
+            }
+        }
+    }
+    float sxd, isx;                                                      // (recomputed: keeps the staging registers out of the main loop)
+    pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), sxd, isx);
+
+    _Float16* rows = KSPLIT ? rows0 : rows0 + (size_t)wave * ks * 2 * RS;
+    // zero padding of the tap rows (the taps themselves are rewritten per slice)
+    for (int e = me; e < ks * RS; e += nthr) reinterpret_cast<unsigned*>(rows)[e] = 0u;
+
+    // lane holds B[k = 8 kq + j][n] of k-step kk = w(u, 32 kk + k - n) = R_u[st + j], st = 32 kk + 8 kq - n + 15
+    const int kq = lane >> 4, n = lane & 15;
+    const int st0 = 8 * kq - n + 15;
+    const unsigned sh = (st0 & 1) * 16;                                  // (32 kk keeps the parity)
+    const unsigned* rbase = reinterpret_cast<const unsigned*>(rows) + (st0 >> 1);
+    constexpr int RSD = RS / 2;                                          // dwords per (u, plane) row
+    auto load_frag = [&](int u, int plane_i, int kk) -> half8v {
+        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+        const unsigned* q = rbase + (u * 2 + plane_i) * RSD + 16 * kk;
+        const unsigned d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+        uint4v r = {__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
+                    __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh)};
+        return __builtin_bit_cast(half8v, r);
+    };
+    const int abase = n * P + 8 * kq;                                    // A fragment: row m = l & 15, 8 halves at k-group l >> 4
+    constexpr int NBY = TH / 16, NBX = TW / 16;
+
+    const int ngroups = KSPLIT ? spw : (spw + 3) / 4;
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const int s = KSPLIT ? chunk * spw + gi : chunk * spw + 4 * gi + wave;
+        const bool live = s < S && (KSPLIT || 4 * gi + wave < spw);
+        if (KSPLIT && !live) break;                                      // uniform
+        // ---- the slice's taps -> registers -> scale -> flipped into the padded rows ----
+        if (gi > 0) load_taps(s, live);
+        float wmax = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j) wmax = fmaxf(wmax, fabsf(tw[j]));
+        wmax = wave_max(wmax);
+        if constexpr (KSPLIT) {
+            __syncthreads();                                             // the previous slice's reduction is done with the rows area; red is free
+            if (lane == 0) red[wave] = wmax;
+            __syncthreads();
+            wmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        }
+        float sw, isw;
+        pow2_scale(wmax, sw, isw);
+        if constexpr (KSPLIT) {                                          // (the reduction area overlaps the rows: restore their zero padding)
+            if (gi > 0) {
+                for (int e = tid; e < ks * RS; e += 256) reinterpret_cast<unsigned*>(rows)[e] = 0u;
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j) {
+            const int e = me + nthr * j;
+            if (e < ks * ks) {
+                const int uu = e / ks, vv = e - uu * ks;                 // psf[uu][vv] = w(ks-1-uu, ks-1-vv)
+                const float w = tw[j] * sw;
+                const _Float16 h = (_Float16)w;
+                const int at = ((ks - 1 - uu) * 2) * RS + (ks - 1 - vv) + 15;
+                rows[at] = h;
+                rows[at + RS] = (_Float16)(w - (float)h);
+            }
+        }
+        if constexpr (KSPLIT) __syncthreads();
+        else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (gi == 0) __syncthreads();                                // the tile (all waves staged it)
+        }
+
+        const float inv = isx * isw;
+        float4v acc[NBY][NBX];
+#pragma unroll
+        for (int by = 0; by < NBY; ++by)
+#pragma unroll
+            for (int bx = 0; bx < NBX; ++bx) acc[by][bx] = (float4v){0.f, 0.f, 0.f, 0.f};
+        if (live) {
+#pragma unroll 1
+            for (int u = KSPLIT ? wave : 0; u < ks; u += KSPLIT ? 4 : 1) {
+#pragma unroll
+                for (int kk = 0; kk < NK; ++kk) {
+                    const half8v bh = load_frag(u, 0, kk), bl = load_frag(u, 1, kk);
+#pragma unroll
+                    for (int by = 0; by < NBY; ++by)
+#pragma unroll
+                        for (int bx = 0; bx < NBX; ++bx) {
+                            const int off = abase + (16 * by + u) * P + 16 * bx + 32 * kk;
+                            const half8v ah = *reinterpret_cast<const half8v*>(&Ahi[off]);
+                            const half8v al = *reinterpret_cast<const half8v*>(&Alo[off]);
+                            acc[by][bx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[by][bx], 0, 0, 0);
+                            acc[by][bx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[by][bx], 0, 0, 0);
+                            acc[by][bx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[by][bx], 0, 0, 0);
+                        }
+                }
+            }
+        }
+        float* oplane = out + (size_t)bc * sbc + (size_t)(live ? s : 0) * ss;
+        if constexpr (KSPLIT) {
+            // the four partial tiles (tap rows u = w mod 4) meet in LDS: [wave][block][lane][4] floats = 16 KB over the rows area
+            float4v* racc = reinterpret_cast<float4v*>(rows0);
+            __syncthreads();                                             // every wave is done reading the tap rows
+#pragma unroll
+            for (int by = 0; by < NBY; ++by)
+#pragma unroll
+                for (int bx = 0; bx < NBX; ++bx) racc[(wave * 4 + by * 2 + bx) * 64 + lane] = acc[by][bx];
+            __syncthreads();
+            const float4v t = (racc[(0 * 4 + wave) * 64 + lane] + racc[(1 * 4 + wave) * 64 + lane]) +
+                              (racc[(2 * 4 + wave) * 64 + lane] + racc[(3 * 4 + wave) * 64 + lane]);
+            const int by = wave >> 1, bx = wave & 1;                     // wave b finishes block b
+            const int x = x0 + 16 * bx + n, yb = y0 + 16 * by + 4 * kq;
+            if (x < x_hi) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (yb + r < y_hi) oplane[(size_t)(yb + r) * W + x] = t[r] * inv;
+            }
+        } else if (live) {
+            // C/D layout: column n = l & 15, rows 4 (l >> 4) + r
+#pragma unroll
+            for (int by = 0; by < NBY; ++by)
+#pragma unroll
+                for (int bx = 0; bx < NBX; ++bx) {
+                    const int x = x0 + 16 * bx + n, yb = y0 + 16 * by + 4 * kq;
+                    if (x < x_hi) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (yb + r < y_hi) oplane[(size_t)(yb + r) * W + x] = acc[by][bx][r] * inv;
+                    }
+                }
+            __builtin_amdgcn_wave_barrier();                             // the next slice overwrites this wave's tap rows
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Slice-batched MFMA path (ks = 11, stacks of >= 3 slices): the S slices of a stack share the image, so the image
 // window is the shared GEMM operand and the slices ride on the M dimension:
 //   D[m][n] += sum_k T[m][k] X[k][n]
@@ -1313,6 +1544,41 @@ static int conv_dispatch(const float* img, const float* psf, float* out, long sb
         mw = std::max(mw, pb.wb[i + 1] - pb.wb[i]);
     }
     const int ntx = (mw + TW - 1) / TW, nty = (mh + TH - 1) / TH;
+    if (ks >= 13 && !getenv("AADFF_CONV_PATH")) {
+        // large kernels on the matrix cores (Toeplitz GEMM over NK k-steps); AADFF_CONV_PATH=valu keeps the packed-FMA / generic kernels
+        const int nk = (16 + ks - 1 + 31) / 32;                         // 1: ks <= 17, 2: ks <= 49, 3: ks 51
+        const int twp = TW + ks - 1, thp = TH + ks - 1;
+        int P = (twp + 7) / 8 * 8;
+        while (P % 16 != 8) P += 8;                                      // P / 2 dwords = 4 (mod 8): conflict-free A-fragment reads
+        if (P < 32 * nk + 16 + 8) P = 32 * nk + 24;                      // the last k-step's 8 halves stay inside the row (zero padding)
+        while (P % 16 != 8) P += 8;
+        const size_t tile_b = (size_t)2 * thp * P * sizeof(_Float16), rows_b = (size_t)ks * 2 * (32 * nk + 18) * sizeof(_Float16);
+        // waves = slices when four tap-row sets fit beside the tile and there are slices to share it; else the waves split the tap rows
+        const bool ksplit = S < 2 || tile_b + 4 * rows_b > 64 * 1024 - 64 || ks > 31;
+        const size_t lds = tile_b + (ksplit ? std::max(rows_b, (size_t)16384) : 4 * rows_b);
+        AADFF_CHECK_ARG(lds <= 64 * 1024 - 64, "render_psf_map: ks %d needs %zu bytes of LDS", ks, lds);
+        // slices per workgroup: the whole stack from one staged tile unless that leaves the chip short of workgroups
+        const long tiles = (long)ntx * grid * nty * grid * B * C;
+        int spw = S;
+        while (spw > (ksplit ? 1 : 4) && tiles * ((S + spw - 1) / spw) < 2048) spw = (spw + 1) / 2;
+        if (!ksplit) spw = (spw + 3) / 4 * 4;
+        const int nchunk = (S + spw - 1) / spw;
+        AADFF_CHECK_ARG((size_t)B * C * nchunk <= 65535, "render_psf_map: B*C*chunks too large");
+        PatchBounds pbm = pb;
+        pbm.m_ntx = magic_of(ntx); pbm.m_nty = magic_of(nty); pbm.m_nchunk = magic_of(nchunk); pbm.m_c = magic_of(C);
+        dim3 g(ntx * grid, nty * grid, B * C * nchunk);
+#define AADFF_WIDE(NKV, KSP, MR, MT) hipLaunchKernelGGL((conv_psf_map_toeplitz_wide_kernel<NKV, KSP, MR, MT>), g, dim3(256), lds, st, img, psf, out, sbc, ss, C, S, H, \
+                                                        W, grid, ks, P, spw, ntx, nty, pbm)
+        // size classes: rows per thread = ceil((32 + ks - 1) / 4), taps per thread = ceil(ks^2 / 256) (tap rows split) or / 64 (slices split)
+        if (ks <= 17) { if (ksplit) AADFF_WIDE(1, true, 12, 2); else AADFF_WIDE(1, false, 12, 5); }
+        else if (ks <= 21) { if (ksplit) AADFF_WIDE(2, true, 13, 2); else AADFF_WIDE(2, false, 13, 7); }
+        else if (ks <= 31) { if (ksplit) AADFF_WIDE(2, true, 16, 4); else AADFF_WIDE(2, false, 16, 16); }
+        else if (ks <= 49) AADFF_WIDE(2, true, 20, 10);
+        else AADFF_WIDE(3, true, 21, 11);
+#undef AADFF_WIDE
+        AADFF_CHECK_LAUNCH();
+        return 0;
+    }
     switch (ks) {
 #define AADFF_CASE(K) case K: { int rc = launch_fast<K>(img, psf, out, sbc, ss, B, C, S, H, W, grid, ntx, nty, pb, st); if (rc) return rc; } break;
         AADFF_CASE(3) AADFF_CASE(5) AADFF_CASE(7) AADFF_CASE(9) AADFF_CASE(11) AADFF_CASE(13)
