@@ -103,6 +103,7 @@ PROTOTYPES = {
     "aadff_adamw_step": [_P, _P, _I, _P, _P, _P, _L, _P, _P, _F, _I, _F, _F, _F, _F, _P],
     "aadff_host_mt19937_uniform_f32": [_P, _L, _L, _P],
     "aadff_host_mt19937_discard": [_P, _L, _L],
+    "aadff_host_mt19937_rows": [_P, _L, _I, _L, _L, _P, _P, _I],
 }
 OTHER_SYMBOLS = ["aadff_abi_version", "aadff_last_error", "aadff_device_info"]
 

@@ -75,32 +75,49 @@ struct Avx512 { AADFF_MT_BODY(16) };
 #pragma clang attribute pop
 }  // namespace
 
-static int advance(unsigned char* torch_state, long state_bytes, long n, float* out) {
+struct Gen { uint32_t st[N]; int left, nxt; };
+
+static int load_gen(const unsigned char* torch_state, long state_bytes, Gen& g) {
     AADFF_CHECK_ARG(state_bytes == 5056, "host_mt19937: unexpected torch CPU generator state size %ld (want 5056)", state_bytes);
     int32_t left;
     uint64_t next64;
     std::memcpy(&left, torch_state + 8, 4);
     std::memcpy(&next64, torch_state + 16, 8);
     AADFF_CHECK_ARG(left >= 1 && left <= N && next64 <= (uint64_t)N, "host_mt19937: corrupt generator state (left=%d next=%llu)", left, (unsigned long long)next64);
-    uint32_t st[N];
     for (int i = 0; i < N; ++i) {
         uint64_t v;
         std::memcpy(&v, torch_state + 24 + 8 * i, 8);
-        st[i] = (uint32_t)v;
+        g.st[i] = (uint32_t)v;
     }
-    int nxt = (int)next64;
-    static const bool avx2 = __builtin_cpu_supports("avx2");
-    static const bool avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl");
-    if (avx512) Avx512::fill(st, left, nxt, n, out);
-    else if (avx2) Avx2::fill(st, left, nxt, n, out);
-    else Base::fill(st, left, nxt, n, out);
-    next64 = (uint64_t)nxt;
+    g.left = left;
+    g.nxt = (int)next64;
+    return 0;
+}
+
+static void store_gen(unsigned char* torch_state, const Gen& g) {
+    const int32_t left = g.left;
+    const uint64_t next64 = (uint64_t)g.nxt;
     std::memcpy(torch_state + 8, &left, 4);
     std::memcpy(torch_state + 16, &next64, 8);
     for (int k = 0; k < N; ++k) {
-        const uint64_t v = st[k];
+        const uint64_t v = g.st[k];
         std::memcpy(torch_state + 24 + 8 * k, &v, 8);
     }
+}
+
+static void fill_any(Gen& g, long n, float* out) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    static const bool avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl");
+    if (avx512) Avx512::fill(g.st, g.left, g.nxt, n, out);
+    else if (avx2) Avx2::fill(g.st, g.left, g.nxt, n, out);
+    else Base::fill(g.st, g.left, g.nxt, n, out);
+}
+
+static int advance(unsigned char* torch_state, long state_bytes, long n, float* out) {
+    Gen g;
+    if (int rc = load_gen(torch_state, state_bytes, g)) return rc;
+    fill_any(g, n, out);
+    store_gen(torch_state, g);
     return 0;
 }
 
@@ -114,4 +131,36 @@ extern "C" int aadff_host_mt19937_uniform_f32(unsigned char* torch_state, long s
 extern "C" int aadff_host_mt19937_discard(unsigned char* torch_state, long state_bytes, long n) {
     AADFF_CHECK_ARG(torch_state && n >= 0, "host_mt19937_discard: NULL pointer or negative count");
     return advance(torch_state, state_bytes, n, nullptr);
+}
+
+// Rows of draws in TWO passes (single-stack latency: what the first launch of a focal stack needs are the 2 x 2048 focus draws at the
+// head of every slice's block, the reference's order puts slice s + 1's behind slice s's PSF draws - SURVEY.md Appendix B):
+//   phase 0: from the generator state, for every row r: produce the first `head` draws of the row into out[r * row_len ..], keep a
+//            snapshot of the generator there (snapshots[r]: 2504 bytes = 624 words + left + next), SKIP the other row_len - head
+//            (regenerations only); the state is left behind the whole block - exactly where torch.rand(n_rows * row_len) leaves it;
+//   phase 1: for every row r: from snapshots[r] produce the remaining row_len - head draws into out[r * row_len + head ..]
+//            (torch_state is not touched).  The block then equals the one a single pass produces, bit for bit.
+extern "C" int aadff_host_mt19937_rows(unsigned char* torch_state, long state_bytes, int n_rows, long row_len, long head, float* out,
+                                       unsigned char* snapshots, int phase) {
+    AADFF_CHECK_ARG(out && snapshots && n_rows >= 0 && row_len >= 0 && head >= 0 && head <= row_len && (phase == 0 || phase == 1),
+                    "host_mt19937_rows: bad arguments");
+    static_assert(sizeof(Gen) == 2504, "snapshot size");
+    if (phase == 0) {
+        AADFF_CHECK_ARG(torch_state, "host_mt19937_rows: NULL state");
+        Gen g;
+        if (int rc = load_gen(torch_state, state_bytes, g)) return rc;
+        for (int r = 0; r < n_rows; ++r) {
+            fill_any(g, head, out + (long)r * row_len);
+            std::memcpy(snapshots + (size_t)r * sizeof(Gen), &g, sizeof(Gen));
+            fill_any(g, row_len - head, nullptr);
+        }
+        store_gen(torch_state, g);
+    } else {
+        for (int r = 0; r < n_rows; ++r) {
+            Gen g;
+            std::memcpy(&g, snapshots + (size_t)r * sizeof(Gen), sizeof(Gen));
+            fill_any(g, row_len - head, out + (long)r * row_len + head);
+        }
+    }
+    return 0;
 }

@@ -224,13 +224,28 @@ def main():
         raise SystemExit(3)
 
     # ---- untimed: per-stack latency as SURVEY.md 8(d) defines it (first host call -> device idle), median of 20
-    lat, lat_render = [], []
-    for i in range(20):
+    lat, lat_render, lat_one_pass = [], [], []
+    if ring is None:
+        # a LONE stack on its own plan (what a caller without a pipeline gets); beside it the opt-in two-pass draw order (focus draws,
+        # refocus launch, PSF rows behind it: StackPlan.two_pass - measured slower)
+        from aadff.focal_stack import StackPlan, render_focal_stack_m1 as _rfs1
+        lplan = StackPlan(lens, S, H, W, 1, 3, GRID, KS, SPP)
+        for two_pass, acc in ((False, lat), (True, lat_one_pass)):
+            lplan.two_pass = two_pass
+            for i in range(24):
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                torch.manual_seed(i)
+                _rfs1(lens, img, dbar, fds, GRID, KS, SPP, plan=lplan, update_lens=False)
+                torch.cuda.synchronize(dev)
+                if i >= 4:
+                    acc.append(time.perf_counter() - t1)
+        lplan.check_flags()
+    for i in range(20 if ring is not None else 0):
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         step(i)
-        if ring is not None:
-            ring.drain()
+        ring.drain()
         torch.cuda.synchronize(dev)
         lat.append(time.perf_counter() - t1)
     for i in range(20 if ring is None else 0):   # the same with the seed outside the window (torch.manual_seed walks the device generators too)
@@ -314,6 +329,7 @@ def main():
             # SURVEY.md 8(d)'s metric as defined there: S x H x W / (first host call -> device idle, one stack, median of 20)
             "value_survey_8d": round(S * H * W / 1e6 / float(np.median(lat)), 2),
             "latency_ms_p50_render_call_only": round(float(np.median(lat_render)) * 1e3, 4) if lat_render else None,
+            "latency_ms_p50_two_pass_draws": round(float(np.median(lat_one_pass)) * 1e3, 4) if lat_one_pass else None,
             "streams": n_streams,
             "one_stream": {"ms_per_step": round(one_stream_ms, 4), "value": round(S * H * W / 1e6 / (one_stream_ms * 1e-3), 2), "steps": n_one,
                            "what": "the same step queued on ONE HIP stream (every kernel alone on the device; untimed leg of this rank)"},

@@ -507,6 +507,15 @@ int aadff_host_mt19937_uniform_f32(unsigned char* torch_state_host, long state_b
  * call order of a stack) instead of producing and dropping them. */
 int aadff_host_mt19937_discard(unsigned char* torch_state_host, long state_bytes, long n);
 
+/* HOST routine: the [n_rows][row_len] block of draws that starts at the generator's position, produced in TWO passes - phase 0: the
+ * first `head` draws of every row (the rest skipped, a 2504-byte generator snapshot per row kept in `snapshots`), the state left
+ * behind the whole block as torch.rand(n_rows * row_len) would; phase 1: the remaining row_len - head draws of every row from the
+ * snapshots.  Same block as one pass, bit for bit.  For a focal stack the heads are the focus draws (torch.rand(2048) twice per
+ * slice, deeplens/surfaces.py:192-193 via optics.py:1166): the refocus launch can start after phase 0 while phase 1 fills the PSF
+ * rows (deeplens/optics.py:480-481) behind it. */
+int aadff_host_mt19937_rows(unsigned char* torch_state_host, long state_bytes, int n_rows, long row_len, long head, float* out_host,
+                            unsigned char* snapshots_host, int phase);
+
 #ifdef __cplusplus
 }
 #endif

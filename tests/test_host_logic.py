@@ -713,3 +713,27 @@ def test_strict_count_table_logic():
     both = np.array([[[10, 4, 4, 4], [10, 4, 5, 3]]])                                                    # [batch, phase, surface]
     ok, fix = check_counts(np.stack([seen(both[0, 0]), seen(both[0, 1])])[None], both, cur, range(4))
     assert ok.tolist() == [[False, True]] and fix.tolist() == [[[10, 4, 5, 4], [10, 4, 5, 3]]]
+
+
+def test_two_pass_row_draws_equal_one_pass_bit_exactly():
+    """aadff_host_mt19937_rows (round 5: the focus draws of every slice first, the PSF rows from per-row generator snapshots behind
+    the refocus launch): the block equals torch.rand of the whole block bit for bit, the heads alone after pass 1, and torch's
+    generator is left exactly where the single draw leaves it - for the bench layout and for ragged sizes that straddle the
+    generator's 624-word regenerations."""
+    import ctypes as C
+    from aadff import _abi
+    lib = _abi.load_library()
+    for S, per, head, seed in ((10, 20480, 4096, 5), (3, 1000, 7, 1), (4, 624, 624, 2), (5, 625, 0, 3), (1, 5, 2, 4)):
+        torch.manual_seed(seed)
+        torch.rand(11)                                       # a generator that is not at a regeneration boundary
+        st0 = torch.get_rng_state()
+        want = torch.rand(S * per)
+        after = torch.get_rng_state()
+        st = st0.clone()
+        out = torch.full((S * per,), -1.0)
+        snaps = torch.empty(S * 2504, dtype=torch.uint8)
+        assert lib.aadff_host_mt19937_rows(C.c_void_p(st.data_ptr()), st.numel(), S, per, head, C.c_void_p(out.data_ptr()), C.c_void_p(snaps.data_ptr()), 0) == 0
+        assert torch.equal(st, after)
+        assert torch.equal(out.view(S, per)[:, :head], want.view(S, per)[:, :head]) and bool((out.view(S, per)[:, head:] == -1).all())
+        assert lib.aadff_host_mt19937_rows(None, 5056, S, per, head, C.c_void_p(out.data_ptr()), C.c_void_p(snaps.data_ptr()), 1) == 0
+        assert torch.equal(out, want)
