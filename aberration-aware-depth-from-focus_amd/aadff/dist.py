@@ -90,6 +90,83 @@ def grouped():
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced_group())
 
 
+def _cpulist(text):
+    out = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_cpus(local_rank, sysfs="/sys"):
+    """(pci address, NUMA node, CPUs of that node) of the local_rank-th AMD GPU in PCI-bus order - the order HIP enumerates in -
+    read from sysfs WITHOUT touching the GPU; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES index lists are honoured.  None when the
+    tree does not say (no amdgpu devices, NUMA node -1, ...)."""
+    base = os.path.join(sysfs, "bus", "pci", "drivers", "amdgpu")
+    try:
+        addrs = sorted(a for a in os.listdir(base) if a.count(":") == 2)
+    except OSError:
+        return None
+    gpus = []
+    for a in addrs:
+        try:
+            cls = open(os.path.join(base, a, "class")).read().strip()
+        except OSError:
+            cls = ""
+        if cls.startswith("0x03") or cls.startswith("0x12") or not cls:      # display controllers / processing accelerators
+            gpus.append(a)
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+        vis = os.environ.get(var, "").strip()
+        if vis and all(v.strip().isdigit() for v in vis.split(",")):
+            idx = [int(v) for v in vis.split(",")]
+            if all(i < len(gpus) for i in idx):
+                gpus = [gpus[i] for i in idx]
+    if not 0 <= local_rank < len(gpus):
+        return None
+    addr = gpus[local_rank]
+    try:
+        node = int(open(os.path.join(base, addr, "numa_node")).read().strip())
+        if node < 0:
+            return addr, node, set()
+        cpus = _cpulist(open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")).read())
+    except (OSError, ValueError):
+        return None
+    return addr, node, cpus
+
+
+def pin_to_gpu_numa(local_rank=None, sysfs="/sys", announce=True):
+    """Restrict this process (every thread it starts later) to the CPUs of the NUMA node its GPU hangs off - BEFORE the first GPU
+    call, so that the runtime's helper threads and the pinned staging blocks land there too: a rank spends ~0.3 ms of host work per
+    stack and its kernels read pinned memory over PCIe.  Leaves the affinity alone when sysfs does not name a node or the node's
+    CPUs are outside the cgroup's set.  One placement line per rank goes to stderr.  AADFF_NUMA_PIN=0 switches it off."""
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else int(local_rank)
+    rank = os.environ.get("RANK", "0")
+    line = f"aadff placement: rank {rank} (local {local_rank}) pid {os.getpid()}"
+    try:
+        have = os.sched_getaffinity(0)
+        info = None if os.environ.get("AADFF_NUMA_PIN", "1") == "0" else gpu_numa_cpus(local_rank, sysfs)
+        if info is None:
+            line += f": no NUMA information, affinity unchanged ({len(have)} CPUs)"
+        else:
+            addr, node, cpus = info
+            use = cpus & have
+            if node < 0 or not use:
+                line += f": GPU {addr} NUMA node {node}, affinity unchanged ({len(have)} CPUs)"
+            else:
+                os.sched_setaffinity(0, use)
+                line += f": GPU {addr} on NUMA node {node}, pinned to {len(use)} of its {len(cpus)} CPUs ({min(use)}..{max(use)})"
+    except (OSError, AttributeError, ValueError) as e:      # never a reason to fail a run
+        line += f": affinity unchanged ({e!r})"
+    if announce:
+        print(line, file=sys.stderr, flush=True)
+    return line
+
+
+INIT_EXIT_CODE = 17
+
+
 def init_from_env(backend=None, device=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
     Returns (rank, world).  Single-process runs need no group (AADFF_FORCE_GROUP=1 forms one all the same: `forced_group`).
@@ -104,26 +181,54 @@ def init_from_env(backend=None, device=None):
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(free_port()))
-        if backend == "nccl":
-            # RCCL writes a version banner ("RCCL version : ...", five lines) to STDOUT through C stdio when its first communicator
-            # comes up - behind whatever Python has printed by then, since C stdio is flushed at exit.  bench.py's contract is ONE
-            # JSON line on stdout: bring the communicator up here with fd 1 pointing at stderr, flush C stdio, restore.
-            import ctypes
-            sys.stdout.flush()
-            keep = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                dist.init_process_group(backend, rank=rank, world_size=world, **kw)
-                t = torch.zeros(1, device=device if device is not None else "cuda")
-                dist.all_reduce(t)
-                torch.cuda.synchronize()
-                ctypes.CDLL(None).fflush(None)
-            finally:
-                os.dup2(keep, 1)
-                os.close(keep)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        # A rendezvous that does not complete (a peer that never started, a wrong MASTER_ADDR, RCCL stuck bringing a link up) must
+        # end the job with a message and a non-zero status, not hang the launcher: the store timeout covers the TCP rendezvous, the
+        # watchdog the communicator bring-up behind it.  The process EXITS (a fresh child is the launcher's business); it never
+        # re-executes itself - it may already have touched the GPU.
+        import datetime
+        import threading
+        limit = float(os.environ.get("AADFF_INIT_TIMEOUT_S", "120"))
+        kw["timeout"] = datetime.timedelta(seconds=limit)
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(limit + 5.0):
+                print(f"aadff: rank {rank} of {world}: process group ({backend}) not up after {limit:.0f} s "
+                      f"(MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')}); giving up", file=sys.stderr, flush=True)
+                os._exit(INIT_EXIT_CODE)
+
+        threading.Thread(target=watchdog, daemon=True, name="aadff-init-watchdog").start()
+        try:
+            _init_group(backend, rank, world, device, kw)
+        except Exception as e:
+            print(f"aadff: rank {rank} of {world}: init_process_group({backend}) failed: {e!r} "
+                  f"(MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')})", file=sys.stderr, flush=True)
+            done.set()
+            raise SystemExit(INIT_EXIT_CODE)
+        done.set()
     return rank, world
+
+
+def _init_group(backend, rank, world, device, kw):
+    if backend == "nccl":
+        # RCCL writes a version banner ("RCCL version : ...", five lines) to STDOUT through C stdio when its first communicator
+        # comes up - behind whatever Python has printed by then, since C stdio is flushed at exit.  bench.py's contract is ONE
+        # JSON line on stdout: bring the communicator up here with fd 1 pointing at stderr, flush C stdio, restore.
+        import ctypes
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+            t = torch.zeros(1, device=device if device is not None else "cuda")
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            os.dup2(keep, 1)
+            os.close(keep)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
 
 def shard_units(n_units, rank, world, block=1):

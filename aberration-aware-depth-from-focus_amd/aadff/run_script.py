@@ -42,6 +42,7 @@ def main(argv=None):
         return 2
     script = prepare(argv[0])
     sys.argv = [script] + argv[1:]
+    sys.dont_write_bytecode = True          # the script's own imports resolve inside the reference checkout: leave no __pycache__ there
     runpy.run_path(script, run_name="__main__")
     return 0
 

@@ -95,7 +95,10 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
                                                            Coord coord, int* __restrict__ flags) {
     constexpr int PLANE = TP * AP;                                              // halves per activation plane
     // end of the kernel: fp32 PSFs [TP][132] and, behind them, the image window of the gather [3][11][TP + 10] (EPI_FLOATS)
-    constexpr int EPI_FLOATS = TP * 132 + 3 * 11 * (TP + 10);
+    // The window only exists where it is free: in the fp32-equivalent mode the two activation planes (64 KB at TP = 64) dominate; in
+    // the fp16 single-pass mode it would raise the workgroup's LDS from 33.8 to 43.6 KB and cost a resident workgroup per CU
+    constexpr bool WINDOW = !SINGLE;
+    constexpr int EPI_FLOATS = TP * 132 + (WINDOW ? 3 * 11 * (TP + 10) : 0);
     constexpr int ACT_HALVES = (SINGLE ? 1 : 2) * PLANE > EPI_FLOATS * 2 ? (SINGLE ? 1 : 2) * PLANE : EPI_FLOATS * 2;
     __shared__ __attribute__((aligned(16))) _Float16 act_raw[ACT_HALVES];      // [hi | lo] planes; reused for the fp32 PSFs [TP][132] at the end
     _Float16* const act[2] = {act_raw, act_raw + (SINGLE ? 0 : PLANE)};
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(NTH, TP == 128 ? 2 : 4) void psfnet_fused_kernel(co
     AADFF_PN_STAMP(0);
     // gather mode, <= 3 channels, all TP pixels of the workgroup inside one row of one image (workgroup-uniform): the epilogue
     // stages the image window in LDS
-    const bool row_tile = mode == 1 && C <= 3 && p0 + TP <= P && (int)((p0 % ((long)H * W)) % W) + TP <= W;
+    const bool row_tile = WINDOW && mode == 1 && C <= 3 && p0 + TP <= P && (int)((p0 % ((long)H * W)) % W) + TP <= W;
 
     // ---- layer-0 input: features 0..3, zero-padded to 32 ----
     for (int e = tid; e < TP * 8; e += NTH) {                                   // 8 groups of 4 halves per pixel and plane

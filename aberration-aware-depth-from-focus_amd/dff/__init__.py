@@ -58,7 +58,12 @@ def _load_consumers():
             loaded = _ilu.module_from_spec(spec)
             _sys.modules[f"dff.{mod}"] = loaded
             try:
-                spec.loader.exec_module(loaded)
+                keep = _sys.dont_write_bytecode
+                _sys.dont_write_bytecode = True            # nothing is ever written into the user's (possibly read-only) checkout
+                try:
+                    spec.loader.exec_module(loaded)
+                finally:
+                    _sys.dont_write_bytecode = keep
             except Exception as e:                                  # e.g. skimage missing for metrics.py
                 del _sys.modules[f"dff.{mod}"]
                 loaded, why = None, f"Loading {path} failed: {type(e).__name__}: {e}"

@@ -122,6 +122,9 @@ def main():
         # Self-launch: one child per rank, started BEFORE this process has made any GPU call (it never makes one).
         from aadff.dist import spawn_ranks
         raise SystemExit(spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus, emulate=args.emulate_ranks))
+    # every rank onto the CPUs of its GPU's NUMA node, before the first GPU call (one placement line per rank on stderr)
+    from aadff.dist import pin_to_gpu_numa
+    pin_to_gpu_numa()
     # the GPU box exposes 256 logical CPUs under a 16-CPU cgroup quota: unbounded OpenMP pools stall small torch CPU ops
     torch.set_num_threads(max(1, usable_cpus() // max(1, int(os.environ.get("WORLD_SIZE", "1")))))
     if args.mode == "m2":
@@ -211,6 +214,20 @@ def main():
         ring.drain()
     barrier()
     dt = adist.all_reduce_max(time.perf_counter() - t0)
+
+    # ---- untimed SOAK leg: the same pipelined step for >= 1 s, so that a sampler with a coarse cadence (the driver's gpu_busy reading,
+    # rocm-smi) sees the GPU under this load at all - the timed region of the default command is ~7 ms
+    soak_s = float(os.environ.get("AADFF_BENCH_SOAK_S", "1.0"))
+    n_soak, t_soak = 0, time.perf_counter()
+    while time.perf_counter() - t_soak < soak_s:
+        for i in range(64):
+            step(n_soak + i)
+        n_soak += 64
+        torch.cuda.synchronize(dev)
+    if ring is not None:
+        ring.drain()
+    torch.cuda.synchronize(dev)
+    soak_ms = (time.perf_counter() - t_soak) / max(n_soak, 1) * 1e3
 
     # ---- untimed: kernel error flags of every step so far (NaN residual / no valid chief ray -> the number is void)
     torch.cuda.synchronize(dev)
@@ -309,7 +326,7 @@ def main():
         have = file_sha256(os.path.join(REPO, "aberration-aware-depth-from-focus_amd", "csrc", source))
         if dj.get("code_sha256", {}).get(source) != have:
             return None, (f"stale: profiles/{name} was collected on another build of csrc/{source} (digest "
-                          f"{str(dj.get('code_sha256', {}).get(source))[:12]}, this tree {have[:12]}); re-run tools/prof_r04.sh + tools/summarise_profiles.py")
+                          f"{str(dj.get('code_sha256', {}).get(source))[:12]}, this tree {have[:12]}); re-run tools/prof_r05.sh + tools/summarise_profiles.py")
         return dj, f"profiles/{name} (rocprofv3 PMC passes of this command on this build of csrc/{source}, sha256 {have[:12]}; not measured in this run)"
     tj, traffic_source = digest("conv_traffic.json", "conv.hip")
     traffic = tj.get("hbm_bytes_per_launch") if tj else None
@@ -331,6 +348,8 @@ def main():
             "latency_ms_p50_render_call_only": round(float(np.median(lat_render)) * 1e3, 4) if lat_render else None,
             "latency_ms_p50_two_pass_draws": round(float(np.median(lat_one_pass)) * 1e3, 4) if lat_one_pass else None,
             "streams": n_streams,
+            "soak": {"ms_per_step": round(soak_ms, 4), "steps": n_soak, "seconds": round(soak_ms * n_soak / 1e3, 2),
+                     "what": "the same pipelined step queued for >= 1 s after the timed region (untimed leg; synchronised every 64 steps)"},
             "one_stream": {"ms_per_step": round(one_stream_ms, 4), "value": round(S * H * W / 1e6 / (one_stream_ms * 1e-3), 2), "steps": n_one,
                            "what": "the same step queued on ONE HIP stream (every kernel alone on the device; untimed leg of this rank)"},
             "config": {"workload": "rf50mm, 1024x1024 synthetic RGB + depth plane, 10 focus distances, 11x11 PSF grid, "

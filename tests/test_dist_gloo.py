@@ -223,3 +223,45 @@ def test_config5_call_pattern_ddp_consumer_with_rank_local_stacks(tmp_path):
     spec.loader.exec_module(ex)
     init = [p.detach() for p in ex.TinyDFF(4).parameters()]
     assert any(not torch.equal(x, y) for x, y in zip(a, init))             # and they did train
+
+
+def test_numa_pinning_reads_sysfs_without_touching_the_gpu(tmp_path, monkeypatch, capsys):
+    """aadff.dist.pin_to_gpu_numa: rank r's threads go to the NUMA node of GPU r - from a fake sysfs tree: PCI-bus
+    order = HIP's enumeration order, HIP_VISIBLE_DEVICES honoured, node -1 / CPUs outside the cgroup set leave the affinity alone,
+    a missing tree is not an error; one placement line per rank."""
+    from aadff import dist as adist
+    sysfs = tmp_path / "sys"
+    drv = sysfs / "bus" / "pci" / "drivers" / "amdgpu"
+    for addr, node in (("0000:05:00.0", 0), ("0000:25:00.0", 0), ("0000:85:00.0", 1), ("0000:a5:00.0", -1)):
+        d = drv / addr
+        d.mkdir(parents=True)
+        (d / "class").write_text("0x120000\n")
+        (d / "numa_node").write_text(f"{node}\n")
+    (drv / "module").mkdir()                                             # a non-device entry of the driver directory
+    for node, cpus in ((0, "0-3,8-11"), (1, "4-7,12-15")):
+        n = sysfs / "devices" / "system" / "node" / f"node{node}"
+        n.mkdir(parents=True)
+        (n / "cpulist").write_text(cpus + "\n")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    assert adist.gpu_numa_cpus(0, str(sysfs)) == ("0000:05:00.0", 0, {0, 1, 2, 3, 8, 9, 10, 11})
+    assert adist.gpu_numa_cpus(2, str(sysfs))[:2] == ("0000:85:00.0", 1)
+    assert adist.gpu_numa_cpus(3, str(sysfs)) == ("0000:a5:00.0", -1, set())
+    assert adist.gpu_numa_cpus(4, str(sysfs)) is None and adist.gpu_numa_cpus(0, str(tmp_path / "nothing")) is None
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
+    assert adist.gpu_numa_cpus(0, str(sysfs))[0] == "0000:85:00.0" and adist.gpu_numa_cpus(1, str(sysfs))[0] == "0000:05:00.0"
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    calls = []
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(0, 6)))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: calls.append(set(cpus)))
+    monkeypatch.setenv("RANK", "2")
+    line = adist.pin_to_gpu_numa(2, str(sysfs))
+    assert calls == [{4, 5}] and "NUMA node 1" in line and "rank 2" in line       # node 1's CPUs inside the cgroup's set
+    assert "rank 2" in capsys.readouterr().err
+    calls.clear()
+    adist.pin_to_gpu_numa(3, str(sysfs), announce=False)                            # node -1
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {20, 21})
+    adist.pin_to_gpu_numa(0, str(sysfs), announce=False)                            # nothing of node 0 is usable
+    monkeypatch.setenv("AADFF_NUMA_PIN", "0")
+    adist.pin_to_gpu_numa(2, str(sysfs), announce=False)
+    assert calls == []

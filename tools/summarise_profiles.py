@@ -10,8 +10,18 @@ G, P = os.path.join(REPO, "gpurun_out"), os.path.join(REPO, "profiles")
 
 
 def code_sha256(*sources):
-    """sha256 of the kernel sources a digest belongs to: bench.py quotes a digest only while the tree still holds these sources."""
+    """sha256 of the kernel sources a digest belongs to: bench.py quotes a digest only while the tree still holds these sources.
+    Taken from gpurun_out/<tag>_code_sha256.json when the collection script wrote it AT COLLECTION TIME (tools/prof_r05.sh: the
+    sources, common.h, include/aadff.h and the libaadff.so that ran - ADVICE r4: a digest summarised after an edit must not be
+    stamped with the new hash); hashing the tree now is the fallback for older collections."""
     import hashlib
+    stamp = os.path.join(G, f"{tag}_code_sha256.json")
+    if os.path.exists(stamp):
+        rec = json.load(open(stamp))
+        out = {src: rec[src] for src in sources if src in rec}
+        out.update({k: rec[k] for k in ("common.h", "aadff.h", "libaadff.so") if k in rec})
+        if all(src in out for src in sources):
+            return out
     out = {}
     for src in sources:
         with open(os.path.join(REPO, "aberration-aware-depth-from-focus_amd", "csrc", src), "rb") as f:
@@ -52,16 +62,25 @@ def write_pmc(dst, sources, keep):
 
 
 for name, sub in (("kernel_stats", "stats"), ("kernel_stats_1stream", "stats_s1"), ("fit_kernel_stats", "fit_stats"), ("local_psf_kernel_stats", "lp_stats"),
-                  ("single_kernel_stats", "single_stats"), ("strict_kernel_stats", "strict_stats")):
+                  ("single_kernel_stats", "single_stats"), ("strict_kernel_stats", "strict_stats"), ("m1l_kernel_stats", "m1l_stats"),
+                  ("dropin_kernel_stats", "dropin_stats")):
     src = one(f"{tag}_{sub}/**/*_kernel_stats.csv")
     if src:
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.csv"))
 for name in ("bench", "bench_fit", "bench_m2", "bench_2streams", "bench_refocus_overlap", "bench_1stream", "bench_c3", "bench_under_rocprof",
              "conv_timeline", "conv_timeline_paired", "parity_per_slice_shipped", "parity_per_slice_literal", "parity_per_slice_strict",
-             "conv_single_timeline", "conv_single_timeline_toeplitz", "bench_rccl1_gather"):
+             "conv_single_timeline", "conv_single_timeline_toeplitz", "bench_rccl1_gather", "bench_m1l", "code_sha256"):
     src = os.path.join(G, f"{tag}_{name}.json")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.json"))
+
+for name in ("conv_ks_sweep", "strict_profile", "kbench", "dropin"):
+    src = os.path.join(G, f"{tag}_{name}.txt")
+    if os.path.exists(src) and os.path.getsize(src):
+        shutil.copy(src, os.path.join(P, f"{tag}_{name}.txt"))
+sp_ = one(f"{tag}_strict_pmc/**/*counter_collection.csv")
+if sp_:
+    write_pmc(os.path.join(P, f"{tag}_strict_kernel_pmc.csv"), [sp_], ("fused_psf_kernel", "fused_flat_kernel"))
 
 rows = write_pmc(os.path.join(P, f"{tag}_psf_kernel_pmc.csv"),
                  [one(f"{tag}_psf_pmc1/**/*counter_collection.csv"), one(f"{tag}_psf_pmc2/**/*counter_collection.csv")], ("psf_points_kernel",))
