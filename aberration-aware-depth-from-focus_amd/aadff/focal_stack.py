@@ -124,13 +124,6 @@ class StackPlan:
         self.stage_counters = torch.zeros(S, dtype=torch.int32, device=dev)
         self.refocus_scratch = torch.zeros(S * 16, dtype=torch.int32, device=dev)     # 64 B per focus state
         self.stage_generation = 0
-        # two-pass host draws (focus draws first, PSF rows behind the refocus launch), OPT-IN: measured 0.547 ms against
-        # 0.490 ms per lone stack with the single pass (profiles/r05_latency_two_pass.json).  MT19937 cannot skip cheaply: "discarding"
-        # the 164 k PSF draws still runs their 263 state regenerations, which is where the generator's time goes (tempering and
-        # conversion are the cheap part), so pass 1 costs what the whole fill costs, and every slice's block then has to ride on the
-        # PSF launch instead of three of them hiding behind the focus traces.
-        self.two_pass = os.environ.get("AADFF_TWO_PASS_DRAWS", "0") == "1"
-        self.snapshots = None
         self._geo = {}
 
     def uniforms(self, sampler):
@@ -166,38 +159,11 @@ class StackPlan:
             if g is not None:
                 g.synchronize()
                 self._poll_mirror()                          # flags of every step up to that guard, no extra sync
-        if sampler is None:                          # two-pass draws: the caller fills the block (draw_heads / draw_rest)
-            return self.u_pin[k], self.u_dev[k]
         if hasattr(sampler, "rand_into"):
             sampler.rand_into(self.u_pin[k])
         else:
             self.u_pin[k].copy_(sampler.rand_block([self.S * self.per]))
         return self.u_pin[k], self.u_dev[k]
-
-    def draw_heads(self, u_pin):
-        """Pass 1 of the two-pass draw (aadff_host_mt19937_rows): the 2 x 2048 focus draws at the head of every slice's block - all the
-        refocus launch needs - with the PSF rows skipped and a generator snapshot kept per slice; torch's generator is left where
-        torch.rand of the whole block would leave it.  False when the fast generator path is unavailable."""
-        from . import sampling
-        if sampling._FAST is None:
-            sampling._fast_host_rand_into(torch.empty(0))    # runs the one-time self-check
-        if sampling._FAST is not True:
-            return False
-        if self.snapshots is None:
-            self.snapshots = torch.empty(self.S * 2504, dtype=torch.uint8)
-        st = torch.get_rng_state()
-        rc = _abi.load_library().aadff_host_mt19937_rows(C.c_void_p(st.data_ptr()), st.numel(), self.S, self.per, 2 * GEO_SPP,
-                                                         C.c_void_p(u_pin.data_ptr()), C.c_void_p(self.snapshots.data_ptr()), 0)
-        if rc != 0:
-            return False
-        torch.set_rng_state(st)
-        return True
-
-    def draw_rest(self, u_pin):
-        """Pass 2: the PSF rows of every slice from the snapshots, while the focus traces run."""
-        rc = _abi.load_library().aadff_host_mt19937_rows(None, 5056, self.S, self.per, 2 * GEO_SPP, C.c_void_p(u_pin.data_ptr()),
-                                                         C.c_void_p(self.snapshots.data_ptr()), 1)
-        assert rc == 0
 
     def staged(self):
         """End of a staged step: every GUARD_EVERY-th step records the event later reuses of the pinned blocks wait on
@@ -318,15 +284,9 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
                       plan.lc, _abi.ptr(plan.states), st)
         else:       # host draws: the upload rides on the refocus launch
             slot = plan.turn % plan.RING
-            # two-pass draws (single-stack latency): only the focus draws precede the refocus launch, the PSF rows are filled behind
-            # it and every slice's block rides on the PSF launch
-            two_pass = plan.two_pass and type(lens.sampler).__name__ == "HostSampler"
-            u_pin, u = plan.uniforms_host(None if two_pass else lens.sampler)    # waits (host) until the stack that last used this slot is done
-            if two_pass and not plan.draw_heads(u_pin):
-                two_pass = False
-                lens.sampler.rand_into(u_pin)
+            u_pin, u = plan.uniforms_host(lens.sampler)          # waits (host) until the stack that last used this slot is done
             ub = u.data_ptr()
-            first = 0 if two_pass else min(S, STAGE_FIRST)
+            first = min(S, STAGE_FIRST)
             plan.states = plan.states_ring[slot]
             rst = st
             if plan.side is not None:
@@ -338,8 +298,6 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
                 rst = C.c_void_p(plan.side.cuda_stream)
             _abi.call("aadff_refocus_staged", _abi.ptr(dep), S, C.c_void_p(u_pin.data_ptr()), C.c_void_p(ub), first * plan.per,
                       GEO_SPP, plan.per, _abi.ptr(plan.tab_green), plan.lc, _abi.ptr(plan.states), _abi.ptr(plan.refocus_scratch), rst)
-            if two_pass:
-                plan.draw_rest(u_pin)
             if plan.side is not None:
                 ev = plan.side_events[slot]
                 ev.record(plan.side)
@@ -406,8 +364,6 @@ class StackPipeline:
         if overlap_refocus is None:
             overlap_refocus = REFOCUS_OVERLAP and self.depth == 1      # with >= 2 streams the other stack already fills the gap
         self.plans = [StackPlan(lens, S, H, W, B, C_, grid, ks, spp, overlap_refocus=overlap_refocus) for _ in range(self.depth)]
-        for p in self.plans:
-            p.two_pass = p.two_pass and self.depth == 1      # several stacks in flight: the host is off the path (see StackPlan.two_pass)
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.depth)] if self.depth > 1 else [None]
         self.done = [None] * self.depth
         self.turn = 0

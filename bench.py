@@ -122,6 +122,9 @@ def main():
         # Self-launch: one child per rank, started BEFORE this process has made any GPU call (it never makes one).
         from aadff.dist import spawn_ranks
         raise SystemExit(spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus, emulate=args.emulate_ranks))
+    if os.environ.get("AADFF_BENCH_HANG_DUMP_S"):           # debugging aid: every thread's stack after N seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["AADFF_BENCH_HANG_DUMP_S"]), exit=True)
     # every rank onto the CPUs of its GPU's NUMA node, before the first GPU call (one placement line per rank on stderr)
     from aadff.dist import pin_to_gpu_numa
     pin_to_gpu_numa()
@@ -241,22 +244,19 @@ def main():
         raise SystemExit(3)
 
     # ---- untimed: per-stack latency as SURVEY.md 8(d) defines it (first host call -> device idle), median of 20
-    lat, lat_render, lat_one_pass = [], [], []
+    lat, lat_render = [], []
     if ring is None:
-        # a LONE stack on its own plan (what a caller without a pipeline gets); beside it the opt-in two-pass draw order (focus draws,
-        # refocus launch, PSF rows behind it: StackPlan.two_pass - measured slower)
+        # a LONE stack on its own plan: what a caller without a pipeline gets
         from aadff.focal_stack import StackPlan, render_focal_stack_m1 as _rfs1
         lplan = StackPlan(lens, S, H, W, 1, 3, GRID, KS, SPP)
-        for two_pass, acc in ((False, lat), (True, lat_one_pass)):
-            lplan.two_pass = two_pass
-            for i in range(24):
-                torch.cuda.synchronize(dev)
-                t1 = time.perf_counter()
-                torch.manual_seed(i)
-                _rfs1(lens, img, dbar, fds, GRID, KS, SPP, plan=lplan, update_lens=False)
-                torch.cuda.synchronize(dev)
-                if i >= 4:
-                    acc.append(time.perf_counter() - t1)
+        for i in range(24):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            torch.manual_seed(i)
+            _rfs1(lens, img, dbar, fds, GRID, KS, SPP, plan=lplan, update_lens=False)
+            torch.cuda.synchronize(dev)
+            if i >= 4:
+                lat.append(time.perf_counter() - t1)
         lplan.check_flags()
     for i in range(20 if ring is not None else 0):
         torch.cuda.synchronize(dev)
@@ -346,7 +346,6 @@ def main():
             # SURVEY.md 8(d)'s metric as defined there: S x H x W / (first host call -> device idle, one stack, median of 20)
             "value_survey_8d": round(S * H * W / 1e6 / float(np.median(lat)), 2),
             "latency_ms_p50_render_call_only": round(float(np.median(lat_render)) * 1e3, 4) if lat_render else None,
-            "latency_ms_p50_two_pass_draws": round(float(np.median(lat_one_pass)) * 1e3, 4) if lat_one_pass else None,
             "streams": n_streams,
             "soak": {"ms_per_step": round(soak_ms, 4), "steps": n_soak, "seconds": round(soak_ms * n_soak / 1e3, 2),
                      "what": "the same pipelined step queued for >= 1 s after the timed region (untimed leg; synchronised every 64 steps)"},
