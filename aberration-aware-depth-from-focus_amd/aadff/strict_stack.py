@@ -412,9 +412,10 @@ def _speculate_small(counts, key, st, lvl, S, n, curved, order, launch, stream):
 
 
 @torch.no_grad()
-def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None):
+def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None, draw_gate=None):
     """PSF maps [S,3,g*ks,g*ks] (device) of a strict-parity lens for the focus distances `focus`, all field points on the plane
-    `depth_plane_mm`; leaves the lens focused at the last distance, like the reference's loop."""
+    `depth_plane_mm`; leaves the lens focused at the last distance, like the reference's loop.  `draw_gate`: a context manager the
+    stack's host draws are taken under (StrictPipeline: stacks rendered by several threads draw in submission order)."""
     from .focal_stack import stack_uniform_layout
     if ks > _abi.MAX_KS:
         raise ValueError(f"ks={ks} exceeds the kernels' limit {_abi.MAX_KS}")
@@ -437,7 +438,11 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None):
 
     # ---- the stack's draws, in the reference's order (one flat draw = the same generator stream as call by call)
     per, o_main, o_chief, per_l = stack_uniform_layout(spp, L)
-    u = lens.sampler.rand_block([S * per]).cpu().reshape(S, per)
+    if draw_gate is None:
+        u = lens.sampler.rand_block([S * per]).cpu().reshape(S, per)
+    else:
+        with draw_gate:
+            u = lens.sampler.rand_block([S * per]).cpu().reshape(S, per)
     uf = u[:, :2 * GEO_SPP].reshape(S, 2, GEO_SPP)
     rest = u[:, 2 * GEO_SPP:].reshape(S, L, per_l)
     um = rest[:, :, :2 * spp].reshape(S, L, 2, spp)
@@ -610,3 +615,61 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None):
         lens._state_upload()
     lens._strict_stack_scalars = {"d_sensor": d_sensor, "hfov": hfov}
     return maps
+
+
+class StrictPipeline:
+    """Several strict-parity stacks in flight: `depth` host threads, each with its own strict `Lensgroup` (count table, staging
+    blocks) and HIP stream, so that the host side and the two short levels of stack k + 1 (launch and round-trip latency, ~2 ms) run
+    beside the psf_map launch of stack k (3-4 ms of GPU time).  Every stack's host draws are taken in SUBMISSION order (a ticket
+    gate), so the generator stream is the sequential loop's and every stack equals what `render_focal_stack_m1(strict_lens, ...)`
+    returns for it.  `submit(...)` returns a future of (stack [B,C,S,H,W], event recorded behind its last launch)."""
+
+    def __init__(self, make_lens, depth=2):
+        import threading
+        self.depth = int(depth)
+        self.lenses = [make_lens() for _ in range(self.depth)]
+        assert all(getattr(l, "parity", "") == "strict" for l in self.lenses), "StrictPipeline renders strict-parity lenses"
+        dev = self.lenses[0]._gpu()
+        self.streams = [torch.cuda.Stream(dev) for _ in range(self.depth)]
+        self.locks = [threading.Lock() for _ in range(self.depth)]
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.depth, thread_name_prefix="aadff-strict-pipe")
+        self.cv = threading.Condition()
+        self.next_draw = 0
+        self.turn = 0
+
+    class _Gate:
+        def __init__(self, pipe, k):
+            self.pipe, self.k = pipe, k
+
+        def __enter__(self):
+            with self.pipe.cv:
+                self.pipe.cv.wait_for(lambda: self.pipe.next_draw == self.k)
+
+        def __exit__(self, *a):
+            with self.pipe.cv:
+                self.pipe.next_draw = self.k + 1
+                self.pipe.cv.notify_all()
+
+    def _run(self, k, img, depth_plane_mm, focus_mm, grid, ks, spp):
+        from .focal_stack import render_focal_stack_m1
+        i = k % self.depth
+        gate = StrictPipeline._Gate(self, k)
+        try:
+            with self.locks[i], torch.cuda.stream(self.streams[i]):
+                out = render_focal_stack_m1(self.lenses[i], img, depth_plane_mm, focus_mm, grid, ks, spp, strict_draw_gate=gate)
+                ev = torch.cuda.Event()
+                ev.record(self.streams[i])
+            return out, ev
+        finally:
+            with self.cv:                                # a stack that failed before its draws must not block the ones behind it
+                if self.next_draw <= k:
+                    self.next_draw = k + 1
+                    self.cv.notify_all()
+
+    def submit(self, img, depth_plane_mm, focus_mm, grid=11, ks=11, spp=GEO_SPP):
+        k = self.turn
+        self.turn += 1
+        return self.pool.submit(self._run, k, img, depth_plane_mm, focus_mm, grid, ks, spp)
+
+    def close(self):
+        self.pool.shutdown(wait=True)

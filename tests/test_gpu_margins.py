@@ -536,3 +536,33 @@ def test_bf16_train_step_runs_and_tracks_fp32(repo_root, margin):
         assert np.isfinite(ls).all() and all(ls[9 + b] < ls[b] for b in range(3)), ls      # batch b: its 4th visit vs its 1st
         losses[bf16] = np.array(ls)
     margin("bf16 train step: |loss_bf16/loss_fp32 - 1| after 12 steps", abs(losses[True][-1] / losses[False][-1] - 1), 0.05)
+
+
+def test_strict_pipeline_equals_the_sequential_loop(repo_root, margin):
+    """aadff.strict_stack.StrictPipeline (round 5): two strict stacks in flight on two host threads / streams / lenses.  The host draws
+    are taken in submission order, so every stack equals the one the sequential loop renders from the same generator (PSF histograms
+    are float atomics: 2e-6 of the peak), and the generator ends where the loop leaves it."""
+    import time
+    from aadff.strict_stack import StrictPipeline
+    H = W = 256
+    S, grid, spp, n = 4, 5, 512, 6
+    depth = synth_depth_mm(H, W, seed=5678)
+    dbar, fds = -float(depth.mean()), [float(f) for f in -np.linspace(depth.min(), depth.max(), S)]
+    img = tt(synth_rgb(H, W, seed=3))[None].to(DEV)
+    make = lambda: Lensgroup(lp(repo_root), sensor_res=(H, W), device=DEV, parity="strict")
+    seq_lens = make()
+    torch.manual_seed(21)
+    want = [render_focal_stack_m1(seq_lens, img, dbar, fds, grid, 11, spp).clone() for _ in range(n)]
+    tail = torch.rand(1).item()
+    pipe = StrictPipeline(make, depth=2)
+    torch.manual_seed(21)
+    futs = [pipe.submit(img, dbar, fds, grid, 11, spp) for _ in range(n)]
+    got = []
+    for f in futs:
+        out, ev = f.result(timeout=120)
+        ev.synchronize()
+        got.append(out)
+    pipe.close()
+    assert torch.rand(1).item() == tail
+    worst = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(got, want))
+    margin("strict pipeline (2 stacks in flight) vs sequential loop, max |d| / max over 6 stacks", worst, 2e-6)
