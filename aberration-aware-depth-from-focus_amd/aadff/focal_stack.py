@@ -223,19 +223,19 @@ def _conv_into_units(x, maps, dest, B, C_, S, H, W, grid, ks, st):
     return units
 
 
-def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, draw_gate=None):
+def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp):
     """PSF maps [S,3,g*ks,g*ks] of a strict-parity lens in the reference's host-RNG order (2_aber_aware_dff_aif.py:104-114 with
     deeplens/optics.py:779-783): three batched traces for the whole stack (aadff/strict_stack.py); AADFF_STRICT_BATCHED=0 runs
     the reference's loop call by call (refocus(f_k) then psf_map per slice, 72 single traces per slice) - same result."""
     from . import strict_stack
     if os.environ.get("AADFF_STRICT_BATCHED", "1") == "0":
         return strict_stack.strict_psf_maps_loop(lens, depth_plane_mm, focus, grid, ks, spp)
-    return strict_stack.strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, draw_gate=draw_gate)
+    return strict_stack.strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp)
 
 
 @torch.no_grad()
 def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, spp=GEO_SPP, plan=None,
-                          return_maps=False, update_lens=True, dest=None, strict_draw_gate=None):
+                          return_maps=False, update_lens=True, dest=None):
     """[B,C,S,H,W] aberrated focal stack of `img` [B,C,H,W] for S focus distances (mm < 0),
     all scene points on one depth plane (mm < 0).  Three kernel launches, no host
     synchronisation; with a reused `plan` the output buffer is reused too.
@@ -253,7 +253,7 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
         dev = lens._gpu()
         keep = None if update_lens else _abi.LensState.from_buffer_copy(bytes(lens._state_sync()))
         try:
-            maps = strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, draw_gate=strict_draw_gate).to(dev).contiguous()
+            maps = strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp).to(dev).contiguous()
         finally:
             if keep is not None:                                 # update_lens=False: the lens stays focused where it was
                 lens._state_host = keep

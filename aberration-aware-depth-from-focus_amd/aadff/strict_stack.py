@@ -50,6 +50,68 @@ def _pupil_points(theta_u, r_u, radius, z):
     return torch.stack((r * torch.cos(theta), r * torch.sin(theta), torch.full_like(r, z)), -1)
 
 
+_SLEEF = []
+
+
+def _sleef():
+    """(cos, sin, sqrt addresses, kind) of the float32 vector cosine / sine torch's CPU kernels call on this machine (MKL's
+    vmsCos / vmsSin / vmsSqrt, kind 1, or Sleef's u10 routines of width 8 / 16 - all exported by libtorch_cpu.so), or None when they are not
+    there or their output differs from torch's own on a probe block (then the pupil points stay with torch: `_pupil_points`).  `aadff_host_pupil_points`
+    evaluates a stack's 70 batches of pupil points with them in three calls that hold no interpreter lock."""
+    if _SLEEF:
+        return _SLEEF[0]
+    got = None
+    try:
+        width = 1 if torch.backends.mkl.is_available() else {"AVX512": 16, "AVX2": 8}.get(torch.backends.cpu.get_cpu_capability())
+        if width is not None and os.environ.get("AADFF_STRICT_HOST_PUPIL", "1") != "0":
+            lib = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libtorch_cpu.so"))
+            names = ("vmsCos", "vmsSin", "vmsSqrt") if width == 1 else (f"Sleef_cosf{width}_u10", f"Sleef_sinf{width}_u10")
+            fn = [C.cast(getattr(lib, name), C.c_void_p) for name in names] + [None]
+            local = None
+            if width == 1:
+                # MKL's vector math may fan a 2048-element call out over its OpenMP team; from a second host thread that is a second
+                # team beside torch's (measured: 5 ms per call inside a CPU quota).  Thread-local setting, restored after each use.
+                local = lib.MKL_Set_Num_Threads_Local
+                local.argtypes, local.restype = [C.c_int], C.c_int
+            got = (fn[0], fn[1], fn[2], width, local)
+            g = torch.Generator().manual_seed(20261003)
+            n = 4099                                                      # not a multiple of the vector width: tails too
+            u = torch.rand(2 * n, generator=g)
+            u[:3] = torch.tensor([0.0, 1.0 - 2.0 ** -24, 2.0 ** -24])
+            for radius, z in ((6.789, -1.25), (torch.tensor(11.0317), 0.0)):
+                want = _pupil_points(u[:n], u[n:], radius, z)
+                have = torch.empty(n, 3)
+                _pupil_rows(got, u, np.array([0], dtype=np.int64), np.array([n], dtype=np.int64), n, radius, z, have)
+                if not torch.equal(want.view(torch.int32), have.view(torch.int32)):
+                    got = None
+                    break
+    except (OSError, AttributeError, RuntimeError):
+        got = None
+    _SLEEF.append(got)
+    return got
+
+
+def _pupil_rows(fns, u, theta_off, r_off, n, radius, z, out):
+    """rows of pupil points through `aadff_host_pupil_points`: row i from u[theta_off[i]:+n], u[r_off[i]:+n] into out[i] ([rows,n,3]
+    float32, contiguous, host); the scalars rounded exactly as `_pupil_points`' tensor-times-scalar operations round them"""
+    R2 = float(torch.ones((), dtype=torch.float32) * radius ** 2)
+    assert u.dtype == torch.float32 and u.is_contiguous() and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == len(theta_off) * n * 3
+    lib = _abi.load_library()
+    prev = fns[4](1) if fns[4] is not None else None
+    try:
+        rc = _pupil_call(lib, fns, u, theta_off, r_off, n, R2, z, out)
+    finally:
+        if prev is not None:
+            fns[4](prev)
+    if rc != 0:
+        raise RuntimeError("aadff_host_pupil_points failed: " + lib.aadff_last_error().decode(errors="replace"))
+
+
+def _pupil_call(lib, fns, u, theta_off, r_off, n, R2, z, out):
+    return lib.aadff_host_pupil_points(C.c_void_p(u.data_ptr()), len(theta_off), C.c_void_p(theta_off.ctypes.data), C.c_void_p(r_off.ctypes.data),
+                   n, float(np.float32(np.pi)), R2, float(np.float32(z)), C.c_void_p(out.data_ptr()), fns[0], fns[1], fns[2], fns[3])
+
+
 def _tables(lens, wvlns):
     """HOST copy of the packed surface tables of `wvlns`, cached with the lens's device tables (`Lensgroup.invalidate()` drops both:
     packing 36 surfaces costs 1.8 ms, an eighth of a strict stack)."""
@@ -342,6 +404,12 @@ class _Stage:
         self.bt_main = torch.arange(L, dtype=i32).repeat(S).to(dev)
         self.bt_green = torch.full((max(B, J),), t_green, dtype=i32, device=dev)
         self.zeros = torch.zeros(J, dtype=i32, device=dev)
+        # where the uniforms of every batch of pupil points sit in the stack's flat block of draws (stack_uniform_layout)
+        from .focal_stack import stack_uniform_layout
+        per, o_main, o_chief, per_l = stack_uniform_layout(spp, L)
+        sl = (np.arange(S, dtype=np.int64)[:, None] * per + np.arange(L, dtype=np.int64)[None, :] * per_l).reshape(-1)
+        self.off_focus = np.arange(S, dtype=np.int64) * per
+        self.off_main, self.off_chief = sl + o_main, sl + o_chief
 
     @staticmethod
     def of(lens, dev, S, L, N, spp, t_green):
@@ -350,13 +418,20 @@ class _Stage:
             st = lens._table_cache["strict-stage"] = _Stage(dev, S, L, N, spp, t_green)
         return st
 
-    def round_trip(self, i, n_up, n_down, launch, stream):
-        """upload the first n_up words of parameter block i, launch, download the first n_down result words and wait for them"""
-        self.d_par[i][:n_up].copy_(self.h_par[i][:n_up], non_blocking=True)
-        launch(self.d_par[i], self.d_res[i])
-        self.h_res[i][:n_down].copy_(self.d_res[i][:n_down], non_blocking=True)
+    def submit(self, i, n_up, n_down, launch, stream):
+        """enqueue: upload the first n_up words of parameter block i, launch, download the first n_down result words"""
+        with torch.cuda.stream(stream):
+            self.d_par[i][:n_up].copy_(self.h_par[i][:n_up], non_blocking=True)
+            launch(self.d_par[i], self.d_res[i])
+            self.h_res[i][:n_down].copy_(self.d_res[i][:n_down], non_blocking=True)
+
+    def wait(self, i, stream):
         stream.synchronize()
         return self.h_res[i].numpy()
+
+    def round_trip(self, i, n_up, n_down, launch, stream):
+        self.submit(i, n_up, n_down, launch, stream)
+        return self.wait(i, stream)
 
 
 def _ptr_at(t, word):
@@ -412,10 +487,21 @@ def _speculate_small(counts, key, st, lvl, S, n, curved, order, launch, stream):
 
 
 @torch.no_grad()
-def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None, draw_gate=None):
+def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None):
     """PSF maps [S,3,g*ks,g*ks] (device) of a strict-parity lens for the focus distances `focus`, all field points on the plane
-    `depth_plane_mm`; leaves the lens focused at the last distance, like the reference's loop.  `draw_gate`: a context manager the
-    stack's host draws are taken under (StrictPipeline: stacks rendered by several threads draw in submission order)."""
+    `depth_plane_mm`; leaves the lens focused at the last distance, like the reference's loop."""
+    steps = _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused)
+    try:
+        while True:
+            next(steps)
+    except StopIteration as done:
+        return done.value
+
+
+def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None):
+    """`strict_psf_maps` as a generator: yields once, right after the psf_map launch of the stack is queued (fused form only) - what
+    comes before is host arithmetic and the two short levels, what comes after waits for that launch.  `StrictPipeline` runs the
+    first half of the next stack in the gap.  Returns the maps (StopIteration.value)."""
     from .focal_stack import stack_uniform_layout
     if ks > _abi.MAX_KS:
         raise ValueError(f"ks={ks} exceeds the kernels' limit {_abi.MAX_KS}")
@@ -438,11 +524,7 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None, draw
 
     # ---- the stack's draws, in the reference's order (one flat draw = the same generator stream as call by call)
     per, o_main, o_chief, per_l = stack_uniform_layout(spp, L)
-    if draw_gate is None:
-        u = lens.sampler.rand_block([S * per]).cpu().reshape(S, per)
-    else:
-        with draw_gate:
-            u = lens.sampler.rand_block([S * per]).cpu().reshape(S, per)
+    u = lens.sampler.rand_block([S * per]).cpu().reshape(S, per)
     uf = u[:, :2 * GEO_SPP].reshape(S, 2, GEO_SPP)
     rest = u[:, 2 * GEO_SPP:].reshape(S, L, per_l)
     um = rest[:, :, :2 * spp].reshape(S, L, 2, spp)
@@ -462,8 +544,18 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None, draw
             st = _Stage.of(lens, dev, S, L, N, spp, t_green)
             # every pupil point of the stack comes from the reference's host calls; the focus ones ride in front of level 1
             hp = st.h_pupil
-            hp[:st.n_pf].view(S, GEO_SPP, 3).copy_(_pupil_points(uf[:, 0], uf[:, 1], s0.r, s0.d.item()))
-            st.d_pupil[:st.n_pf].copy_(hp[:st.n_pf], non_blocking=True)
+            vec = _sleef()
+            if vec is not None:
+                _pupil_rows(vec, u, st.off_focus, st.off_focus + GEO_SPP, GEO_SPP, s0.r, s0.d.item(), hp[:st.n_pf])
+            else:
+                hp[:st.n_pf].view(S, GEO_SPP, 3).copy_(_pupil_points(uf[:, 0], uf[:, 1], s0.r, s0.d.item()))
+            # the two short levels may run on a stream of their own (StrictPipeline: a high-priority one, so that they do not queue
+            # behind the psf_map launch of the stack in front); every level ends with a host wait, which orders them with level 3
+            s12 = getattr(lens, "_strict_fast_stream", None)
+            s12 = stream if s12 is None else s12
+            sp12 = C.c_void_p(s12.cuda_stream)
+            with torch.cuda.stream(s12):
+                st.d_pupil[:st.n_pf].copy_(hp[:st.n_pf], non_blocking=True)
             mark("level 1 rays")
             # ---- level 1: refocus (deeplens/optics.py:1155-1180) - rays from the first surface's aperture points away from (0, 0, focus)
             t = st.h_par[0][:S * 3].view(f32).view(S, 3)
@@ -475,6 +567,10 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None, draw
                 # sqrt / cos / sin) while this thread goes through levels 1 and 2, which are launch and round-trip latency.  Slice by
                 # slice: below ATen's grain size (32768 elements) an element-wise op stays on the calling thread - a second OpenMP
                 # team next to the main thread's oversubscribes a CPU quota (spinning workers: 60-80 ms stalls were measured)
+                if vec is not None:                      # two calls into the library, no interpreter lock held
+                    _pupil_rows(vec, u, st.off_main, st.off_main + spp, spp, enp_rr, enp_z, hp[st.n_pf:st.n_pf + st.n_pm])
+                    _pupil_rows(vec, u, st.off_chief, st.off_chief + GEO_SPP, GEO_SPP, enp_rr * 0.5, enp_z, hp[st.n_pf + st.n_pm:])
+                    return
                 pm_h = hp[st.n_pf:st.n_pf + st.n_pm].view(S, L, spp, 3)
                 pc_h = hp[st.n_pf + st.n_pm:].view(S, L, GEO_SPP, 3)
                 for k in range(S):
@@ -487,9 +583,9 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None, draw
                 G = st.G[0]
                 _abi.call("aadff_trace_rays_strict_fused", None, None, None, GEO_SPP, J, _abi.ptr(tab_dev), len(wv), n_surf, _abi.ptr(st.bt_green),
                           _ptr_at(par, 0), _ptr_at(par, G), _abi.ptr(st.d_pupil), 1, 0, n_surf, 1, None, _ptr_at(par, G + st.J),
-                          _ptr_at(res, 2 * J * GEO_SPP), 1, 1, _ptr_at(res, 0), _ptr_at(res, J * GEO_SPP), _ptr_at(par, G), sp)
+                          _ptr_at(res, 2 * J * GEO_SPP), 1, 1, _ptr_at(res, 0), _ptr_at(res, J * GEO_SPP), _ptr_at(par, G), sp12)
 
-            got = _speculate_small(counts, keys[0], st, 0, S, GEO_SPP, curved, fwd_order, launch1, stream)
+            got = _speculate_small(counts, keys[0], st, 0, S, GEO_SPP, curved, fwd_order, launch1, s12)
             if got is not None:
                 fd_all, alive = got[0], got[1] > 0
         if not fused or got is None:
@@ -513,10 +609,10 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None, draw
                 G = st.G[1]
                 _abi.call("aadff_trace_rays_strict_fused", None, None, None, M, J, _abi.ptr(tab_dev), len(wv), n_surf, _abi.ptr(st.bt_green),
                           _ptr_at(par, 0), _ptr_at(par, G), _ptr_at(par, S * 3), 1, 0, n_surf, int(not backward), None, _ptr_at(par, G + st.J),
-                          _ptr_at(res, 2 * J * M), 0, 2, _ptr_at(res, 0), _ptr_at(res, J * M), _abi.ptr(st.zeros), sp)
+                          _ptr_at(res, 2 * J * M), 0, 2, _ptr_at(res, 0), _ptr_at(res, J * M), _abi.ptr(st.zeros), sp12)
 
             mark("level 2 rays")
-            got = _speculate_small(counts, keys[1], st, 1, S, M, curved, bwd_order if backward else fwd_order, launch2, stream)
+            got = _speculate_small(counts, keys[1], st, 1, S, M, curved, bwd_order if backward else fwd_order, launch2, s12)
             if got is not None:
                 tan_fov, rra = torch.from_numpy(got[0]), torch.from_numpy(got[1])
         else:
@@ -540,17 +636,27 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None, draw
             h[B:B + S * N * 3].view(f32).view(S, N, 3).copy_(pobj)
             h[B + S * N * 3:].view(B, 2, MS).copy_(torch.from_numpy(pred3))
 
-            def launch3(J, jobs_ptr, pred_ptr, res):
+            def launch3(J, jobs_ptr, pred_ptr, res, on=None):
+                # re-launches go to the short levels' stream: behind a pipeline's NEXT psf_map launch they would wait 3 ms (the host
+                # has seen the first launch finish, and waits for the re-launch before the convolution is queued: ordered either way)
                 par = st.d_par[2]
                 _abi.call("aadff_strict_psf_points", _ptr_at(par, B), N, J, jobs_ptr, _abi.ptr(st.pset), _abi.ptr(tab_dev), len(wv), n_surf,
                           _abi.ptr(st.bt_main), _abi.ptr(st.bt_green), _ptr_at(par, 0), _ptr_at(st.d_pupil, st.n_pf), spp,
                           _ptr_at(st.d_pupil, st.n_pf + st.n_pm), GEO_SPP, pred_ptr, float(lens.pixel_size), ks, grid, _abi.ptr(maps), _abi.ptr(centre),
-                          _ptr_at(res, 0), _ptr_at(res, J * 4 * MS), sp)
+                          _ptr_at(res, 0), _ptr_at(res, J * 4 * MS), sp if on is None else on)
 
             pupils_ready.result()
             st.d_pupil[st.n_pf:].copy_(hp[st.n_pf:], non_blocking=True)
             mark("level 3 inputs")
-            r = st.round_trip(2, h.numel(), B * 4 * MS + B, lambda par, res: launch3(B, None, _ptr_at(par, B + S * N * 3), res), stream)
+            after = getattr(lens, "_strict_l3_after", None)
+            if after is not None:
+                # StrictPipeline: behind the psf_map launch of the stack in front, not beside it - two such launches sharing the chip
+                # finish together, and the host would learn the first one's counts 3 ms later
+                stream.wait_event(after)
+            st.submit(2, h.numel(), B * 4 * MS + B, lambda par, res: launch3(B, None, _ptr_at(par, B + S * N * 3), res), stream)
+            yield "psf_map queued"
+            r = st.wait(2, stream)
+            mark("level 3 launch waited for")
             counts.stats["fused"] += 1
             hb = r[:B * 4 * MS].view(np.uint32).reshape(B, 2, 2, MS)
             any_valid = torch.from_numpy(r[B * 4 * MS:B * 4 * MS + B].copy())
@@ -569,7 +675,7 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None, draw
                 hr = st.h_par[3].numpy()
                 hr[:J] = bad
                 hr[B:B + J * 2 * MS] = rows.reshape(-1)
-                r = st.round_trip(3, B + J * 2 * MS, J * 4 * MS + J, lambda par, res: launch3(J, _ptr_at(par, 0), _ptr_at(par, B), res), stream)
+                r = st.round_trip(3, B + J * 2 * MS, J * 4 * MS + J, lambda par, res: launch3(J, _ptr_at(par, 0), _ptr_at(par, B), res, sp12), s12)
                 counts.stats["fused_replays"] += 1
                 jb = r[:J * 4 * MS].view(np.uint32).reshape(J, 2, 2, MS)
                 okj2, fixj = check_counts(jb[:, :, 0], rows, curved, fwd_order)
@@ -579,6 +685,7 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None, draw
                 truth[bad[okj]] = rows[okj]
                 any_valid[bad[okj]] = torch.from_numpy(r[J * 4 * MS:J * 4 * MS + J][okj].copy())
                 bad, rows_next = bad[~okj], fixj[~okj]
+            mark("counts checked, re-launches")
             if len(bad):                                    # still unconfirmed: the per-surface form finds the counts itself
                 counts.stats["per_surface_replays"] += 1
                 sel = torch.from_numpy(bad).to(dev)
@@ -618,58 +725,95 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None, draw
 
 
 class StrictPipeline:
-    """Several strict-parity stacks in flight: `depth` host threads, each with its own strict `Lensgroup` (count table, staging
-    blocks) and HIP stream, so that the host side and the two short levels of stack k + 1 (launch and round-trip latency, ~2 ms) run
-    beside the psf_map launch of stack k (3-4 ms of GPU time).  Every stack's host draws are taken in SUBMISSION order (a ticket
-    gate), so the generator stream is the sequential loop's and every stack equals what `render_focal_stack_m1(strict_lens, ...)`
-    returns for it.  `submit(...)` returns a future of (stack [B,C,S,H,W], event recorded behind its last launch)."""
+    """Strict-parity stacks software-pipelined on ONE host thread: `depth` strict lenses (count table, staging blocks, HIP stream
+    each; 3 by default: with 2 the host blocks on a re-launch while nothing else is queued) take turns; `submit` runs a stack up to its psf_map launch (draws, host arithmetic, the two short levels - ~1.8 ms of
+    host time and round trips, on a high-priority stream so that they do not queue behind the 3 ms launch in front) and returns;
+    the stack is finished (wait, count check, re-launches, convolution) when its lens is needed again or its result is asked for.
+    The GPU then goes from one psf_map launch to the next while the host prepares the one after.  Draws are taken at `submit`, in
+    submission order: every stack is bit for bit what `render_focal_stack_m1(strict_lens, ...)` returns for it in a sequential loop
+    (to the histograms' float atomics).  `submit(...)` returns a handle whose `result()` is (stack [B,C,S,H,W], event recorded
+    behind its convolution).  (A first version ran the stacks on two host threads: the interpreter lock made it slower than the
+    sequential loop - profiles/r05_x_bench.json, `timed_two_in_flight` 8.7 ms against 6.4.)"""
 
-    def __init__(self, make_lens, depth=2):
-        import threading
+    class _Pending:
+        def __init__(self, pipe, k, steps):
+            self.pipe, self.k, self.steps, self.value = pipe, k, steps, None
+
+        def result(self):
+            self.pipe._finish_through(self.k)
+            return self.value
+
+    def __init__(self, make_lens, depth=3):
         self.depth = int(depth)
         self.lenses = [make_lens() for _ in range(self.depth)]
         assert all(getattr(l, "parity", "") == "strict" for l in self.lenses), "StrictPipeline renders strict-parity lenses"
         dev = self.lenses[0]._gpu()
         self.streams = [torch.cuda.Stream(dev) for _ in range(self.depth)]
-        self.locks = [threading.Lock() for _ in range(self.depth)]
-        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.depth, thread_name_prefix="aadff-strict-pipe")
-        self.cv = threading.Condition()
-        self.next_draw = 0
+        if os.environ.get("AADFF_STRICT_PRIO", "1") != "0":
+            for l in self.lenses:
+                l._strict_fast_stream = torch.cuda.Stream(dev, priority=-1)
+        _abi.call("aadff_strict_replay_threads", 256)        # re-launches run beside the next stack's psf_map launch
+        self.pending = []                                    # oldest first
+        self.l3_tail = None                                  # recorded behind the newest psf_map launch
+        self.trace = [] if os.environ.get("AADFF_STRICT_PIPE_TRACE") == "1" else None       # (stack, "in" / "out" of a half, seconds)
         self.turn = 0
 
-    class _Gate:
-        def __init__(self, pipe, k):
-            self.pipe, self.k = pipe, k
+    def _steps(self, lens, img, depth_plane_mm, focus_mm, grid, ks, spp):
+        focus = [float(f) for f in np.asarray(focus_mm, dtype=np.float64).reshape(-1)]
+        B, C_, H, W = img.shape
+        assert tuple(lens.sensor_res) == (H, W), "lens.sensor_res must match the image"
+        dev = lens._gpu()
+        maps = yield from _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp)
+        maps = maps.to(dev).contiguous()
+        x = _abi.f32c(img, dev)
+        out = torch.empty((B, C_, len(focus), H, W), dtype=torch.float32, device=dev)
+        _abi.call("aadff_render_psf_map_stack", _abi.ptr(x), _abi.ptr(maps), _abi.ptr(out), B, C_, len(focus), H, W, grid, ks, _abi.stream_ptr(dev))
+        return out
 
-        def __enter__(self):
-            with self.pipe.cv:
-                self.pipe.cv.wait_for(lambda: self.pipe.next_draw == self.k)
-
-        def __exit__(self, *a):
-            with self.pipe.cv:
-                self.pipe.next_draw = self.k + 1
-                self.pipe.cv.notify_all()
-
-    def _run(self, k, img, depth_plane_mm, focus_mm, grid, ks, spp):
-        from .focal_stack import render_focal_stack_m1
-        i = k % self.depth
-        gate = StrictPipeline._Gate(self, k)
-        try:
-            with self.locks[i], torch.cuda.stream(self.streams[i]):
-                out = render_focal_stack_m1(self.lenses[i], img, depth_plane_mm, focus_mm, grid, ks, spp, strict_draw_gate=gate)
+    def _advance(self, p):
+        """run stack p to its next yield; at the end set p.value = (stack, event)"""
+        i = p.k % self.depth
+        with torch.no_grad(), torch.cuda.stream(self.streams[i]):
+            try:
+                self.lenses[i]._strict_l3_after = self.l3_tail
+                if self.trace is not None:
+                    self.trace.append((p.k, "in", time.perf_counter()))
+                try:
+                    next(p.steps)
+                finally:
+                    if self.trace is not None:
+                        self.trace.append((p.k, "out", time.perf_counter()))
+                self.l3_tail = torch.cuda.Event()
+                self.l3_tail.record(self.streams[i])
+                return False
+            except StopIteration as done:
                 ev = torch.cuda.Event()
                 ev.record(self.streams[i])
-            return out, ev
-        finally:
-            with self.cv:                                # a stack that failed before its draws must not block the ones behind it
-                if self.next_draw <= k:
-                    self.next_draw = k + 1
-                    self.cv.notify_all()
+                p.value, p.steps = (done.value, ev), None
+                return True
+
+    def _finish_through(self, k):
+        while self.pending and self.pending[0].k <= k:
+            p = self.pending.pop(0)
+            try:
+                while not self._advance(p):
+                    pass
+            except BaseException:
+                p.steps = None
+                raise
 
     def submit(self, img, depth_plane_mm, focus_mm, grid=11, ks=11, spp=GEO_SPP):
         k = self.turn
         self.turn += 1
-        return self.pool.submit(self._run, k, img, depth_plane_mm, focus_mm, grid, ks, spp)
+        self._finish_through(k - self.depth)                 # the stack that had this lens
+        p = StrictPipeline._Pending(self, k, self._steps(self.lenses[k % self.depth], img, depth_plane_mm, focus_mm, grid, ks, spp))
+        if self._advance(p):                                 # a seed run (no count table yet) goes through in one piece
+            return p
+        self.pending.append(p)
+        return p
 
     def close(self):
-        self.pool.shutdown(wait=True)
+        try:
+            self._finish_through(self.turn)
+        finally:
+            _abi.call("aadff_strict_replay_threads", 1024)

@@ -164,3 +164,117 @@ extern "C" int aadff_host_mt19937_rows(unsigned char* torch_state, long state_by
     }
     return 0;
 }
+
+// Pupil / aperture points of the strict-parity mode from host uniforms, in the reference's float32 operations
+// (deeplens/optics.py:480-486, deeplens/surfaces.py:188-199):  theta = (u_t * 2) * pi,  r = sqrt(u_r * R^2),
+// point = (r * cos(theta), r * sin(theta), z) - every step a separately rounded float32 operation, the cosine and sine the SAME
+// vector routines torch's CPU kernels call, exported by the libtorch_cpu.so of the caller's process: MKL's vmsCos / vmsSin (and
+// vmsSqrt for the root) when torch is built with MKL (ATen/cpu/vml.h; kind 1), else Sleef's u10 functions `Sleef_cosf16_u10` / `Sleef_sinf16_u10` (torch CPU
+// capability AVX512; kind 16) or `Sleef_cosf8_u10` / `Sleef_sinf8_u10` (AVX2; kind 8).  The caller resolves them and passes the
+// addresses; this library does not link torch.  The host mirror compares a block against torch itself before it trusts this path.
+// Row i reads n theta uniforms at u + theta_off[i], n radius uniforms at u + r_off[i] and writes out[i][n][3].
+#include <immintrin.h>
+
+namespace {
+#pragma clang attribute push(__attribute__((target("avx512f,avx512bw,avx512vl"))), apply_to = function)
+void pupil_rows_16(const float* u, long n_rows, const long* t_off, const long* r_off, long n, float pi_f, float R2, float z, float* out,
+                   const void* cos_fn, const void* sin_fn) {
+    typedef __m512 (*fn_t)(__m512);
+    const fn_t cosv = (fn_t)cos_fn, sinv = (fn_t)sin_fn;
+    alignas(64) float bx[16], by[16];
+    for (long i = 0; i < n_rows; ++i) {
+        const float *ut = u + t_off[i], *ur = u + r_off[i];
+        float* o = out + i * n * 3;
+        for (long k = 0; k < n; k += 16) {
+            const int m = (int)(n - k < 16 ? n - k : 16);
+            const __mmask16 mask = (__mmask16)((1u << m) - 1u);
+            const __m512 tu = _mm512_maskz_loadu_ps(mask, ut + k), ru = _mm512_maskz_loadu_ps(mask, ur + k);
+            const __m512 theta = _mm512_mul_ps(_mm512_mul_ps(tu, _mm512_set1_ps(2.f)), _mm512_set1_ps(pi_f));
+            const __m512 r = _mm512_sqrt_ps(_mm512_mul_ps(ru, _mm512_set1_ps(R2)));
+            _mm512_store_ps(bx, _mm512_mul_ps(r, cosv(theta)));
+            _mm512_store_ps(by, _mm512_mul_ps(r, sinv(theta)));
+            for (int j = 0; j < m; ++j) {
+                o[(k + j) * 3 + 0] = bx[j];
+                o[(k + j) * 3 + 1] = by[j];
+                o[(k + j) * 3 + 2] = z;
+            }
+        }
+    }
+}
+#pragma clang attribute pop
+#pragma clang attribute push(__attribute__((target("avx2,fma"))), apply_to = function)
+void pupil_rows_8(const float* u, long n_rows, const long* t_off, const long* r_off, long n, float pi_f, float R2, float z, float* out,
+                  const void* cos_fn, const void* sin_fn) {
+    typedef __m256 (*fn_t)(__m256);
+    const fn_t cosv = (fn_t)cos_fn, sinv = (fn_t)sin_fn;
+    alignas(32) float bt[8], br[8], bx[8], by[8];
+    for (long i = 0; i < n_rows; ++i) {
+        const float *ut = u + t_off[i], *ur = u + r_off[i];
+        float* o = out + i * n * 3;
+        for (long k = 0; k < n; k += 8) {
+            const int m = (int)(n - k < 8 ? n - k : 8);
+            for (int j = 0; j < 8; ++j) {
+                bt[j] = j < m ? ut[k + j] : 0.f;
+                br[j] = j < m ? ur[k + j] : 0.f;
+            }
+            const __m256 theta = _mm256_mul_ps(_mm256_mul_ps(_mm256_load_ps(bt), _mm256_set1_ps(2.f)), _mm256_set1_ps(pi_f));
+            const __m256 r = _mm256_sqrt_ps(_mm256_mul_ps(_mm256_load_ps(br), _mm256_set1_ps(R2)));
+            _mm256_store_ps(bx, _mm256_mul_ps(r, cosv(theta)));
+            _mm256_store_ps(by, _mm256_mul_ps(r, sinv(theta)));
+            for (int j = 0; j < m; ++j) {
+                o[(k + j) * 3 + 0] = bx[j];
+                o[(k + j) * 3 + 1] = by[j];
+                o[(k + j) * 3 + 2] = z;
+            }
+        }
+    }
+}
+#pragma clang attribute pop
+
+// torch built with MKL evaluates cos / sin / sqrt of a contiguous float32 CPU tensor with MKL's vector-math calls
+// vmsCos / vmsSin / vmsSqrt(n, in, out, VML_HA | VML_FTZDAZ_OFF | VML_ERRMODE_IGNORE) (ATen/cpu/vml.h), not with Sleef / the IEEE root.
+void pupil_rows_vml(const float* u, long n_rows, const long* t_off, const long* r_off, long n, float pi_f, float R2, float z, float* out,
+                    const void* cos_fn, const void* sin_fn, const void* sqrt_fn) {
+    typedef void (*fn_t)(int, const float*, float*, long long);
+    const fn_t cosv = (fn_t)cos_fn, sinv = (fn_t)sin_fn, sqrtv = (fn_t)sqrt_fn;
+    constexpr long long kMode = 0x2 | 0x00140000 | 0x100;
+    constexpr long CH = 512;                             // small calls: MKL never fans them out over its threads
+    float th[CH], c[CH], sn[CH], q[CH], r[CH];
+    for (long i = 0; i < n_rows; ++i) {
+        const float *ut = u + t_off[i], *ur = u + r_off[i];
+        float* o = out + i * n * 3;
+        for (long k = 0; k < n; k += CH) {
+            const long m = n - k < CH ? n - k : CH;
+            for (long j = 0; j < m; ++j) {
+                th[j] = (ut[k + j] * 2.f) * pi_f;
+                q[j] = ur[k + j] * R2;
+            }
+            cosv((int)m, th, c, kMode);
+            sinv((int)m, th, sn, kMode);
+            sqrtv((int)m, q, r, kMode);                  // torch.sqrt is MKL's too (not the correctly rounded root everywhere)
+            for (long j = 0; j < m; ++j) {
+                o[(k + j) * 3 + 0] = r[j] * c[j];
+                o[(k + j) * 3 + 1] = r[j] * sn[j];
+                o[(k + j) * 3 + 2] = z;
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int aadff_host_pupil_points(const float* u, long n_rows, const long* theta_off, const long* r_off, long n, float pi_f, float R2,
+                                       float z, float* out, const void* cos_fn, const void* sin_fn, const void* sqrt_fn, int width) {
+    AADFF_CHECK_ARG(u && theta_off && r_off && out && cos_fn && sin_fn && (sqrt_fn || width != 1) && n_rows >= 0 && n >= 0, "host_pupil_points: NULL pointer or negative size");
+    AADFF_CHECK_ARG(width == 1 || width == 8 || width == 16, "host_pupil_points: kind %d (1 = MKL vmsCos / vmsSin, 8 = the AVX2 Sleef routines, 16 = the AVX-512 ones)", width);
+    if (width == 1) {
+        pupil_rows_vml(u, n_rows, theta_off, r_off, n, pi_f, R2, z, out, cos_fn, sin_fn, sqrt_fn);
+    } else if (width == 16) {
+        AADFF_CHECK_ARG(__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl"),
+                        "host_pupil_points: width 16 on a CPU without AVX-512");
+        pupil_rows_16(u, n_rows, theta_off, r_off, n, pi_f, R2, z, out, cos_fn, sin_fn);
+    } else {
+        AADFF_CHECK_ARG(__builtin_cpu_supports("avx2"), "host_pupil_points: width 8 on a CPU without AVX2");
+        pupil_rows_8(u, n_rows, theta_off, r_off, n, pi_f, R2, z, out, cos_fn, sin_fn);
+    }
+    return 0;
+}

@@ -15,6 +15,7 @@
 // evaluating it.  The reference makes all ten iterations at nine of rf50mm's eleven curved surfaces for the full-pupil batches
 // (dead rays frozen far from a surface keep |ft| above the tolerance for ever), 96 residual evaluations per ray; a ray's iterate is
 // periodic after 3.0 evaluations on average (tools/strict_cycle_stats.py), a wave's slowest after 5.
+#include <atomic>
 #include "strict_math2.h"
 
 #pragma clang fp contract(off)
@@ -399,6 +400,16 @@ extern "C" int aadff_trace_rays_strict_fused(float* o, float* d, float* ra, int 
     return 0;
 }
 
+// Workgroup size of a psf_map launch with fewer than 1024 workgroups (a re-launch of a few mispredicted batches): 1024 threads
+// shorten the latency chain on an idle chip; beside another stack's full launch (StrictPipeline) a 16-wave workgroup waits for a
+// whole CU to drain, so the pipeline asks for the 256-thread form (measured: 5.7 -> 4.2 ms per stack at depth 3).
+static std::atomic<int> g_replay_threads{1024};
+extern "C" int aadff_strict_replay_threads(int threads) {
+    AADFF_CHECK_ARG(threads == 256 || threads == 1024, "strict_replay_threads: %d (256 or 1024)", threads);
+    g_replay_threads.store(threads, std::memory_order_relaxed);
+    return 0;
+}
+
 extern "C" int aadff_strict_psf_points(const float* points, int N, int B, const int* job_batch_or_null, const int* point_set, const aadff_surface_t* tables_dev, int n_tables,
                                        int n_surf, const int* table_main, const int* table_chief, const float* z_sensor, const float* pupil_main,
                                        int spp, const float* pupil_chief, int spp_chief, const int* pred, float pixel_size, int ks,
@@ -425,7 +436,7 @@ extern "C" int aadff_strict_psf_points(const float* points, int N, int B, const 
     const double ps = (double)pixel_size;                                        // monte_carlo.py:24: Python floats, rounded once
     const double lo = (-ks / 2.0 + 0.5) * ps, hi = (ks / 2.0 - 0.5) * ps;
     a.lo = (float)lo; a.hi = (float)hi; a.lim = (float)(hi - 0.01 * ps); a.den_row = (float)(lo - hi); a.den_col = (float)(hi - lo);
-    if ((long)N * B >= 1024) hipLaunchKernelGGL(strict::fused_psf_kernel<256>, dim3(N, B), dim3(256), lds, st, a);
+    if ((long)N * B >= 1024 || g_replay_threads.load(std::memory_order_relaxed) == 256) hipLaunchKernelGGL(strict::fused_psf_kernel<256>, dim3(N, B), dim3(256), lds, st, a);
     else hipLaunchKernelGGL(strict::fused_psf_kernel<1024>, dim3(N, B), dim3(1024), lds, st, a);
     AADFF_CHECK_LAUNCH();
     return 0;

@@ -516,6 +516,20 @@ int aadff_host_mt19937_discard(unsigned char* torch_state_host, long state_bytes
 int aadff_host_mt19937_rows(unsigned char* torch_state_host, long state_bytes, int n_rows, long row_len, long head, float* out_host,
                             unsigned char* snapshots_host, int phase);
 
+/* Workgroup size (256 or 1024, default 1024) of an aadff_strict_psf_points launch with fewer than 1024 workgroups, i.e. a re-launch
+ * of the few batches whose speculated Newton counts (deeplens/surfaces.py:547) were off: 1024 threads shorten it on an idle GPU,
+ * 256 get scheduled beside another stack's full launch (aadff.strict_stack.StrictPipeline).  Process-wide. */
+int aadff_strict_replay_threads(int threads);
+
+/* HOST routine (strict-parity mode): rows of pupil / aperture points from host uniforms in the reference's float32 operations -
+ * theta = (u * 2) * pi, r = sqrt(u' * R^2), (r cos theta, r sin theta, z): deeplens/optics.py:480-486 (sample_point_source's pupil
+ * sampling) and deeplens/surfaces.py:188-199 (the aperture points of refocus).  cos_fn / sin_fn / sqrt_fn: addresses of the vector routines
+ * torch's CPU kernels use, resolved by the caller in the libtorch_cpu.so of its process - kind 1: MKL's vmsCos / vmsSin / vmsSqrt
+ * (torch built with MKL: ATen/cpu/vml.h), kind 16: Sleef_cosf16_u10 / Sleef_sinf16_u10, kind 8: Sleef_cosf8_u10 / Sleef_sinf8_u10
+ * (sqrt_fn unused: IEEE root) - same routines, same bits, without the ~70 small tensor operations per stack.  Row i: n theta uniforms at u + theta_off[i], n radius uniforms at u + r_off[i] -> out[i][n][3]. */
+int aadff_host_pupil_points(const float* u_host, long n_rows, const long* theta_off, const long* r_off, long n, float pi_f, float R2,
+                            float z, float* out_host, const void* cos_fn, const void* sin_fn, const void* sqrt_fn, int kind);
+
 #ifdef __cplusplus
 }
 #endif

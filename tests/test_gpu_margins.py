@@ -539,9 +539,10 @@ def test_bf16_train_step_runs_and_tracks_fp32(repo_root, margin):
 
 
 def test_strict_pipeline_equals_the_sequential_loop(repo_root, margin):
-    """aadff.strict_stack.StrictPipeline (round 5): two strict stacks in flight on two host threads / streams / lenses.  The host draws
-    are taken in submission order, so every stack equals the one the sequential loop renders from the same generator (PSF histograms
-    are float atomics: 2e-6 of the peak), and the generator ends where the loop leaves it."""
+    """aadff.strict_stack.StrictPipeline (round 5): two strict stacks in flight (two lenses / streams, one host thread: the first half
+    of stack k + 1 runs between the psf_map launch of stack k and the wait for it).  The host draws are taken at submission, so every
+    stack equals the one the sequential loop renders from the same generator (PSF histograms are float atomics: 2e-6 of the peak),
+    the generator ends where the loop leaves it, and results may be asked for in any order."""
     import time
     from aadff.strict_stack import StrictPipeline
     H = W = 256
@@ -557,12 +558,13 @@ def test_strict_pipeline_equals_the_sequential_loop(repo_root, margin):
     pipe = StrictPipeline(make, depth=2)
     torch.manual_seed(21)
     futs = [pipe.submit(img, dbar, fds, grid, 11, spp) for _ in range(n)]
-    got = []
-    for f in futs:
-        out, ev = f.result(timeout=120)
+    got = [None] * n
+    for k in (1, 0, 2, 5, 4, 3):
+        out, ev = futs[k].result()
         ev.synchronize()
-        got.append(out)
+        got[k] = out
     pipe.close()
+    assert not pipe.pending
     assert torch.rand(1).item() == tail
     worst = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(got, want))
     margin("strict pipeline (2 stacks in flight) vs sequential loop, max |d| / max over 6 stacks", worst, 2e-6)

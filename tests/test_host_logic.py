@@ -715,6 +715,33 @@ def test_strict_count_table_logic():
     assert ok.tolist() == [[False, True]] and fix.tolist() == [[[10, 4, 5, 4], [10, 4, 5, 3]]]
 
 
+def test_host_pupil_points_equal_torch_bit_for_bit():
+    """aadff_host_pupil_points (strict mode's pupil / aperture points in three library calls per stack) against the tensor operations
+    of the reference (deeplens/optics.py:480-486, deeplens/surfaces.py:188-199) that `_pupil_points` restates: same bits, for the
+    reference's call-by-call [2048] shape, the batched shape and ragged lengths; and the routines torch itself uses on this machine
+    are found (a silent fall-back to the tensor path would cost the strict mode ~1 ms per stack)."""
+    from aadff import strict_stack as ss
+    vec = ss._sleef()
+    assert vec is not None, "the vector cos / sin / sqrt routines of torch's CPU kernels were not found or do not reproduce torch"
+    g = torch.Generator().manual_seed(77)
+    per = 3 * 2048 + 2 * 999
+    u = torch.rand(5 * per, generator=g)
+    for n, off_t, off_r, radius, z in ((2048, 0, 2048, 7.25, -3.5), (999, 3 * 2048, 3 * 2048 + 999, torch.tensor(3.0177), 0.0),
+                                       (1, 5, 9, 1e-3, 12.0), (2048, 2048, 4096, np.float64(6.1), np.float32(0.3))):
+        t_off = np.arange(5, dtype=np.int64) * per + off_t
+        r_off = np.arange(5, dtype=np.int64) * per + off_r
+        have = torch.empty(5, n, 3)
+        ss._pupil_rows(vec, u, t_off, r_off, n, radius, z, have)
+        rows = u.view(5, per)
+        batched = ss._pupil_points(rows[:, off_t:off_t + n], rows[:, off_r:off_r + n], radius, z)
+        assert torch.equal(batched.contiguous().view(torch.int32), have.view(torch.int32))
+        for i in range(5):                                                   # the reference's own shape: one [n] call per batch
+            one = ss._pupil_points(u[t_off[i]:t_off[i] + n].clone(), u[r_off[i]:r_off[i] + n].clone(), radius, z)
+            assert torch.equal(one.view(torch.int32), have[i].view(torch.int32))
+    with pytest.raises(RuntimeError, match="kind"):
+        ss._pupil_rows(vec[:3] + (5, None), u, t_off, r_off, 4, 1.0, 0.0, torch.empty(5, 4, 3))
+
+
 def test_two_pass_row_draws_equal_one_pass_bit_exactly():
     """aadff_host_mt19937_rows (round 5: the focus draws of every slice first, the PSF rows from per-row generator snapshots behind
     the refocus launch): the block equals torch.rand of the whole block bit for bit, the heads alone after pass 1, and torch's
