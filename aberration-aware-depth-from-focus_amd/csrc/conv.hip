@@ -1336,6 +1336,248 @@ __global__ __launch_bounds__(64 * blk::NW, 5) void conv_psf_map_blk_kernel(
 #undef AADFF_BLK_STAMP
 
 // ------------------------------------------------------------------------------------
+// Block-GEMM path for ks 13 .. 21 (round 5; the reference's own render_single_img(method='psf') uses grid 7, ks 21:
+// deeplens/optics.py:779-783).  conv_psf_map_blk_kernel's form with the input window of a 4 x 4 output block grown to
+//   WR x WC = (KS + 3 rounded up to even) x (KS + 3 rounded up to a multiple of 4) pixels,
+// cut into NB = (WR / 2)(WC / 4) blocks of 2 rows x 4 columns - the 16 contiguous, 16-byte aligned bytes one lane reads from the
+// row-pair interleaved tile - and block b = 4 st + kg is lane group kg's share of k-step st (NST = ceil(NB / 4); the blocks past NB
+// carry zero taps).  Useful MACs / issued: 169 / 256 (ks 13), 225 / 384 (15), 289 / 416 (17), 361 / 544 (19), 441 / 576 (21) -
+// the Toeplitz form above issues 32 NK columns per tap row for ks of them: 13 / 32 ... 21 / 64.  At ks 21: 54 MFMAs per 256
+// outputs against 126.  The T fragments (taps arranged for the 16 (du, j) outputs of a block) are loop-invariant per workgroup
+// and live in registers: 8 NST VGPRs (144 at ks 21, two workgroups of 3 waves per CU).
+// Staging, scaling and the exact fp16 hi / lo split are conv_psf_map_blk_kernel's; pixels of the window that no tap touches
+// (beyond the ks - 1 halo) are staged as zeros, so a NaN there cannot reach an output it does not belong to.
+// ------------------------------------------------------------------------------------
+template <int KS>
+struct BlkW {
+    static constexpr int PAD = KS / 2;
+    // AFF: window rounded up to 4 rows x 8 columns, k-step = 2 row pairs x 2 quads (lane group kg = (row pair kg >> 1, quad kg & 1)):
+    // the tile offset of a k-step is a compile-time constant plus one per-lane term, no per-step offset registers (ks 21 holds
+    // 144 VGPRs of T fragments); costs nothing at ks 13 / 21 (16 x 16, 24 x 24 are the minimal windows), one step at ks 19.
+    // Otherwise (ks 15 / 17): minimal window, blocks dealt to the lane groups in order, offsets in registers.
+    static constexpr bool AFF = KS == 13 || KS == 19 || KS == 21;
+    static constexpr int WR = AFF ? (KS + 3 + 3) / 4 * 4 : (KS + 3 + 1) / 2 * 2, WC = AFF ? (KS + 3 + 7) / 8 * 8 : (KS + 3 + 3) / 4 * 4;
+    static constexpr int NQ = WC / 4, NB = (WR / 2) * NQ, NST = (NB + 3) / 4;
+    static constexpr int TCOLS = 96, RB = 24, NW = 3;
+    static constexpr int WCOLS = TCOLS + WC - 4, WDW = WCOLS / 2, THP = RB + WR - 4;
+    static constexpr int NEEDC = TCOLS + KS - 1, NEEDR = RB + KS - 1;          // columns / rows some tap touches
+    static constexpr int LO = (WCOLS + 3) / 4 * 4, RPP = 240;                   // lo-plane offset, row-pair pitch (dwords; 240 = 16 mod 32)
+    static constexpr int TROWS = WR + 3, TPD = (WC + 6) / 2;                    // padded tap rows (a = -3 ..), dwords per row
+    static constexpr int NTP = (KS * KS + 63) / 64;                             // taps a lane loads (every wave loads all of them)
+    static_assert(WDW <= 64 && LO + WCOLS <= RPP && THP % 2 == 0, "tile layout");
+};
+
+template <int KS>
+__global__ __launch_bounds__(192, 2) void conv_psf_map_blkw_kernel(
+    const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
+    int grid, int ntx, int nty, PatchBounds pb) {
+    using Z = BlkW<KS>;
+    using blk::uint4v; using blk::float4u; using blk::float2u;
+    constexpr int PAD = Z::PAD, NW = Z::NW, RPP = Z::RPP, LO = Z::LO, TPD = Z::TPD, NST = Z::NST, NQ = Z::NQ;
+    __shared__ __attribute__((aligned(16))) unsigned tile[(Z::THP / 2) * RPP];
+    __shared__ __attribute__((aligned(16))) unsigned ptap[2][Z::TROWS * TPD];
+    __shared__ float red[NW];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lin = pb.xcd_q ? xcd_remap(blockIdx.x, pb.xcd_q, pb.xcd_r) : blockIdx.x;
+    const unsigned lrow = pb.m_gx ? (unsigned)udiv_magic(lin, pb.gx, pb.m_gx) : lin / pb.gx, bx = lin - lrow * pb.gx;
+    const unsigned bz = pb.m_gx ? (unsigned)udiv_magic(lrow, pb.gy, pb.m_gy) : lrow / pb.gy, by = lrow - bz * pb.gy;
+    const int pj = udiv_magic(bx, ntx, pb.m_ntx), tx = bx - pj * ntx;
+    const int pi = udiv_magic(by, nty, pb.m_nty), ty = by - pi * nty;
+    const int bc = udiv_magic(bz, S, pb.m_nchunk), s = bz - bc * S;
+    const int c = bc - udiv_magic(bc, C, pb.m_c) * C;
+    const int x_hi = pb.wb[pj + 1], y_hi = pb.hb[pi + 1];
+    const int x0 = pb.wb[pj] + tx * Z::TCOLS, y0 = pb.hb[pi] + ty * Z::RB;
+    if (x0 >= x_hi || y0 >= y_hi) return;
+    const int G = grid * KS;
+
+    // ---- global loads up front: the taps (every wave loads all of them: NTP per lane, its own maximum and scale - no cross-wave
+    //      reduction), then this wave's share of the image rows ----
+    float tw[Z::NTP];
+    {
+        // w(a,b) = psf[KS-1-a][KS-1-b]  (deeplens/render_psf.py:60 flips the kernel before conv2d)
+        const float* wp = psf + ((size_t)(s * C + c) * G + pi * KS) * G + pj * KS;
+#pragma unroll
+        for (int e = 0; e < Z::NTP; ++e) {
+            const int t = lane + e * 64;
+            const int tu = t / KS, tc = t - tu * KS;
+            tw[e] = t < KS * KS ? wp[(KS - 1 - tu) * G + (KS - 1 - tc)] : 0.f;
+        }
+    }
+    constexpr int NPT = (Z::THP + NW - 1) / NW;
+    float v0[NPT], v1[NPT];
+    float amax = 0.f;
+    {
+        const float* plane = img + (size_t)bc * H * W;
+        const bool interior = x0 - PAD >= 0 && x0 - PAD + Z::WCOLS <= W && y0 - PAD >= 0 && y0 - PAD + Z::THP <= H;     // workgroup-uniform
+        const bool ca = 2 * lane < Z::NEEDC, cb = 2 * lane + 1 < Z::NEEDC;
+        if (interior) {
+            const float* base = plane + (size_t)(y0 - PAD + wave) * W + (x0 - PAD) + 2 * lane;
+#pragma unroll
+            for (int e = 0; e < NPT; ++e) {
+                v0[e] = 0.f; v1[e] = 0.f;
+                if (lane < Z::WDW && wave + e * NW < Z::NEEDR) {
+                    const float2u t = *reinterpret_cast<const float2u*>(base + (size_t)(e * NW) * W);
+                    v0[e] = ca ? t.x : 0.f; v1[e] = cb ? t.y : 0.f;
+                }
+            }
+        } else {
+            const int xa = reflect_idx(x0 - PAD + 2 * lane, W), xb = reflect_idx(x0 - PAD + 2 * lane + 1, W);
+#pragma unroll
+            for (int e = 0; e < NPT; ++e) {
+                const int r = wave + e * NW;
+                const bool in = lane < Z::WDW && r < Z::NEEDR;
+                const float* row = plane + (size_t)reflect_idx(y0 - PAD + r, H) * W;
+                v0[e] = in && ca ? row[xa] : 0.f;
+                v1[e] = in && cb ? row[xb] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NPT; ++e) amax = fmaxf(amax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
+    }
+    for (int e = tid; e < Z::TROWS * TPD; e += 64 * NW) { ptap[0][e] = 0u; ptap[1][e] = 0u; }
+    amax = wave_max(amax);
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();                                                          // band maximum known, tap array zeroed
+    float tmax = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) tmax = fmaxf(tmax, red[w]);
+    float sx, isx;
+    pow2_scale(tmax, sx, isx);
+#pragma unroll
+    for (int e = 0; e < NPT; ++e) {
+        const int r = wave + e * NW;
+        if (lane < Z::WDW && r < Z::THP) {
+            const float a = v0[e] * sx, b = v1[e] * sx;
+            const _Float16 ah = (_Float16)a, bh = (_Float16)b;
+            const _Float16 al = (_Float16)(a - (float)ah), bl = (_Float16)(b - (float)bh);
+            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+            const int d = (r >> 1) * RPP + 2 * lane + (r & 1);
+            tile[d] = __builtin_bit_cast(unsigned, (half2v){ah, bh});
+            tile[d + LO] = __builtin_bit_cast(unsigned, (half2v){al, bl});
+        }
+    }
+    const int kg = lane >> 4, n = lane & 15;
+    const int ry = n >> 3, cx = n & 7;
+    const int xw = x0 + 32 * wave;
+    // block b = 4 st + kg of the window -> (row pair, column quad) -> dword offset in the tile
+    constexpr int NXO = Z::AFF ? 1 : NST;
+    int xo[NXO];
+    if constexpr (Z::AFF) xo[0] = (kg >> 1) * RPP + 4 * (kg & 1);
+    else {
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const int b = 4 * st + kg;
+            const int bb = b < Z::NB ? b : 0;
+            const int rp = bb / NQ, q = bb - rp * NQ;
+            xo[st] = rp * RPP + 4 * q;
+        }
+    }
+    // tile offset (dwords) of lane group kg's block in k-step st
+    auto xoff = [&](int st) { if constexpr (Z::AFF) return xo[0] + 2 * (st / (NQ / 2)) * RPP + 8 * (st % (NQ / 2)); else return xo[st]; };
+    float sw, isw;
+    {
+        // zero-padded fp16 hi / lo taps: tap (a, b) at half index (a + 3) * 2 TPD + (b + 3); wave w writes every NW-th group
+        float wmax = 0.f;
+#pragma unroll
+        for (int e = 0; e < Z::NTP; ++e) wmax = fmaxf(wmax, fabsf(tw[e]));
+        pow2_scale(wave_max(wmax), sw, isw);
+        _Float16* ph = reinterpret_cast<_Float16*>(&ptap[0][0]);
+        _Float16* pl = reinterpret_cast<_Float16*>(&ptap[1][0]);
+#pragma unroll
+        for (int e = 0; e < Z::NTP; ++e) {
+            const int t = lane + e * 64;
+            const int tu = t / KS, tc = t - tu * KS;
+            if (t < KS * KS && e % NW == wave) {
+                const float a = tw[e] * sw;
+                const _Float16 h = (_Float16)a;
+                ph[(tu + 3) * 2 * TPD + tc + 3] = h;
+                pl[(tu + 3) * 2 * TPD + tc + 3] = (_Float16)(a - (float)h);
+            }
+        }
+    }
+    __syncthreads();                                                          // band and taps are in LDS
+
+    // ---- T fragments: lane (m = (du, j), kg), k-step st: block b = 4 st + kg = (row pair rp, column quad q);
+    //      halves i = 0..7 = (row 2 rp + (i >> 1 & 1), column 4 q + (i & 1) + 2 (i >> 2)) ----
+    uint4v Th[NST], Tl[NST];
+    {
+        const int du = n >> 2, j = n & 3;
+        // AFF: padded tap row / dword column of the block = per-lane part + compile-time part of the k-step (one LDS base register)
+        const int cl = Z::AFF ? 4 * (kg & 1) - j + 3 : 0;
+        const unsigned* tl0 = &ptap[0][(2 * (kg >> 1) - du + 3) * TPD + (cl >> 1)];
+        const unsigned shl = (cl & 1) * 16;
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const unsigned *a0, *a1;
+            unsigned sh;
+            bool valid = true;
+            if constexpr (Z::AFF) {
+                a0 = tl0 + 4 * (st / (NQ / 2)) * TPD + 4 * (st % (NQ / 2));
+                a1 = a0 + Z::TROWS * TPD;
+                sh = shl;
+            } else {
+                const int b = 4 * st + kg;
+                valid = b < Z::NB;
+                const int bb = valid ? b : 0;
+                const int rp = bb / NQ, q = bb - rp * NQ;
+                const int c0 = 4 * q - j + 3;                                   // half index of tap column t - j, t = 4 q
+                const int ra = 2 * rp - du + 3;                                 // padded row of tap row u - du, u = 2 rp
+                a0 = &ptap[0][ra * TPD + (c0 >> 1)];
+                a1 = &ptap[1][ra * TPD + (c0 >> 1)];
+                sh = (c0 & 1) * 16;
+            }
+            const uint4v th = (uint4v){__builtin_amdgcn_alignbit(a0[1], a0[0], sh), __builtin_amdgcn_alignbit(a0[TPD + 1], a0[TPD], sh),
+                                       __builtin_amdgcn_alignbit(a0[2], a0[1], sh), __builtin_amdgcn_alignbit(a0[TPD + 2], a0[TPD + 1], sh)};
+            const uint4v tl = (uint4v){__builtin_amdgcn_alignbit(a1[1], a1[0], sh), __builtin_amdgcn_alignbit(a1[TPD + 1], a1[TPD], sh),
+                                       __builtin_amdgcn_alignbit(a1[2], a1[1], sh), __builtin_amdgcn_alignbit(a1[TPD + 2], a1[TPD + 1], sh)};
+            const uint4v zero = (uint4v){0u, 0u, 0u, 0u};
+            Th[st] = valid ? th : zero;
+            Tl[st] = valid ? tl : zero;
+        }
+    }
+    const float inv = isx * isw;
+
+    // ---- matrix phase: column block `wave` of the band, groups of 8 rows x NST k-steps ----
+    if (xw < x_hi) {
+        const unsigned* xptr = tile + (2 * ry) * RPP + 32 * wave + 4 * cx;
+        const int x = xw + 4 * cx;
+        const bool full = x + 3 < x_hi;
+        float* obase = out + (size_t)bc * sbc + (size_t)s * ss + x;
+#pragma unroll
+        for (int g = 0; g < Z::RB / 8; ++g) {
+            const int yg = y0 + 8 * g;
+            if (yg < y_hi) {
+                float4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    const uint4v h4 = *reinterpret_cast<const uint4v*>(xptr + 4 * g * RPP + xoff(st));
+                    const uint4v l4 = *reinterpret_cast<const uint4v*>(xptr + 4 * g * RPP + xoff(st) + LO);
+                    const half8v bh = __builtin_bit_cast(half8v, h4), bl = __builtin_bit_cast(half8v, l4);
+                    const half8v th = __builtin_bit_cast(half8v, Th[st]), tl = __builtin_bit_cast(half8v, Tl[st]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl, bh, acc, 0, 0, 0);
+                }
+                // D[m = 4 kg + r][n]: du = kg, j = r -> out[yg + 4 ry + kg][x + r]
+                const int y = yg + 4 * ry + kg;
+                if (y < y_hi) {
+                    float* o = obase + (size_t)y * W;
+                    const float a0 = acc[0] * inv, a1 = acc[1] * inv, a2 = acc[2] * inv, a3 = acc[3] * inv;
+                    if (full) __builtin_nontemporal_store((float4u){a0, a1, a2, a3}, reinterpret_cast<float4u*>(o));
+                    else {
+                        if (x < x_hi) o[0] = a0;
+                        if (x + 1 < x_hi) o[1] = a1;
+                        if (x + 2 < x_hi) o[2] = a2;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Generic path (any odd ks <= AADFF_MAX_KS): same tiling, runtime loops, PSF taps staged
 // flipped in LDS and read as broadcasts.  Correctness path for unusual kernel sizes.
 // ------------------------------------------------------------------------------------
@@ -1544,6 +1786,33 @@ static int conv_dispatch(const float* img, const float* psf, float* out, long sb
         mw = std::max(mw, pb.wb[i + 1] - pb.wb[i]);
     }
     const int ntx = (mw + TW - 1) / TW, nty = (mh + TH - 1) / TH;
+    if (ks >= 13 && ks <= 21 && !getenv("AADFF_CONV_PATH")) {
+        // block-GEMM form (conv_psf_map_blkw_kernel): AADFF_CONV_BLKW = 0 never, 1 always, unset: where it measured faster
+        // (tools/conv_blkw_probe.py, 1024^2, us per launch blkw / wide Toeplitz / packed-FMA - lone slices: ks 13 16.6 / 31.6 / 30.7,
+        // ks 15 24.8 / 32.2 / 41.7, ks 17 23.4 / 33.2 / 95.6, ks 19 36.4 / 41.7 / 113.5, ks 21 32.5 / 43.8 / 79.9 at grid 7 and
+        // 24.9 / 39.3 / 80.6 at grid 11; 10-slice stacks (one workgroup per slice and band here, the Toeplitz form shares its staged
+        // tile between four slices): ks 21 269 / 277 / 394 and 200 / 247 / 358, ks 13 - 19 0.68 - 1.13 x the Toeplitz form's rate)
+        const char* benv = getenv("AADFF_CONV_BLKW");
+        const int blkw = benv ? atoi(benv) : -1;
+        const bool use = blkw == 1 || (blkw == -1 && (S == 1 || ks == 21));
+        const int bntx = (mw + 96 - 1) / 96, bnty = (mh + 24 - 1) / 24;
+        const size_t gx = (size_t)bntx * grid, gy = (size_t)bnty * grid, total = gx * gy * B * C * S;
+        if (use && total < ((size_t)1 << 31) && (size_t)H * W <= ((size_t)1 << 30)) {
+            PatchBounds pbb = pb;
+            pbb.m_ntx = magic_of(bntx); pbb.m_nty = magic_of(bnty); pbb.m_nchunk = magic_of(S); pbb.m_c = magic_of(C);
+            pbb.gx = (unsigned)gx; pbb.gy = (unsigned)gy;
+            const bool magic = total < 65536;
+            pbb.m_gx = magic ? (gx == 1 ? 1u : magic_of((unsigned)gx)) : 0u;
+            pbb.m_gy = magic ? (gy == 1 ? 1u : magic_of((unsigned)gy)) : 0u;
+            pbb.xcd_q = total >= 64 ? (unsigned)(total / 8) : 0u;
+            pbb.xcd_r = (unsigned)(total % 8);
+#define AADFF_BLKW(K) case K: hipLaunchKernelGGL((conv_psf_map_blkw_kernel<K>), dim3((unsigned)total), dim3(192), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, bntx, bnty, pbb); break;
+            switch (ks) { AADFF_BLKW(13) AADFF_BLKW(15) AADFF_BLKW(17) AADFF_BLKW(19) AADFF_BLKW(21) }
+#undef AADFF_BLKW
+            AADFF_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (ks >= 13 && !getenv("AADFF_CONV_PATH")) {
         // large kernels on the matrix cores (Toeplitz GEMM over NK k-steps); AADFF_CONV_PATH=valu keeps the packed-FMA / generic kernels
         const int nk = (16 + ks - 1 + 31) / 32;                         // 1: ks <= 17, 2: ks <= 49, 3: ks 51

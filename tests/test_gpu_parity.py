@@ -94,7 +94,7 @@ def test_cpu_tensors_round_trip_through_the_gpu(g5):
     assert np.abs(out.numpy() - g5["map_a_out"]).max() <= CONV_ATOL
 
 
-@pytest.mark.parametrize("ks", [3, 5, 7, 9, 11, 13, 15, 17, 21, 31])
+@pytest.mark.parametrize("ks", [3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 31])
 def test_render_psf_map_all_kernel_sizes_vs_oracle(ks):
     """fast path (templated ks) and generic path (17, 31) against the oracle."""
     rng = np.random.Generator(np.random.PCG64(ks))
@@ -165,6 +165,56 @@ def test_render_psf_map_block_gemm_path_vs_oracle_and_toeplitz(B, Cn, H, W, g, S
         assert np.abs(gotn[:, :, s] - want).max() <= 4e-6 * 40, f"slice {s}"
         lone = rp.render_psf_map(img.to(DEV), maps[s].to(DEV), g).cpu().numpy()            # every slice through the block-GEMM kernel
         assert np.abs(lone - want).max() <= 4e-6 * 40, f"lone slice {s}"
+
+
+@pytest.mark.parametrize("B,Cn,H,W,g,S,ks", [(1, 3, 50, 50, 3, 1, 13), (2, 3, 97, 131, 1, 1, 21), (1, 3, 64, 230, 1, 2, 15), (1, 1, 33, 40, 4, 2, 17),
+                                             (1, 3, 201, 97, 2, 1, 19), (1, 4, 120, 120, 7, 1, 13), (1, 3, 25, 300, 2, 3, 21), (1, 3, 203, 203, 2, 1, 21),
+                                             (1, 3, 61, 83, 3, 7, 15), (1, 3, 13, 13, 1, 1, 21), (1, 2, 12, 200, 2, 1, 17), (1, 3, 400, 520, 3, 1, 21)])
+def test_render_psf_map_wide_block_gemm_path_vs_oracle_and_the_other_paths(B, Cn, H, W, g, S, ks, monkeypatch):
+    """ks 13 ... 21 (round 5: `conv_psf_map_blkw_kernel`, the block-GEMM form with a window of up to 24 x 24 pixels per 4 x 4 output
+    block; lone slices of every such ks and stacks at ks 21 - the reference's `render_single_img` size, deeplens/optics.py:779-783 -
+    take it by default): the same edge cases as the ks 9 / 11 test above (patches wider than one tile, blocks and row groups cut by
+    the patch border, images smaller than a band with every row and column reflected, interior bands next to border bands, odd patch
+    origins, B > 1, C != 3, inputs far from [0, 1], a 1e-3 PSF), forced for every slice count (AADFF_CONV_BLKW=1) and compared with
+    the oracle, with the wide Toeplitz form (=0) and with the packed-FMA / generic kernels (AADFF_CONV_PATH=valu).  Non-finite pixels:
+    the contract of the GEMM forms - whatever the reference poisons is non-finite, nothing beyond 128 px is."""
+    rng = np.random.Generator(np.random.PCG64(B * 1000 + H * 7 + W + S + ks))
+    img = tt(rng.random((B, Cn, H, W), dtype=np.float32)) * 37.5 - 3.0
+    maps = tt(rng.random((S, Cn, g * ks, g * ks), dtype=np.float32)) / (ks * ks)
+    maps[S // 2, 0] *= 1e-3
+    default = rp.render_psf_map_stack(img.to(DEV), maps.to(DEV), g)
+    monkeypatch.setenv("AADFF_CONV_BLKW", "1")
+    got = rp.render_psf_map_stack(img.to(DEV), maps.to(DEV), g)
+    monkeypatch.setenv("AADFF_CONV_BLKW", "0")
+    toe = rp.render_psf_map_stack(img.to(DEV), maps.to(DEV), g)
+    monkeypatch.delenv("AADFF_CONV_BLKW")
+    monkeypatch.setenv("AADFF_CONV_PATH", "valu")
+    valu = rp.render_psf_map_stack(img.to(DEV), maps.to(DEV), g)
+    monkeypatch.delenv("AADFF_CONV_PATH")
+    assert got.shape == (B, Cn, S, H, W)
+    tol = 4e-6 * 40
+    assert (toe - got).abs().max().item() <= tol and (valu - got).abs().max().item() <= tol and (default - got).abs().max().item() <= tol
+    if S == 1 or ks == 21:
+        assert torch.equal(default, got)                                       # the default dispatch IS this kernel there
+    gotn = got.cpu().numpy()
+    for s in range(S):
+        want = oconv.render_psf_map(img, maps[s], g).numpy()
+        assert np.abs(gotn[:, :, s] - want).max() <= tol, f"slice {s}"
+    # one NaN pixel
+    if H > ks and W > ks:
+        bad = img.clone()
+        bad[0, 0, H // 2, W // 3] = float("nan")
+        monkeypatch.setenv("AADFF_CONV_BLKW", "1")
+        a = rp.render_psf_map_stack(bad.to(DEV), maps.to(DEV), g)
+        monkeypatch.delenv("AADFF_CONV_BLKW")
+        monkeypatch.setenv("AADFF_CONV_PATH", "valu")
+        b = rp.render_psf_map_stack(bad.to(DEV), maps.to(DEV), g)
+        monkeypatch.delenv("AADFF_CONV_PATH")
+        na, nb = ~torch.isfinite(a), ~torch.isfinite(b)
+        assert int(nb.sum()) > 0 and bool((na | ~nb).all())                    # everything the reference poisons is non-finite here too
+        far = torch.ones(H, W, dtype=torch.bool, device=a.device)
+        far[max(0, H // 2 - 128):H // 2 + 129, max(0, W // 3 - 128):W // 3 + 129] = False
+        assert not bool(na[0, 0, :, far].any()) and not bool(na[0, 1:].any()) and not bool(na[1:].any())   # nothing farther than 128 px, no other plane
 
 
 @pytest.mark.parametrize("Cn", [1, 2, 4, 6])
