@@ -1348,7 +1348,7 @@ __global__ __launch_bounds__(64 * blk::NW, 5) void conv_psf_map_blk_kernel(
 // Staging, scaling and the exact fp16 hi / lo split are conv_psf_map_blk_kernel's; pixels of the window that no tap touches
 // (beyond the ks - 1 halo) are staged as zeros, so a NaN there cannot reach an output it does not belong to.
 // ------------------------------------------------------------------------------------
-template <int KS>
+template <int KS, int RBV>
 struct BlkW {
     static constexpr int PAD = KS / 2;
     // AFF: window rounded up to 4 rows x 8 columns, k-step = 2 row pairs x 2 quads (lane group kg = (row pair kg >> 1, quad kg & 1)):
@@ -1358,7 +1358,7 @@ struct BlkW {
     static constexpr bool AFF = KS == 13 || KS == 19 || KS == 21;
     static constexpr int WR = AFF ? (KS + 3 + 3) / 4 * 4 : (KS + 3 + 1) / 2 * 2, WC = AFF ? (KS + 3 + 7) / 8 * 8 : (KS + 3 + 3) / 4 * 4;
     static constexpr int NQ = WC / 4, NB = (WR / 2) * NQ, NST = (NB + 3) / 4;
-    static constexpr int TCOLS = 96, RB = 24, NW = 3;
+    static constexpr int TCOLS = 96, RB = RBV, NW = 3;                           // RB: rows of the band (24, 32 or 48: groups of 8)
     static constexpr int WCOLS = TCOLS + WC - 4, WDW = WCOLS / 2, THP = RB + WR - 4;
     static constexpr int NEEDC = TCOLS + KS - 1, NEEDR = RB + KS - 1;          // columns / rows some tap touches
     static constexpr int LO = (WCOLS + 3) / 4 * 4, RPP = 240;                   // lo-plane offset, row-pair pitch (dwords; 240 = 16 mod 32)
@@ -1367,16 +1367,23 @@ struct BlkW {
     static_assert(WDW <= 64 && LO + WCOLS <= RPP && THP % 2 == 0, "tile layout");
 };
 
-template <int KS>
+template <int KS, int RBV>
 __global__ __launch_bounds__(192, 2) void conv_psf_map_blkw_kernel(
     const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
     int grid, int ntx, int nty, PatchBounds pb) {
-    using Z = BlkW<KS>;
+    using Z = BlkW<KS, RBV>;
     using blk::uint4v; using blk::float4u; using blk::float2u;
     constexpr int PAD = Z::PAD, NW = Z::NW, RPP = Z::RPP, LO = Z::LO, TPD = Z::TPD, NST = Z::NST, NQ = Z::NQ;
     __shared__ __attribute__((aligned(16))) unsigned tile[(Z::THP / 2) * RPP];
     __shared__ __attribute__((aligned(16))) unsigned ptap[2][Z::TROWS * TPD];
     __shared__ float red[NW];
+#ifdef AADFF_SB_TRACE
+    unsigned long long* const trace_slot = g_sb_trace ? g_sb_trace + (size_t)blockIdx.x * 8 : nullptr;
+#define AADFF_BLK_STAMP(slot) do { if (trace_slot && threadIdx.x == 0) trace_slot[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AADFF_BLK_STAMP(slot) do {} while (0)
+#endif
+    AADFF_BLK_STAMP(0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1439,6 +1446,7 @@ __global__ __launch_bounds__(192, 2) void conv_psf_map_blkw_kernel(
     for (int e = tid; e < Z::TROWS * TPD; e += 64 * NW) { ptap[0][e] = 0u; ptap[1][e] = 0u; }
     amax = wave_max(amax);
     if (lane == 0) red[wave] = amax;
+    AADFF_BLK_STAMP(1);                                                        // global loads have arrived (wave 0)
     __syncthreads();                                                          // band maximum known, tap array zeroed
     float tmax = red[0];
 #pragma unroll
@@ -1498,6 +1506,7 @@ __global__ __launch_bounds__(192, 2) void conv_psf_map_blkw_kernel(
         }
     }
     __syncthreads();                                                          // band and taps are in LDS
+    AADFF_BLK_STAMP(2);
 
     // ---- T fragments: lane (m = (du, j), kg), k-step st: block b = 4 st + kg = (row pair rp, column quad q);
     //      halves i = 0..7 = (row 2 rp + (i >> 1 & 1), column 4 q + (i & 1) + 2 (i >> 2)) ----
@@ -1538,6 +1547,10 @@ __global__ __launch_bounds__(192, 2) void conv_psf_map_blkw_kernel(
         }
     }
     const float inv = isx * isw;
+#ifdef AADFF_SB_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragments built
+    AADFF_BLK_STAMP(3);
+#endif
 
     // ---- matrix phase: column block `wave` of the band, groups of 8 rows x NST k-steps ----
     if (xw < x_hi) {
@@ -1575,7 +1588,13 @@ __global__ __launch_bounds__(192, 2) void conv_psf_map_blkw_kernel(
             }
         }
     }
+#ifdef AADFF_SB_TRACE
+    AADFF_BLK_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stores retired
+    AADFF_BLK_STAMP(5);
+#endif
 }
+#undef AADFF_BLK_STAMP
 
 // ------------------------------------------------------------------------------------
 // Generic path (any odd ks <= AADFF_MAX_KS): same tiling, runtime loops, PSF taps staged
@@ -1788,14 +1807,22 @@ static int conv_dispatch(const float* img, const float* psf, float* out, long sb
     const int ntx = (mw + TW - 1) / TW, nty = (mh + TH - 1) / TH;
     if (ks >= 13 && ks <= 21 && !getenv("AADFF_CONV_PATH")) {
         // block-GEMM form (conv_psf_map_blkw_kernel): AADFF_CONV_BLKW = 0 never, 1 always, unset: where it measured faster
-        // (tools/conv_blkw_probe.py, 1024^2, us per launch blkw / wide Toeplitz / packed-FMA - lone slices: ks 13 16.6 / 31.6 / 30.7,
-        // ks 15 24.8 / 32.2 / 41.7, ks 17 23.4 / 33.2 / 95.6, ks 19 36.4 / 41.7 / 113.5, ks 21 32.5 / 43.8 / 79.9 at grid 7 and
-        // 24.9 / 39.3 / 80.6 at grid 11; 10-slice stacks (one workgroup per slice and band here, the Toeplitz form shares its staged
-        // tile between four slices): ks 21 269 / 277 / 394 and 200 / 247 / 358, ks 13 - 19 0.68 - 1.13 x the Toeplitz form's rate)
+        // (tools/conv_blkw_probe.py -> profiles/r05_y_conv_blkw_probe.txt, 1024^2, us per launch blkw / wide Toeplitz / packed-FMA -
+        // lone slices at grid 7: ks 13 15.0 / 31.6 / 30.8, ks 15 22.3 / 32.0 / 41.3, ks 17 21.4 / 33.5 / 94.8, ks 19 30.7 / 41.4 / 110.5,
+        // ks 21 27.3 / 43.6 / 79.8 (grid 11: 24.3 / 38.7 / 80.4); 10-slice stacks (one workgroup per slice and band here, the Toeplitz
+        // form shares its staged tile between four slices) at grid 7 / 11: ks 13 105 / 113 and 78 / 105, ks 15 156 / 124 and 113 / 109,
+        // ks 17 134 / 131 and 100 / 124, ks 19 291 / 247 and 198 / 217, ks 21 224 / 270 and 158 / 237)
         const char* benv = getenv("AADFF_CONV_BLKW");
         const int blkw = benv ? atoi(benv) : -1;
-        const bool use = blkw == 1 || (blkw == -1 && (S == 1 || ks == 21));
-        const int bntx = (mw + 96 - 1) / 96, bnty = (mh + 24 - 1) / 24;
+        const bool use = blkw == 1 || (blkw == -1 && (S == 1 || ks == 13 || ks == 17 || ks == 21));
+        // rows per band: every workgroup pays ~5.5 us of loads / staging / fragment building in front of 0.76 us of matrix work per
+        // 8-row group (tools/conv_single_timeline.py --ks 21: profiles/r05_y_conv_blkw_timeline_ks21.json), so taller bands win until the
+        // launch is too few workgroups for two rounds on 512 slots.  Measured at 1024^2 (ks 21, us, RB 24 / 32 / 48): grid 7 (147-row
+        // patches) 32.4 / 27.8 / 30.6, grid 11 (94) 25.2 / 25.3 / 24.2, grid 5 (205) 29.1 / 26.8 / 25.4; the other ks alike.
+        const char* renv = getenv("AADFF_CONV_BLKW_RB");
+        int rb = renv ? atoi(renv) : 0;
+        if (rb != 24 && rb != 32 && rb != 48) rb = mh <= 24 ? 24 : (mh <= 32 ? 32 : (mh <= 48 ? 48 : (mh <= 64 ? 32 : (mh <= 96 ? 48 : 32))));
+        const int bntx = (mw + 96 - 1) / 96, bnty = (mh + rb - 1) / rb;
         const size_t gx = (size_t)bntx * grid, gy = (size_t)bnty * grid, total = gx * gy * B * C * S;
         if (use && total < ((size_t)1 << 31) && (size_t)H * W <= ((size_t)1 << 30)) {
             PatchBounds pbb = pb;
@@ -1806,9 +1833,11 @@ static int conv_dispatch(const float* img, const float* psf, float* out, long sb
             pbb.m_gy = magic ? (gy == 1 ? 1u : magic_of((unsigned)gy)) : 0u;
             pbb.xcd_q = total >= 64 ? (unsigned)(total / 8) : 0u;
             pbb.xcd_r = (unsigned)(total % 8);
-#define AADFF_BLKW(K) case K: hipLaunchKernelGGL((conv_psf_map_blkw_kernel<K>), dim3((unsigned)total), dim3(192), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, bntx, bnty, pbb); break;
+#define AADFF_BLKW2(K, R) hipLaunchKernelGGL((conv_psf_map_blkw_kernel<K, R>), dim3((unsigned)total), dim3(192), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, bntx, bnty, pbb)
+#define AADFF_BLKW(K) case K: if (rb == 24) AADFF_BLKW2(K, 24); else if (rb == 32) AADFF_BLKW2(K, 32); else AADFF_BLKW2(K, 48); break;
             switch (ks) { AADFF_BLKW(13) AADFF_BLKW(15) AADFF_BLKW(17) AADFF_BLKW(19) AADFF_BLKW(21) }
 #undef AADFF_BLKW
+#undef AADFF_BLKW2
             AADFF_CHECK_LAUNCH();
             return 0;
         }

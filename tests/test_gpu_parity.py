@@ -172,8 +172,8 @@ def test_render_psf_map_block_gemm_path_vs_oracle_and_toeplitz(B, Cn, H, W, g, S
                                              (1, 3, 61, 83, 3, 7, 15), (1, 3, 13, 13, 1, 1, 21), (1, 2, 12, 200, 2, 1, 17), (1, 3, 400, 520, 3, 1, 21)])
 def test_render_psf_map_wide_block_gemm_path_vs_oracle_and_the_other_paths(B, Cn, H, W, g, S, ks, monkeypatch):
     """ks 13 ... 21 (round 5: `conv_psf_map_blkw_kernel`, the block-GEMM form with a window of up to 24 x 24 pixels per 4 x 4 output
-    block; lone slices of every such ks and stacks at ks 21 - the reference's `render_single_img` size, deeplens/optics.py:779-783 -
-    take it by default): the same edge cases as the ks 9 / 11 test above (patches wider than one tile, blocks and row groups cut by
+    block; lone slices of every such ks and stacks at ks 13 / 17 / 21 - 21 is the reference's `render_single_img` size,
+    deeplens/optics.py:779-783 - take it by default): the same edge cases as the ks 9 / 11 test above (patches wider than one tile, blocks and row groups cut by
     the patch border, images smaller than a band with every row and column reflected, interior bands next to border bands, odd patch
     origins, B > 1, C != 3, inputs far from [0, 1], a 1e-3 PSF), forced for every slice count (AADFF_CONV_BLKW=1) and compared with
     the oracle, with the wide Toeplitz form (=0) and with the packed-FMA / generic kernels (AADFF_CONV_PATH=valu).  Non-finite pixels:
@@ -194,7 +194,7 @@ def test_render_psf_map_wide_block_gemm_path_vs_oracle_and_the_other_paths(B, Cn
     assert got.shape == (B, Cn, S, H, W)
     tol = 4e-6 * 40
     assert (toe - got).abs().max().item() <= tol and (valu - got).abs().max().item() <= tol and (default - got).abs().max().item() <= tol
-    if S == 1 or ks == 21:
+    if S == 1 or ks in (13, 17, 21):
         assert torch.equal(default, got)                                       # the default dispatch IS this kernel there
     gotn = got.cpu().numpy()
     for s in range(S):

@@ -26,14 +26,16 @@ def main():
     ap.add_argument("--lib", default=os.path.join(os.path.dirname(_abi.LIB_PATH), "libaadff_sbtrace.so"))
     ap.add_argument("--json", default=None)
     ap.add_argument("--runs", type=int, default=5)
+    ap.add_argument("--ks", type=int, default=11)        # 13 .. 21: conv_psf_map_blkw_kernel (stamp 3 = T fragments built)
+    ap.add_argument("--grid", type=int, default=11)
     a = ap.parse_args()
     lib = _abi.load_library(a.lib)
     dev = torch.device("cuda:0")
     H = W = 1024
-    G, KS = 11, 11
+    G, KS = a.grid, a.ks
     img = torch.from_numpy(synth_rgb(H, W))[None].to(dev)
     rng = np.random.Generator(np.random.PCG64(3))
-    maps = torch.from_numpy(rng.random((3, G * KS, G * KS), dtype=np.float32)).to(dev) / 121
+    maps = torch.from_numpy(rng.random((3, G * KS, G * KS), dtype=np.float32)).to(dev) / (KS * KS)
     out = torch.empty((1, 3, H, W), device=dev)
     n_wg = 16384                                      # upper bound: Toeplitz form 3 267 workgroups (32 x 32 tiles), block-GEMM form 1 452 (24 x 96 bands)
     buf = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
