@@ -1368,7 +1368,7 @@ struct BlkW {
 };
 
 template <int KS, int RBV>
-__global__ __launch_bounds__(192, 2) void conv_psf_map_blkw_kernel(
+__global__ __launch_bounds__(192, KS <= 11 ? 5 : 2) void conv_psf_map_blkw_kernel(
     const float* __restrict__ img, const float* __restrict__ psf, float* __restrict__ out, long sbc, long ss, int C, int S, int H, int W,
     int grid, int ntx, int nty, PatchBounds pb) {
     using Z = BlkW<KS, RBV>;
@@ -1805,7 +1805,7 @@ static int conv_dispatch(const float* img, const float* psf, float* out, long sb
         mw = std::max(mw, pb.wb[i + 1] - pb.wb[i]);
     }
     const int ntx = (mw + TW - 1) / TW, nty = (mh + TH - 1) / TH;
-    if (ks >= 13 && ks <= 21 && !getenv("AADFF_CONV_PATH")) {
+    if (ks >= 3 && ks <= 21 && !getenv("AADFF_CONV_PATH")) {
         // block-GEMM form (conv_psf_map_blkw_kernel): AADFF_CONV_BLKW = 0 never, 1 always, unset: where it measured faster
         // (tools/conv_blkw_probe.py -> profiles/r05_y_conv_blkw_probe.txt, 1024^2, us per launch blkw / wide Toeplitz / packed-FMA -
         // lone slices at grid 7: ks 13 15.0 / 31.6 / 30.8, ks 15 22.3 / 32.0 / 41.3, ks 17 21.4 / 33.5 / 94.8, ks 19 30.7 / 41.4 / 110.5,
@@ -1814,14 +1814,28 @@ static int conv_dispatch(const float* img, const float* psf, float* out, long sb
         // ks 17 134 / 131 and 100 / 124, ks 19 291 / 247 and 198 / 217, ks 21 224 / 270 and 158 / 237)
         const char* benv = getenv("AADFF_CONV_BLKW");
         const int blkw = benv ? atoi(benv) : -1;
-        const bool use = blkw == 1 || (blkw == -1 && (S == 1 || ks == 13 || ks == 17 || ks == 21));
+        // ks 9 / 11 lone slices (us, conv_psf_map_blk_kernel / this kernel with 24- / 32- / 48-row bands; ks 9's window here is 12 x 12 =
+        // 5 k-steps, the older kernel's fixed 14 x 14 = 7): ks 9 grid 7 16.3 / 13.0 / 12.1 / 13.2, grid 11 12.9 / 11.1 / 11.4 / 12.0, grid 5
+        // 15.1 / 11.7 / 12.1 / 12.8; ks 11 grid 7 15.4 / 15.9 / 13.2 / 14.9, grid 11 12.3 / 12.9 / 13.4 / 12.9, grid 5 14.8 / 15.7 / 14.0 / 14.7
+        // ks 3 / 5 / 7 (window ks + 3: 2 / 2 / 4 k-steps; the Toeplitz kernel (b) issues 3 ks MFMAs per 16 x 16 block, this form 3 NST per
+        // 16 x 16): lone slices 9 - 12 us against 13 - 17 at every grid, 10-slice stacks faster at ks 5 only (grid 7 / 11: 53 / 47 against 62 / 54)
+        const bool use = blkw == 1 || (blkw == -1 && (ks >= 13 ? (S == 1 || ks == 13 || ks == 17 || ks == 21)
+                                                                : (S == 1 ? (ks <= 9 || mh > 96) : ks == 5)));
         // rows per band: every workgroup pays ~5.5 us of loads / staging / fragment building in front of 0.76 us of matrix work per
         // 8-row group (tools/conv_single_timeline.py --ks 21: profiles/r05_y_conv_blkw_timeline_ks21.json), so taller bands win until the
         // launch is too few workgroups for two rounds on 512 slots.  Measured at 1024^2 (ks 21, us, RB 24 / 32 / 48): grid 7 (147-row
         // patches) 32.4 / 27.8 / 30.6, grid 11 (94) 25.2 / 25.3 / 24.2, grid 5 (205) 29.1 / 26.8 / 25.4; the other ks alike.
         const char* renv = getenv("AADFF_CONV_BLKW_RB");
         int rb = renv ? atoi(renv) : 0;
-        if (rb != 24 && rb != 32 && rb != 48) rb = mh <= 24 ? 24 : (mh <= 32 ? 32 : (mh <= 48 ? 48 : (mh <= 64 ? 32 : (mh <= 96 ? 48 : 32))));
+        if (rb != 24 && rb != 32 && rb != 48) {
+            if (ks <= 11) {
+                // 6 workgroups per CU: 32-row bands when that saves a round of workgroups on the chip's 1536 slots (1024^2: grid 7 yes,
+                // grid 5 / 11 no - measured, ks 5: 9.4 / 9.1, 9.2 / 9.7, 8.7 / 8.9 us with 24 / 32 rows)
+                const size_t per = (size_t)((mw + 95) / 96) * grid * grid * B * C * S;
+                const size_t w24 = per * ((mh + 23) / 24), w32 = per * ((mh + 31) / 32);
+                rb = (w24 + 1535) / 1536 > (w32 + 1535) / 1536 ? 32 : 24;
+            } else rb = mh <= 24 ? 24 : (mh <= 32 ? 32 : (mh <= 48 ? 48 : (mh <= 64 ? 32 : (mh <= 96 ? 48 : 32))));
+        }
         const int bntx = (mw + 96 - 1) / 96, bnty = (mh + rb - 1) / rb;
         const size_t gx = (size_t)bntx * grid, gy = (size_t)bnty * grid, total = gx * gy * B * C * S;
         if (use && total < ((size_t)1 << 31) && (size_t)H * W <= ((size_t)1 << 30)) {
@@ -1835,7 +1849,7 @@ static int conv_dispatch(const float* img, const float* psf, float* out, long sb
             pbb.xcd_r = (unsigned)(total % 8);
 #define AADFF_BLKW2(K, R) hipLaunchKernelGGL((conv_psf_map_blkw_kernel<K, R>), dim3((unsigned)total), dim3(192), 0, st, img, psf, out, sbc, ss, C, S, H, W, grid, bntx, bnty, pbb)
 #define AADFF_BLKW(K) case K: if (rb == 24) AADFF_BLKW2(K, 24); else if (rb == 32) AADFF_BLKW2(K, 32); else AADFF_BLKW2(K, 48); break;
-            switch (ks) { AADFF_BLKW(13) AADFF_BLKW(15) AADFF_BLKW(17) AADFF_BLKW(19) AADFF_BLKW(21) }
+            switch (ks) { AADFF_BLKW(3) AADFF_BLKW(5) AADFF_BLKW(7) AADFF_BLKW(9) AADFF_BLKW(11) AADFF_BLKW(13) AADFF_BLKW(15) AADFF_BLKW(17) AADFF_BLKW(19) AADFF_BLKW(21) }
 #undef AADFF_BLKW
 #undef AADFF_BLKW2
             AADFF_CHECK_LAUNCH();

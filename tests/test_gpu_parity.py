@@ -163,8 +163,16 @@ def test_render_psf_map_block_gemm_path_vs_oracle_and_toeplitz(B, Cn, H, W, g, S
     for s in range(S):
         want = oconv.render_psf_map(img, maps[s], g).numpy()
         assert np.abs(gotn[:, :, s] - want).max() <= 4e-6 * 40, f"slice {s}"
-        lone = rp.render_psf_map(img.to(DEV), maps[s].to(DEV), g).cpu().numpy()            # every slice through the block-GEMM kernel
-        assert np.abs(lone - want).max() <= 4e-6 * 40, f"lone slice {s}"
+        # every slice through the block-GEMM kernels: the default pick, the round-4 kernel (fixed 14 x 14 window, 24-row bands) and
+        # the round-5 one (window ks + 3, band height by patch height) - ks 9 and tall-patch ks 11 lone slices default to the latter
+        for force in (None, "0", "1"):
+            if force is None:
+                monkeypatch.delenv("AADFF_CONV_BLKW", raising=False)
+            else:
+                monkeypatch.setenv("AADFF_CONV_BLKW", force)
+            lone = rp.render_psf_map(img.to(DEV), maps[s].to(DEV), g).cpu().numpy()
+            assert np.abs(lone - want).max() <= 4e-6 * 40, f"lone slice {s}, AADFF_CONV_BLKW={force}"
+        monkeypatch.delenv("AADFF_CONV_BLKW", raising=False)
 
 
 @pytest.mark.parametrize("B,Cn,H,W,g,S,ks", [(1, 3, 50, 50, 3, 1, 13), (2, 3, 97, 131, 1, 1, 21), (1, 3, 64, 230, 1, 2, 15), (1, 1, 33, 40, 4, 2, 17),

@@ -4,15 +4,17 @@ import numpy as np, torch
 from aadff import _abi
 lib = _abi.load_library(); dev = torch.device("cuda:0"); p = lambda t: C.c_void_p(t.data_ptr()); st = _abi.stream_ptr(dev)
 H = W = 1024
-for ks in (13, 15, 17, 19, 21):
+for ks in (3, 5, 7):
     for G in (7, 11, 5):
-        img = torch.rand(1, 3, H, W, device=dev); maps = torch.rand(1, 3, G * ks, G * ks, device=dev) / (ks * ks); out = torch.empty(1, 3, 1, H, W, device=dev)
+      for S in (1, 10):
+        img = torch.rand(1, 3, H, W, device=dev); maps = torch.rand(S, 3, G * ks, G * ks, device=dev) / (ks * ks); out = torch.empty(1, 3, S, H, W, device=dev)
         row = []
         ref = None
-        for rb in ("24", "32", "48", ""):
-            if rb: os.environ["AADFF_CONV_BLKW_RB"] = rb
-            else: os.environ.pop("AADFF_CONV_BLKW_RB", None)
-            f = lambda: lib.aadff_render_psf_map_stack(p(img), p(maps), p(out), 1, 3, 1, H, W, G, ks, st)
+        for rb in ("", "24", "32", "48"):
+            os.environ.pop("AADFF_CONV_BLKW", None); os.environ.pop("AADFF_CONV_BLKW_RB", None)
+            if rb:
+                os.environ["AADFF_CONV_BLKW"] = "1"; os.environ["AADFF_CONV_BLKW_RB"] = rb
+            f = lambda: lib.aadff_render_psf_map_stack(p(img), p(maps), p(out), 1, 3, S, H, W, G, ks, st)
             for _ in range(3): f()
             torch.cuda.synchronize()
             if ref is None: ref = out.clone()
@@ -23,4 +25,4 @@ for ks in (13, 15, 17, 19, 21):
                 for _ in range(20): f()
                 e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 20 * 1e3)
             row.append(float(np.median(ts)))
-        print(f"ks {ks} grid {G}: RB 24 / 32 / 48 / auto = " + " / ".join(f"{v:.1f}" for v in row), flush=True)
+        print(f"ks {ks} grid {G} S {S}: default / blkw RB 24 / 32 / 48 = " + " / ".join(f"{v:.1f}" for v in row), flush=True)
