@@ -1418,6 +1418,20 @@ int aadff_post_computation(int S, const aadff_surface_t* surf_green, aadff_lens_
     return 0;
 }
 
+// The address at which the GPU sees a block of pinned host memory (hipHostMalloc / torch pin_memory), or an error when the block
+// is not device-mapped: the per-call API hands such addresses to aadff_refocus (2 x 2048 draws and the depth read over PCIe by one
+// workgroup) and as `points` to aadff_psf_points_staged instead of queueing a copy in front of every launch.
+int aadff_host_device_pointer(const void* host, void** dev_out) {
+    AADFF_CHECK_ARG(host && dev_out, "host_device_pointer: NULL pointer");
+    void* mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, const_cast<void*>(host), 0) != hipSuccess || !mapped) {
+        (void)hipGetLastError();
+        AADFF_CHECK_ARG(false, "host_device_pointer: not pinned (device-mapped) host memory");
+    }
+    *dev_out = mapped;
+    return 0;
+}
+
 __global__ void publish_flags_kernel(const int* __restrict__ flags, int* mirror) {
     if (threadIdx.x == 0) __hip_atomic_store(mirror, __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

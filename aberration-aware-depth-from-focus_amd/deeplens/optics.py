@@ -67,12 +67,42 @@ class _CallRing:
     SLOTS = 16
 
     def __init__(self, dev, words):
-        self.words = int(words)
+        self.words = (int(words) + 3) // 4 * 4               # 16-byte aligned blocks (the staged upload copies float4s)
         self.host = torch.empty((self.SLOTS, self.words), dtype=torch.float32, pin_memory=True)
         self.dev = torch.empty((self.SLOTS, self.words), dtype=torch.float32, device=dev)
         self.events = [torch.cuda.Event() for _ in range(self.SLOTS)]
         self.used = [False] * self.SLOTS
         self.turn = 0
+        # No copy in front of a launch where the kernel can fetch the block itself (round 5: a copy and the dispatch gap behind it
+        # were 15 us of every refocus / psf_map call, a fifth of the reference's slice loop): `mapped` = the address at which the
+        # GPU sees the pinned blocks (refocus reads its 16 KB over PCIe; psf launches stage theirs into `dev` with their first
+        # workgroups: aadff_psf_points_staged), a completion counter per block for those.
+        self.mapped = None
+        if os.environ.get("AADFF_CALL_ZERO_COPY", "1") != "0":
+            out = C.c_void_p()
+            try:
+                _abi.call("aadff_host_device_pointer", C.c_void_p(self.host.data_ptr()), C.byref(out))
+                self.mapped = out.value
+            except RuntimeError:
+                self.mapped = None
+        self.counters = torch.zeros(self.SLOTS, dtype=torch.int32, device=dev)
+        self.gen = [0] * self.SLOTS
+        self.shape = [None] * self.SLOTS
+
+    def mapped_ptr(self, k):
+        """device-visible address of pinned block k"""
+        return self.mapped + 4 * self.words * k
+
+    def stage(self, k, n_u, shape):
+        """aadff_stage_t for block k: the launch's first workgroups copy its first n_u words (a multiple of 4) from the pinned block to
+        the device block and count themselves into the block's counter; a launch of another shape has another number of copy
+        workgroups, so the counter restarts then."""
+        if self.shape[k] != shape:
+            self.counters[k:k + 1].zero_()
+            self.gen[k], self.shape[k] = 0, shape
+        self.gen[k] += 1
+        return _abi.Stage(self.host.data_ptr() + 4 * self.words * k, self.dev.data_ptr() + 4 * self.words * k, n_u, 0, self.gen[k] & 0xFFFFFFFF,
+                          self.counters.data_ptr() + 4 * k)
 
     def next(self):
         k = self.turn % self.SLOTS
@@ -360,8 +390,12 @@ class Lensgroup(DeepObj):
                 k, h, d = ring.next()
                 self.sampler.rand_into(h[:2 * GEO_SPP])
                 h[2 * GEO_SPP] = float(depth)
-                ring.sent(k, 2 * GEO_SPP + 4, stream)
-                _abi.call("aadff_refocus", C.c_void_p(d.data_ptr() + 8 * GEO_SPP), 1, C.c_void_p(d.data_ptr()), GEO_SPP, 2 * GEO_SPP,
+                if ring.mapped is not None:                  # the one workgroup reads draws and depth from the pinned block itself
+                    base = ring.mapped_ptr(k)
+                else:
+                    ring.sent(k, 2 * GEO_SPP + 4, stream)
+                    base = d.data_ptr()
+                _abi.call("aadff_refocus", C.c_void_p(base + 8 * GEO_SPP), 1, C.c_void_p(base), GEO_SPP, 2 * GEO_SPP,
                           _abi.ptr(self._table([DEFAULT_WAVE])), lc, _abi.ptr(st), C.c_void_p(stream.cuda_stream))
                 ring.launched(k, stream)
         self._state_stale = True
@@ -600,7 +634,9 @@ class Lensgroup(DeepObj):
                 k, h, d = ring.next()
                 self.sampler.rand_into(h[:n_u])              # one fill = the reference's 4 L torch.rand calls, same generator stream
                 h[n_u:n_u + 3 * N].view(N, 3).copy_(points)
-                ring.sent(k, n_u + 3 * N, stream)
+                staged = ring.mapped is not None and n_u % 4 == 0 and not torch.compiler.is_compiling()
+                if not staged:
+                    ring.sent(k, n_u + 3 * N, stream)
                 if torch.compiler.is_compiling():
                     out = torch.ops.aadff.psf_points_block(d[n_u:n_u + 3 * N].view(N, 3), self._table(wvlns), self._table([DEFAULT_WAVE]), lcl[1],
                                                            self._state_device(), d[:n_u], L, spp, spc, ks, bool(map_layout), flags)
@@ -608,10 +644,16 @@ class Lensgroup(DeepObj):
                     g = int(round(N ** 0.5))
                     out = torch.empty((L, g * ks, g * ks) if map_layout else (N, L, ks, ks), dtype=torch.float32, device=dev)
                     per_l, base = 2 * spp + 2 * spc, d.data_ptr()
-                    _abi.call("aadff_psf_points", C.c_void_p(base + 4 * n_u), 1, N, L, _abi.ptr(self._table(wvlns)), _abi.ptr(self._table([DEFAULT_WAVE])),
-                              self._lens_const(), _abi.ptr(self._state_device()), C.c_void_p(base), spp, L * per_l, per_l,
-                              C.c_void_p(base + 8 * spp) if spc else None, spc, L * per_l, per_l, ks, int(spc > 0), int(map_layout), _abi.ptr(out), None,
-                              _abi.ptr(flags), C.c_void_p(stream.cuda_stream))
+                    if staged:      # the draws are copied by the launch's first workgroups, the points read where they lie (12 bytes per workgroup)
+                        _abi.call("aadff_psf_points_staged", C.c_void_p(ring.mapped_ptr(k) + 4 * n_u), 1, N, L, _abi.ptr(self._table(wvlns)),
+                                  _abi.ptr(self._table([DEFAULT_WAVE])), self._lens_const(), _abi.ptr(self._state_device()), C.c_void_p(base), spp, L * per_l, per_l,
+                                  C.c_void_p(base + 8 * spp) if spc else None, spc, L * per_l, per_l, ks, int(spc > 0), int(map_layout), _abi.ptr(out), None,
+                                  _abi.ptr(flags), C.byref(ring.stage(k, n_u, (N, L, n_u))), C.c_void_p(stream.cuda_stream))
+                    else:
+                        _abi.call("aadff_psf_points", C.c_void_p(base + 4 * n_u), 1, N, L, _abi.ptr(self._table(wvlns)), _abi.ptr(self._table([DEFAULT_WAVE])),
+                                  self._lens_const(), _abi.ptr(self._state_device()), C.c_void_p(base), spp, L * per_l, per_l,
+                                  C.c_void_p(base + 8 * spp) if spc else None, spc, L * per_l, per_l, ks, int(spc > 0), int(map_layout), _abi.ptr(out), None,
+                                  _abi.ptr(flags), C.c_void_p(stream.cuda_stream))
                 ring.launched(k, stream)
             self._psf_calls += 1
             if self.sync_flags:

@@ -398,6 +398,11 @@ int aadff_refocus_staged(const float* depth, int S, const float* u_host, float* 
                          long u_stride_s, const aadff_surface_t* surf_green, aadff_lens_const_t lc,
                          aadff_lens_state_t* states, void* scratch, aadff_stream_t stream);
 
+/* The device-visible address of a block of PINNED host memory (error when it is not device-mapped).  The per-call mirror of
+ * Lensgroup.refocus / psf_map (deeplens/optics.py:1155-1180, :888-1026) passes such addresses to aadff_refocus (draws and depth
+ * read over PCIe by the one workgroup) and as `points` of aadff_psf_points_staged, so that no copy is queued in front of a launch. */
+int aadff_host_device_pointer(const void* host, void** dev_out);
+
 /* hfov/foclen/fnum for states whose d_sensor is already set (lens load, or a caller
  * that assigns d_sensor).  Replaces post_computation, deeplens/optics.py:178-187. */
 int aadff_post_computation(int S, const aadff_surface_t* surf_green, aadff_lens_const_t lc,

@@ -1511,6 +1511,40 @@ def test_staged_upload_late_block_is_read_from_pinned_memory(repo_root, monkeypa
             raise_psf_flags(bits[True])
 
 
+def test_per_call_api_without_copies_equals_the_copy_path(repo_root, monkeypatch):
+    """Round 5: `refocus` reads its draws and depth from the pinned call block over PCIe and `psf_map` / `psf` / `psf_rgb` launches
+    stage theirs with their first workgroups (`aadff_psf_points_staged`, S = 1, first_slice 0; the points are read where they lie) -
+    no hipMemcpyAsync in front of a launch.  Same draws, same kernels: the lens state is bit-equal to the copy path's
+    (`AADFF_CALL_ZERO_COPY=0`), the PSFs equal to the histogram's float atomics, over a sequence that changes the launch shape (the
+    per-block completion counters restart), reuses every ring block more than once and ends where the copy path leaves the generator."""
+    from deeplens.optics import _CallRing
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AADFF_CALL_ZERO_COPY", mode)
+        lens = Lensgroup(lens_path(repo_root, "rf50mm"), sensor_res=(128, 128), device=DEV)
+        torch.manual_seed(5)
+        outs = []
+        for i in range(2 * _CallRing.SLOTS + 3):
+            lens.refocus(-1500.0 - 40.0 * i)
+            outs.append(torch.tensor([lens.d_sensor, lens.hfov, lens.foclen, lens.fnum], dtype=torch.float64))
+            if i % 3 == 0:
+                outs.append(lens.psf_map(depth=-1200.0, grid=5, ks=11, spp=512).cpu().double().flatten())
+            elif i % 3 == 1:
+                outs.append(lens.psf(torch.tensor([[0.3, -0.2, -900.0], [0.0, 0.0, -2000.0]]), ks=11, spp=1024).cpu().double().flatten())
+            else:
+                outs.append(lens.psf_rgb(torch.tensor([0.1, 0.4, -1700.0]), ks=9, spp=256).cpu().double().flatten())
+        lens.check_flags()
+        assert (lens._ring.mapped is not None) == (mode == "1")
+        res[mode] = (outs, torch.rand(1).item())
+    monkeypatch.delenv("AADFF_CALL_ZERO_COPY")
+    assert res["1"][1] == res["0"][1]
+    for a, b in zip(res["1"][0], res["0"][0]):
+        if a.numel() == 4:
+            assert torch.equal(a, b)                                             # refocus: one workgroup, fixed summation order
+        else:
+            assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()    # PSF histograms: float atomics
+
+
 def test_paired_band_convolution_is_bit_equal_to_one_band_per_workgroup(monkeypatch):
     """AADFF_CONV_PAIR=N (round-3 experiment kept as an option: a workgroup renders two consecutive bands of every N-th
     (patch, plane), the second band prefetched by LDS-DMA into the memory the tap rows no longer need) against the default
