@@ -35,3 +35,8 @@ timeout 300 python bench.py --mode m2 > gpurun_out/${TAG}_bench_m2.json 2>/dev/n
 timeout 300 python bench.py --mode m1l > gpurun_out/${TAG}_bench_m1l.json 2>/dev/null
 timeout 300 python tools/conv_ks_sweep.py > gpurun_out/${TAG}_conv_ks_sweep.txt 2>/dev/null
 timeout 300 python tools/kbench.py > gpurun_out/${TAG}_kbench.txt 2>/dev/null
+timeout 300 python tools/conv_blkw_probe.py 2>/dev/null | tail -22 > gpurun_out/${TAG}_conv_blkw_probe.txt
+timeout 200 python tools/conv_single_timeline.py --ks 21 --grid 7 --json gpurun_out/${TAG}_conv_blkw_timeline_ks21.json > /dev/null 2>&1
+AADFF_CONV_BLKW_RB=24 timeout 200 python tools/conv_single_timeline.py --ks 21 --grid 7 --json gpurun_out/${TAG}_conv_blkw_timeline_ks21_rb24.json > /dev/null 2>&1
+PROBE_DEPTHS=3 timeout 300 python tools/strict_pipe_probe.py 30 2>/dev/null | grep -v "^/opt" > gpurun_out/${TAG}_strict_pipe_probe.txt
+AADFF_CALL_ZERO_COPY=0 timeout 300 python tools/dropin_bench.py 20 > gpurun_out/${TAG}_dropin_with_copies.txt 2>/dev/null

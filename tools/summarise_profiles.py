@@ -69,12 +69,13 @@ for name, sub in (("kernel_stats", "stats"), ("kernel_stats_1stream", "stats_s1"
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.csv"))
 for name in ("bench", "bench_fit", "bench_m2", "bench_2streams", "bench_refocus_overlap", "bench_1stream", "bench_c3", "bench_under_rocprof",
              "conv_timeline", "conv_timeline_paired", "parity_per_slice_shipped", "parity_per_slice_literal", "parity_per_slice_strict",
-             "conv_single_timeline", "conv_single_timeline_toeplitz", "bench_rccl1_gather", "bench_m1l", "code_sha256"):
+             "conv_single_timeline", "conv_single_timeline_toeplitz", "bench_rccl1_gather", "bench_m1l", "code_sha256",
+             "conv_blkw_timeline_ks21", "conv_blkw_timeline_ks21_rb24"):
     src = os.path.join(G, f"{tag}_{name}.json")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.json"))
 
-for name in ("conv_ks_sweep", "strict_profile", "kbench", "dropin"):
+for name in ("conv_ks_sweep", "strict_profile", "kbench", "dropin", "conv_blkw_probe", "strict_pipe_probe", "dropin_with_copies"):
     src = os.path.join(G, f"{tag}_{name}.txt")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.txt"))
@@ -132,4 +133,4 @@ for txt in ("latency_breakdown.txt", "soak.txt", "kbench.txt", "kbench_toeplitz.
 lp = one(f"{tag}_lp_fetch/**/*counter_collection.csv")
 if lp:
     write_pmc(os.path.join(P, f"{tag}_local_psf_fetch_pmc.csv"), [lp], ("local_psf",))
-print(sorted(os.listdir(P)))
+print(sorted(f for f in os.listdir(P) if f.startswith(tag)))
