@@ -404,6 +404,7 @@ class _Stage:
         self.bt_main = torch.arange(L, dtype=i32).repeat(S).to(dev)
         self.bt_green = torch.full((max(B, J),), t_green, dtype=i32, device=dev)
         self.zeros = torch.zeros(J, dtype=i32, device=dev)
+        self.events = [torch.cuda.Event() for _ in sizes]
         # where the uniforms of every batch of pupil points sit in the stack's flat block of draws (stack_uniform_layout)
         from .focal_stack import stack_uniform_layout
         per, o_main, o_chief, per_l = stack_uniform_layout(spp, L)
@@ -419,19 +420,19 @@ class _Stage:
         return st
 
     def submit(self, i, n_up, n_down, launch, stream):
-        """enqueue: upload the first n_up words of parameter block i, launch, download the first n_down result words"""
+        """enqueue: upload the first n_up words of parameter block i, launch, download the first n_down result words; returns the
+        event recorded behind the download (the generators of this module `yield` it: the sequential driver waits for it, the
+        pipeline goes on with another stack until it has happened)"""
         with torch.cuda.stream(stream):
             self.d_par[i][:n_up].copy_(self.h_par[i][:n_up], non_blocking=True)
             launch(self.d_par[i], self.d_res[i])
             self.h_res[i][:n_down].copy_(self.d_res[i][:n_down], non_blocking=True)
+            self.events[i].record(stream)
+        return self.events[i]
 
-    def wait(self, i, stream):
-        stream.synchronize()
+    def result(self, i):
+        """the result block of the last `submit(i, ...)` once its event has happened"""
         return self.h_res[i].numpy()
-
-    def round_trip(self, i, n_up, n_down, launch, stream):
-        self.submit(i, n_up, n_down, launch, stream)
-        return self.wait(i, stream)
 
 
 def _ptr_at(t, word):
@@ -448,8 +449,9 @@ def _speculate_small(counts, key, st, lvl, S, n, curved, order, launch, stream):
     """A cheap level (S batches of n rays) on speculated counts: every batch is traced under each candidate row of the table at
     once (`StrictCounts.candidates`: 2048-ray batches cost nothing, a second round trip costs 60-100 us), the first candidate whose
     any-bits confirm it is the batch's result; batches without one are re-launched with the row `check_counts` corrected.
-    `launch(J, par, res)` enqueues the kernel for J jobs.  Returns (out0 [S,n], out1 [S,n]) float32, or None when some batch is still
-    unconfirmed after FUSED_ROUNDS launches (the caller falls back to the per-surface form)."""
+    `launch(J, par, res)` enqueues the kernel for J jobs.  A generator (yields the event of every launch; `yield from` it): returns
+    (out0 [S,n], out1 [S,n]) float32, or None when some batch is still unconfirmed after FUSED_ROUNDS launches (the caller falls back
+    to the per-surface form)."""
     MS, G = _abi.MAX_SURF, st.G[lvl]
     cand = [(b, row) for b in range(S) for row in counts.candidates(key, b, JOBS_PER_BATCH)]
     out0, out1 = np.empty((S, n), dtype=np.float32), np.empty((S, n), dtype=np.float32)
@@ -461,7 +463,8 @@ def _speculate_small(counts, key, st, lvl, S, n, curved, order, launch, stream):
         pred = np.stack([row for _, row in cand]).astype(np.int32)
         h[G:G + J] = [b for b, _ in cand]
         h[G + st.J:G + st.J + J * MS] = pred.reshape(-1)
-        r = st.round_trip(lvl, G + st.J + J * MS, 2 * J * n + J * 2 * MS, lambda par, res: launch(J, par, res), stream)
+        yield st.submit(lvl, G + st.J + J * MS, 2 * J * n + J * 2 * MS, lambda par, res: launch(J, par, res), stream)
+        r = st.result(lvl)
         counts.stats["fused"] += 1
         bits = r[2 * J * n:2 * J * n + J * 2 * MS].view(np.uint32).reshape(J, 2, MS)
         ok, fix = check_counts(bits[:, 0], pred, curved, order)
@@ -493,15 +496,15 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None):
     steps = _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused)
     try:
         while True:
-            next(steps)
+            next(steps).synchronize()                        # every yield is the event of a launch whose result the next step reads
     except StopIteration as done:
         return done.value
 
 
 def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None):
-    """`strict_psf_maps` as a generator: yields once, right after the psf_map launch of the stack is queued (fused form only) - what
-    comes before is host arithmetic and the two short levels, what comes after waits for that launch.  `StrictPipeline` runs the
-    first half of the next stack in the gap.  Returns the maps (StopIteration.value)."""
+    """`strict_psf_maps` as a generator: every host wait of the fused form - the round trips of the two short levels, the psf_map
+    launch, its re-launches - is a `yield` of the event to wait for.  `strict_psf_maps` waits right there; `StrictPipeline` goes on
+    with whichever other stack's event has happened.  Returns the maps (StopIteration.value)."""
     from .focal_stack import stack_uniform_layout
     if ks > _abi.MAX_KS:
         raise ValueError(f"ks={ks} exceeds the kernels' limit {_abi.MAX_KS}")
@@ -585,7 +588,7 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                           _ptr_at(par, 0), _ptr_at(par, G), _abi.ptr(st.d_pupil), 1, 0, n_surf, 1, None, _ptr_at(par, G + st.J),
                           _ptr_at(res, 2 * J * GEO_SPP), 1, 1, _ptr_at(res, 0), _ptr_at(res, J * GEO_SPP), _ptr_at(par, G), sp12)
 
-            got = _speculate_small(counts, keys[0], st, 0, S, GEO_SPP, curved, fwd_order, launch1, s12)
+            got = yield from _speculate_small(counts, keys[0], st, 0, S, GEO_SPP, curved, fwd_order, launch1, s12)
             if got is not None:
                 fd_all, alive = got[0], got[1] > 0
         if not fused or got is None:
@@ -612,7 +615,7 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                           _ptr_at(res, 2 * J * M), 0, 2, _ptr_at(res, 0), _ptr_at(res, J * M), _abi.ptr(st.zeros), sp12)
 
             mark("level 2 rays")
-            got = _speculate_small(counts, keys[1], st, 1, S, M, curved, bwd_order if backward else fwd_order, launch2, s12)
+            got = yield from _speculate_small(counts, keys[1], st, 1, S, M, curved, bwd_order if backward else fwd_order, launch2, s12)
             if got is not None:
                 tan_fov, rra = torch.from_numpy(got[0]), torch.from_numpy(got[1])
         else:
@@ -648,14 +651,16 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
             pupils_ready.result()
             st.d_pupil[st.n_pf:].copy_(hp[st.n_pf:], non_blocking=True)
             mark("level 3 inputs")
-            after = getattr(lens, "_strict_l3_after", None)
-            if after is not None:
+            chain = getattr(lens, "_strict_l3_chain", None)
+            if chain is not None and chain[0] is not None:
                 # StrictPipeline: behind the psf_map launch of the stack in front, not beside it - two such launches sharing the chip
                 # finish together, and the host would learn the first one's counts 3 ms later
-                stream.wait_event(after)
-            st.submit(2, h.numel(), B * 4 * MS + B, lambda par, res: launch3(B, None, _ptr_at(par, B + S * N * 3), res), stream)
-            yield "psf_map queued"
-            r = st.wait(2, stream)
+                stream.wait_event(chain[0])
+            ev3 = st.submit(2, h.numel(), B * 4 * MS + B, lambda par, res: launch3(B, None, _ptr_at(par, B + S * N * 3), res), stream)
+            if chain is not None:
+                chain[0] = ev3
+            yield ev3
+            r = st.result(2)
             mark("level 3 launch waited for")
             counts.stats["fused"] += 1
             hb = r[:B * 4 * MS].view(np.uint32).reshape(B, 2, 2, MS)
@@ -675,7 +680,8 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                 hr = st.h_par[3].numpy()
                 hr[:J] = bad
                 hr[B:B + J * 2 * MS] = rows.reshape(-1)
-                r = st.round_trip(3, B + J * 2 * MS, J * 4 * MS + J, lambda par, res: launch3(J, _ptr_at(par, 0), _ptr_at(par, B), res, sp12), s12)
+                yield st.submit(3, B + J * 2 * MS, J * 4 * MS + J, lambda par, res: launch3(J, _ptr_at(par, 0), _ptr_at(par, B), res, sp12), s12)
+                r = st.result(3)
                 counts.stats["fused_replays"] += 1
                 jb = r[:J * 4 * MS].view(np.uint32).reshape(J, 2, 2, MS)
                 okj2, fixj = check_counts(jb[:, :, 0], rows, curved, fwd_order)
@@ -725,38 +731,40 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
 
 
 class StrictPipeline:
-    """Strict-parity stacks software-pipelined on ONE host thread: `depth` strict lenses (count table, staging blocks, HIP stream
-    each; 3 by default: with 2 the host blocks on a re-launch while nothing else is queued) take turns; `submit` runs a stack up to its psf_map launch (draws, host arithmetic, the two short levels - ~1.8 ms of
-    host time and round trips, on a high-priority stream so that they do not queue behind the 3 ms launch in front) and returns;
-    the stack is finished (wait, count check, re-launches, convolution) when its lens is needed again or its result is asked for.
-    The GPU then goes from one psf_map launch to the next while the host prepares the one after.  Draws are taken at `submit`, in
-    submission order: every stack is bit for bit what `render_focal_stack_m1(strict_lens, ...)` returns for it in a sequential loop
-    (to the histograms' float atomics).  `submit(...)` returns a handle whose `result()` is (stack [B,C,S,H,W], event recorded
-    behind its convolution).  (A first version ran the stacks on two host threads: the interpreter lock made it slower than the
-    sequential loop - profiles/r05_x_bench.json, `timed_two_in_flight` 8.7 ms against 6.4.)"""
+    """Strict-parity stacks interleaved on ONE host thread: `depth` strict lenses (count table, staging blocks, HIP stream each; 4 by
+    default: 3.3 - 3.5 ms per stack, the psf_map launches back to back on the GPU; 3: 3.6 - 3.8; 2: 4.3 - 4.5; sequential 5.1 - 5.5) take turns, and every host wait of a stack - the round trips of its two short levels, its psf_map launch, a re-launch
+    - is a point where the host goes on with whichever other stack is ready (`_strict_psf_maps_steps` yields the event it would wait
+    for; the pipeline polls them, oldest stack first).  The short levels and the re-launches run on a high-priority stream so that
+    they do not queue behind the 3 ms psf_map launch of another stack, psf_map launches are chained by an event (side by side they
+    would finish together), re-launches use the 256-thread form.  Draws are taken at `submit`, in submission order: every stack
+    is bit for bit what `render_focal_stack_m1(strict_lens, ...)` returns for it in a sequential loop (to the histograms' float
+    atomics).  `submit(...)` returns a handle whose `result()` is (stack [B,C,S,H,W], event recorded behind its convolution).
+    (History, DESIGN.md section 2: two host threads - slower than the sequential loop under the interpreter lock; one thread with one
+    switch point per stack - 4.4 ms against 5.2 sequential; this form.)"""
 
     class _Pending:
         def __init__(self, pipe, k, steps):
-            self.pipe, self.k, self.steps, self.value = pipe, k, steps, None
+            self.pipe, self.k, self.steps, self.value, self.event = pipe, k, steps, None, None
 
         def result(self):
-            self.pipe._finish_through(self.k)
+            self.pipe._drive(lambda: self.steps is None)
             return self.value
 
-    def __init__(self, make_lens, depth=3):
+    def __init__(self, make_lens, depth=4):
         self.depth = int(depth)
         self.lenses = [make_lens() for _ in range(self.depth)]
         assert all(getattr(l, "parity", "") == "strict" for l in self.lenses), "StrictPipeline renders strict-parity lenses"
         dev = self.lenses[0]._gpu()
         self.streams = [torch.cuda.Stream(dev) for _ in range(self.depth)]
-        if os.environ.get("AADFF_STRICT_PRIO", "1") != "0":
-            for l in self.lenses:
+        self.chain = [None]                                  # the event behind the newest psf_map launch, shared by the lenses
+        for l in self.lenses:
+            l._strict_l3_chain = self.chain
+            if os.environ.get("AADFF_STRICT_PRIO", "1") != "0":
                 l._strict_fast_stream = torch.cuda.Stream(dev, priority=-1)
-        _abi.call("aadff_strict_replay_threads", 256)        # re-launches run beside the next stack's psf_map launch
+        _abi.call("aadff_strict_replay_threads", 256)        # re-launches run beside another stack's psf_map launch
         self.pending = []                                    # oldest first
-        self.l3_tail = None                                  # recorded behind the newest psf_map launch
-        self.trace = [] if os.environ.get("AADFF_STRICT_PIPE_TRACE") == "1" else None       # (stack, "in" / "out" of a half, seconds)
         self.turn = 0
+        self.trace = [] if os.environ.get("AADFF_STRICT_PIPE_TRACE") == "1" else None       # (stack, "in" / "out" of a step, seconds)
 
     def _steps(self, lens, img, depth_plane_mm, focus_mm, grid, ks, spp):
         focus = [float(f) for f in np.asarray(focus_mm, dtype=np.float64).reshape(-1)]
@@ -771,49 +779,51 @@ class StrictPipeline:
         return out
 
     def _advance(self, p):
-        """run stack p to its next yield; at the end set p.value = (stack, event)"""
+        """run stack p to its next wait (p.event) or to its end (p.value = (stack, event), p.steps = None)"""
         i = p.k % self.depth
         with torch.no_grad(), torch.cuda.stream(self.streams[i]):
+            if self.trace is not None:
+                self.trace.append((p.k, "in", time.perf_counter()))
             try:
-                self.lenses[i]._strict_l3_after = self.l3_tail
-                if self.trace is not None:
-                    self.trace.append((p.k, "in", time.perf_counter()))
-                try:
-                    next(p.steps)
-                finally:
-                    if self.trace is not None:
-                        self.trace.append((p.k, "out", time.perf_counter()))
-                self.l3_tail = torch.cuda.Event()
-                self.l3_tail.record(self.streams[i])
-                return False
+                p.event = next(p.steps)
             except StopIteration as done:
                 ev = torch.cuda.Event()
                 ev.record(self.streams[i])
-                p.value, p.steps = (done.value, ev), None
-                return True
-
-    def _finish_through(self, k):
-        while self.pending and self.pending[0].k <= k:
-            p = self.pending.pop(0)
-            try:
-                while not self._advance(p):
-                    pass
+                p.value, p.steps, p.event = (done.value, ev), None, None
+                self.pending.remove(p)
             except BaseException:
-                p.steps = None
+                p.steps, p.event = None, None
+                self.pending.remove(p)
                 raise
+            finally:
+                if self.trace is not None:
+                    self.trace.append((p.k, "out", time.perf_counter()))
+
+    def _drive(self, done):
+        """advance ready stacks (oldest first) until done(); when none is ready, wait for the oldest one's event"""
+        while not done():
+            ready = next((p for p in self.pending if p.event.query()), None)
+            if ready is None:
+                self.pending[0].event.synchronize()
+                ready = self.pending[0]
+            self._advance(ready)
 
     def submit(self, img, depth_plane_mm, focus_mm, grid=11, ks=11, spp=GEO_SPP):
         k = self.turn
         self.turn += 1
-        self._finish_through(k - self.depth)                 # the stack that had this lens
+        self._drive(lambda: all(p.k % self.depth != k % self.depth for p in self.pending))      # the stack that has this lens is done
         p = StrictPipeline._Pending(self, k, self._steps(self.lenses[k % self.depth], img, depth_plane_mm, focus_mm, grid, ks, spp))
-        if self._advance(p):                                 # a seed run (no count table yet) goes through in one piece
-            return p
         self.pending.append(p)
+        self._advance(p)                                     # draws, host arithmetic and the first launch of the stack
+        while True:                                          # and whatever else is ready meanwhile
+            ready = next((q for q in self.pending if q.event.query()), None)
+            if ready is None:
+                break
+            self._advance(ready)
         return p
 
     def close(self):
         try:
-            self._finish_through(self.turn)
+            self._drive(lambda: not self.pending)
         finally:
             _abi.call("aadff_strict_replay_threads", 1024)

@@ -482,11 +482,11 @@ def main():
                                                         "arithmetic; one fused launch per level on speculated batch-wide Newton counts, verified from the any-bits "
                                                         "and re-launched where a count was off (aadff/strict_stack.py, csrc/strict_fused.hip); DESIGN.md section 2"}
                 _ss.release_buffers(ls)
-                # the same mode with THREE stacks in flight (StrictPipeline: three lenses / streams software-pipelined on this thread; draws at submission)
+                # the same mode with FOUR stacks in flight (StrictPipeline: four lenses / streams software-pipelined on this thread; draws at submission)
                 try:
-                    pipe2 = _ss.StrictPipeline(lambda: Lensgroup(lens_path, sensor_res=(H, W), device=dev, parity="strict"), depth=3)
+                    pipe2 = _ss.StrictPipeline(lambda: Lensgroup(lens_path, sensor_res=(H, W), device=dev, parity="strict"), depth=4)
                     torch.manual_seed(1)
-                    for f_ in [pipe2.submit(img, dbar, fds, GRID, KS, SPP) for _ in range(9)]:       # seeds the lenses' count tables, warms
+                    for f_ in [pipe2.submit(img, dbar, fds, GRID, KS, SPP) for _ in range(12)]:      # seeds the lenses' count tables, warms
                         f_.result()[1].synchronize()
                     torch.cuda.synchronize(dev)
                     t_p = time.perf_counter()
@@ -501,8 +501,8 @@ def main():
                         _ss.release_buffers(l_)
                     res["parity"]["strict_mode"]["timed_pipelined"] = {
                         "steps": n_strict, "ms_per_step": round(t_p * 1e3, 3), "value": round(S * H * W / 1e6 / t_p, 1), "unit": "MP/s",
-                        "what": "aadff.strict_stack.StrictPipeline(depth=3), one host thread: the host side and the two short levels of stack k + 1 run between "
-                                "the psf_map launch of stack k and the wait for it; same stacks as the sequential loop (draws at submission)"}
+                        "what": "aadff.strict_stack.StrictPipeline(depth=4), one host thread: every host wait of a stack (round trips of the short levels, "
+                                "psf_map launch, re-launches) is where the host goes on with another stack; same stacks as the sequential loop (draws at submission)"}
                 except Exception as e:
                     res["parity"]["strict_mode"]["timed_pipelined"] = {"error": repr(e)}
                 if not max(per2) <= 1e-4:

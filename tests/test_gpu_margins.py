@@ -539,8 +539,8 @@ def test_bf16_train_step_runs_and_tracks_fp32(repo_root, margin):
 
 
 def test_strict_pipeline_equals_the_sequential_loop(repo_root, margin):
-    """aadff.strict_stack.StrictPipeline (round 5): two strict stacks in flight (two lenses / streams, one host thread: the first half
-    of stack k + 1 runs between the psf_map launch of stack k and the wait for it).  The host draws are taken at submission, so every
+    """aadff.strict_stack.StrictPipeline (round 5): two / four strict stacks in flight (as many lenses / streams, one host thread: at every
+    host wait of a stack the host goes on with another one whose awaited launch has finished).  The host draws are taken at submission, so every
     stack equals the one the sequential loop renders from the same generator (PSF histograms are float atomics: 2e-6 of the peak),
     the generator ends where the loop leaves it, and results may be asked for in any order."""
     import time
@@ -555,16 +555,18 @@ def test_strict_pipeline_equals_the_sequential_loop(repo_root, margin):
     torch.manual_seed(21)
     want = [render_focal_stack_m1(seq_lens, img, dbar, fds, grid, 11, spp).clone() for _ in range(n)]
     tail = torch.rand(1).item()
-    pipe = StrictPipeline(make, depth=2)
-    torch.manual_seed(21)
-    futs = [pipe.submit(img, dbar, fds, grid, 11, spp) for _ in range(n)]
-    got = [None] * n
-    for k in (1, 0, 2, 5, 4, 3):
-        out, ev = futs[k].result()
-        ev.synchronize()
-        got[k] = out
-    pipe.close()
-    assert not pipe.pending
-    assert torch.rand(1).item() == tail
-    worst = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(got, want))
-    margin("strict pipeline (2 stacks in flight) vs sequential loop, max |d| / max over 6 stacks", worst, 2e-6)
+    worst = 0.0
+    for depth_n in (2, 4):
+        pipe = StrictPipeline(make, depth=depth_n)
+        torch.manual_seed(21)
+        futs = [pipe.submit(img, dbar, fds, grid, 11, spp) for _ in range(n)]
+        got = [None] * n
+        for k in (1, 0, 2, 5, 4, 3):
+            out, ev = futs[k].result()
+            ev.synchronize()
+            got[k] = out
+        pipe.close()
+        assert not pipe.pending
+        assert torch.rand(1).item() == tail
+        worst = max(worst, max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(got, want)))
+    margin("strict pipeline (2 and 4 stacks in flight) vs sequential loop, max |d| / max over 6 stacks", worst, 2e-6)
