@@ -359,6 +359,12 @@ __global__ void selftest_ops_kernel(const float* __restrict__ num, const float* 
         const f2 b = {den[i], den[k]};
         q = div2(a, b);
         r0 = a.x / b.x; r1 = a.y / b.y;
+    } else if (op == 2) {                                // n / (d * d) with the reciprocal of d * d grown from the one of d (sag_dsag2)
+        const f2 b = {den[i], den[k]};
+        const f2 b2 = b * b;
+        const f2 rb = recip2(b);
+        q = div2_r(a, b2, recip_refine2(b2, rb * rb));
+        r0 = a.x / b2.x; r1 = a.y / b2.y;
     } else {
         q = sqrt2(a);
         r0 = sqrtf(a.x); r1 = sqrtf(a.y);
@@ -443,7 +449,7 @@ extern "C" int aadff_strict_psf_points(const float* points, int N, int B, const 
 }
 
 extern "C" int aadff_selftest_strict_ops(const float* num, const float* den, int n, int op, unsigned* mismatches, aadff_stream_t stream) {
-    AADFF_CHECK_ARG(num && (den || op == 1) && mismatches && n >= 0 && (op == 0 || op == 1), "selftest_strict_ops: bad arguments");
+    AADFF_CHECK_ARG(num && (den || op == 1) && mismatches && n >= 0 && op >= 0 && op <= 2, "selftest_strict_ops: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     AADFF_CHECK_HIP(hipMemsetAsync(mismatches, 0, 17 * sizeof(unsigned), st));
     if (n == 0) return 0;

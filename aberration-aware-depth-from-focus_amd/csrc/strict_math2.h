@@ -44,10 +44,18 @@ __device__ __forceinline__ f2 sqrt2(f2 x) {
     return (f2){keep.x ? x.x : r.x, keep.y ? x.y : r.y};
 }
 
-__device__ __forceinline__ f2 div2(f2 n, f2 d) {
-    f2 r = (f2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-    const f2 e = fma2(-d, r, f2s(1.f));
-    r = fma2(e, r, r);
+// The division in two halves: the refined reciprocal of the denominator (from any approximation r0 with a relative error of a
+// few 2^-23: one Newton step), then quotient, two residual corrections and the fix-up.  Several quotients over ONE denominator
+// share the reciprocal (the three components of a normal), and the reciprocal of d * d starts from the square of the refined
+// reciprocal of d instead of a second pair of quarter-rate v_rcp_f32 (sag and d sag / d r^2 divide by 1 + sf and (1 + sf)^2):
+// the quotient is the correctly rounded one either way - `aadff_selftest_strict_ops` op 2 checks that form for EVERY float
+// 1 + sf in [1, 2] against the compiler's division.
+__device__ __forceinline__ f2 recip_refine2(f2 d, f2 r0) {
+    const f2 e = fma2(-d, r0, f2s(1.f));
+    return fma2(e, r0, r0);
+}
+__device__ __forceinline__ f2 recip2(f2 d) { return recip_refine2(d, (f2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)}); }
+__device__ __forceinline__ f2 div2_r(f2 n, f2 d, f2 r) {
     f2 q = n * r;
     const f2 e2 = fma2(-d, q, n);
     q = fma2(e2, r, q);
@@ -55,6 +63,7 @@ __device__ __forceinline__ f2 div2(f2 n, f2 d) {
     q = fma2(e3, r, q);
     return (f2){__builtin_amdgcn_div_fixupf(q.x, d.x, n.x), __builtin_amdgcn_div_fixupf(q.y, d.y, n.y)};
 }
+__device__ __forceinline__ f2 div2(f2 n, f2 d) { return div2_r(n, d, recip2(d)); }
 
 struct R32 { f2 x, y, z; };
 
@@ -65,8 +74,10 @@ __device__ __forceinline__ void sag_dsag2(const Surf& s, f2 r2, f2& z, f2& g) {
     const f2 a = conic_a2(s, r2);
     const f2 sf = sqrt2(1.f - a);
     const f2 opsf = 1.f + sf;
-    z = div2(r2 * s.c, opsf);
-    g = div2((opsf + div2(a * 0.5f, sf)) * s.c, opsf * opsf);
+    const f2 ro = recip2(opsf);
+    z = div2_r(r2 * s.c, opsf, ro);
+    const f2 o2 = opsf * opsf;
+    g = div2_r((opsf + div2(a * 0.5f, sf)) * s.c, o2, recip_refine2(o2, ro * ro));
     if (s.n_ai > 0) {                                    // uniform
         z = (f2){sag_poly(s, r2.x, z.x), sag_poly(s, r2.y, z.y)};
         g = (f2){dsag_poly(s, r2.x, g.x), dsag_poly(s, r2.y, g.y)};
@@ -107,7 +118,8 @@ __device__ __forceinline__ void normalize32(f2& x, f2& y, f2& z) {
     const f2 n2 = fma2(z, z, fma2(y, y, x * x));
     const f2 sq = sqrt2(n2);
     const f2 den = (f2){fmaxf(sq.x, 1e-12f), fmaxf(sq.y, 1e-12f)};
-    x = div2(x, den); y = div2(y, den); z = div2(z, den);
+    const f2 rd = recip2(den);
+    x = div2_r(x, den, rd); y = div2_r(y, den, rd); z = div2_r(z, den, rd);
 }
 
 __device__ __forceinline__ unsigned fbits(float x) { return __float_as_uint(x); }

@@ -264,7 +264,9 @@ int aadff_strict_psf_points(const float* points, int N, int B, const int* job_ba
 /* Self test (no reference counterpart) of the packed float32 primitives the two-rays-per-lane strict kernels use (csrc/strict_math2.h)
  * against the compiler's IEEE forms, bit for bit: op 0: num[i] / den[i] (reciprocal refinement with packed FMAs + v_div_fixup_f32,
  * no v_div_scale_f32 pre-scaling); op 1: sqrt(num[i]) (v_sqrt_f32 + two-neighbour correction, no pre-scaling of arguments below
- * 2^-96).  n values (device).  mismatches: 17 device words = count, then (index, bits of the packed result) of the first 8. */
+ * 2^-96); op 2: num[i] / (den[i] * den[i]) with the reciprocal of the squared denominator grown from the refined reciprocal of
+ * den[i] (how sag / d sag share 1 / (1 + sf), deeplens/surfaces.py:787-830) against the compiler's division by the rounded square.
+ * n values (device).  mismatches: 17 device words = count, then (index, bits of the packed result) of the first 8. */
 int aadff_selftest_strict_ops(const float* num, const float* den, int n, int op, unsigned* mismatches, aadff_stream_t stream);
 
 /* Chief-ray PSF centres of B batches: centre[b][p] = -(sum_s o_xy[b,s,p] ra[b,s,p]) / (sum_s ra[b,s,p] + 1e-9), o [B,spp,N,3],

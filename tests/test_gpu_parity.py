@@ -1741,6 +1741,16 @@ def test_packed_division_and_sqrt_of_the_strict_kernels_are_ieee():
         m = mm.cpu().numpy().view(np.uint32)
         first = [(int(m[1 + 2 * k]), float(a[int(m[1 + 2 * k])]), float(b[int(m[1 + 2 * k])])) for k in range(min(int(m[0]), 8))]
         assert m[0] == 0, (name, int(m[0]), first)
+    # the shared reciprocal of sag / d sag (op 2): EVERY float 1 + sf in [1, 2] as the denominator whose square is divided by, against
+    # the compiler's n / (d * d), with numerators of the magnitudes (opsf + a / (2 sf)) * c takes, of any magnitude, and the hard ones
+    # next to multiples of d * d
+    d_all = torch.arange(0x3f800000, 0x40000001, dtype=torch.int32).view(torch.float32).to(dev)
+    for name, num in (("curvature-sized", rnd(-12, 3, d_all.numel())), ("wide", rnd(-60, 60, d_all.numel())),
+                      ("near k d^2", (d_all.cpu() * d_all.cpu()) * torch.randint(1, 9, (d_all.numel(),), generator=g).float() * (1 + (torch.randint(-2, 3, (d_all.numel(),), generator=g).float() * 2.0 ** -23)))):
+        mm = torch.zeros(17, dtype=torch.int32, device=dev)
+        _abi.call("aadff_selftest_strict_ops", _abi.ptr(num.float().to(dev).contiguous()), _abi.ptr(d_all), d_all.numel(), 2, _abi.ptr(mm), _abi.stream_ptr(dev))
+        m = mm.cpu().numpy().view(np.uint32)
+        assert m[0] == 0, (name, int(m[0]), [(float(num[int(m[1 + 2 * k])]), float(d_all[int(m[1 + 2 * k])])) for k in range(min(int(m[0]), 8))])
     a, b = rnd(-126, -100, n), rnd(-4, 100, n)                                  # outside the domain: informative
     mm = torch.zeros(17, dtype=torch.int32, device=dev)
     _abi.call("aadff_selftest_strict_ops", _abi.ptr(a.to(dev)), _abi.ptr(b.to(dev)), n, 0, _abi.ptr(mm), _abi.stream_ptr(dev))
