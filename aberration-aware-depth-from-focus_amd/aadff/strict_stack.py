@@ -764,6 +764,7 @@ class StrictPipeline:
         _abi.call("aadff_strict_replay_threads", 256)        # re-launches run beside another stack's psf_map launch
         self.pending = []                                    # oldest first
         self.turn = 0
+        self.closed = False
         self.trace = [] if os.environ.get("AADFF_STRICT_PIPE_TRACE") == "1" else None       # (stack, "in" / "out" of a step, seconds)
 
     def _steps(self, lens, img, depth_plane_mm, focus_mm, grid, ks, spp):
@@ -809,6 +810,7 @@ class StrictPipeline:
             self._advance(ready)
 
     def submit(self, img, depth_plane_mm, focus_mm, grid=11, ks=11, spp=GEO_SPP):
+        assert not self.closed, "StrictPipeline is closed"
         k = self.turn
         self.turn += 1
         self._drive(lambda: all(p.k % self.depth != k % self.depth for p in self.pending))      # the stack that has this lens is done
@@ -823,7 +825,25 @@ class StrictPipeline:
         return p
 
     def close(self):
+        """finish what is pending and hand the re-launch form back to the sequential path (idempotent)"""
+        if self.closed:
+            return
+        self.closed = True
         try:
             self._drive(lambda: not self.pending)
         finally:
             _abi.call("aadff_strict_replay_threads", 1024)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            if not self.closed:
+                self.closed = True
+                _abi.call("aadff_strict_replay_threads", 1024)
+        except Exception:
+            pass
