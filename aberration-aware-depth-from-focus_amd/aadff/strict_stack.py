@@ -744,10 +744,12 @@ class StrictPipeline:
 
     class _Pending:
         def __init__(self, pipe, k, steps):
-            self.pipe, self.k, self.steps, self.value, self.event = pipe, k, steps, None, None
+            self.pipe, self.k, self.steps, self.value, self.event, self.error = pipe, k, steps, None, None, None
 
         def result(self):
             self.pipe._drive(lambda: self.steps is None)
+            if self.error is not None:                       # what this stack raised (the reference's assertions, a NaN in Newton's method, ...)
+                raise self.error
             return self.value
 
     def __init__(self, make_lens, depth=4):
@@ -791,6 +793,9 @@ class StrictPipeline:
                 ev = torch.cuda.Event()
                 ev.record(self.streams[i])
                 p.value, p.steps, p.event = (done.value, ev), None, None
+                self.pending.remove(p)
+            except Exception as e:                           # belongs to THIS stack: raised by its handle, the others go on
+                p.steps, p.event, p.error = None, None, e
                 self.pending.remove(p)
             except BaseException:
                 p.steps, p.event = None, None

@@ -570,3 +570,15 @@ def test_strict_pipeline_equals_the_sequential_loop(repo_root, margin):
         assert torch.rand(1).item() == tail
         worst = max(worst, max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(got, want)))
     margin("strict pipeline (2 and 4 stacks in flight) vs sequential loop, max |d| / max over 6 stacks", worst, 2e-6)
+    # a stack that fails (a focus distance in front of the lens: the reference's "sensor position is negative." / no valid ray) raises
+    # from ITS handle; the stacks around it are rendered, the pipeline stays usable
+    with StrictPipeline(make, depth=2) as pipe:
+        torch.manual_seed(21)
+        a = pipe.submit(img, dbar, fds, grid, 11, spp)
+        bad = pipe.submit(img, dbar, [fds[0], 5.0], grid, 11, spp)
+        c = pipe.submit(img, dbar, fds, grid, 11, spp)
+        assert c.result()[0].shape == want[0].shape and a.result()[0].shape == want[0].shape
+        with pytest.raises((AssertionError, FloatingPointError)):
+            bad.result()
+        d = pipe.submit(img, dbar, fds, grid, 11, spp)
+        assert torch.isfinite(d.result()[0]).all()
