@@ -38,8 +38,40 @@ MAX_ITER = 10
 
 
 def strict_psf_maps_loop(lens, depth_plane_mm, focus, grid, ks, spp):
-    """The reference's loop, call by call (refocus(f_k) then psf_map, every trace a single `aadff_trace_rays_strict` call)."""
-    return torch.stack([(lens.refocus(f), lens.psf_map(depth=depth_plane_mm, grid=grid, ks=ks, spp=spp))[1] for f in focus])
+    """The reference's loop, call by call (refocus(f_k) then psf_map, every trace a single `aadff_trace_rays_strict` call: the
+    round-3 form the batched and fused forms are tested against - the per-call API's own fused halves are switched off here)."""
+    keep = getattr(lens, "_strict_calls_fused", True)
+    lens._strict_calls_fused = False
+    try:
+        return torch.stack([(lens.refocus(f), lens.psf_map(depth=depth_plane_mm, grid=grid, ks=ks, spp=spp))[1] for f in focus])
+    finally:
+        lens._strict_calls_fused = keep
+
+
+def _run_steps(steps):
+    try:
+        while True:
+            next(steps).synchronize()
+    except StopIteration as done:
+        return done.value
+
+
+def calls_fused(lens):
+    return getattr(lens, "_strict_calls_fused", True) and os.environ.get("AADFF_STRICT_CALLS_FUSED", "1") != "0"
+
+
+@torch.no_grad()
+def strict_refocus_call(lens, depth):
+    """`Lensgroup.refocus` of a strict lens (deeplens/optics.py:1155-1180 + post_computation): the refocus and calc_fov levels of
+    `_strict_psf_maps_steps` for one state - two fused launches on speculated counts instead of ~50 per-surface ones."""
+    _run_steps(_strict_psf_maps_steps(lens, float(depth), [float(depth)], 1, 1, GEO_SPP, phase="focus"))
+
+
+@torch.no_grad()
+def strict_psf_map_call(lens, depth, grid, ks, spp):
+    """`Lensgroup.psf_map` of a strict lens at its current state (deeplens/optics.py:888-1026): the psf_map level of
+    `_strict_psf_maps_steps` for one state; [3, grid*ks, grid*ks] on the device."""
+    return _run_steps(_strict_psf_maps_steps(lens, float(depth), [None], grid, ks, spp, phase="psf"))[0]
 
 
 def _pupil_points(theta_u, r_u, radius, z):
@@ -382,10 +414,10 @@ class _Stage:
     level 1, one small parameter block up and one result block down per launch (every `.to(device)` / `.cpu()` of a small tensor is
     30-100 us of its own).  Integer and float words share a block (int32 storage, float32 views)."""
 
-    def __init__(self, dev, S, L, N, spp, t_green):
+    def __init__(self, dev, S, L, N, spp, t_green, phase="all"):
         B, MS, M = S * L, _abi.MAX_SURF, 100
         i32, f32 = torch.int32, torch.float32
-        self.key = (S, L, N, spp, t_green)
+        self.key = (S, L, N, spp, t_green, phase)
         self.J = J = JOBS_PER_BATCH * S
         self.n_pf, self.n_pm, self.n_pc = S * GEO_SPP * 3, B * spp * 3, B * GEO_SPP * 3
         self.h_pupil = torch.empty(self.n_pf + self.n_pm + self.n_pc, dtype=f32, pin_memory=True)
@@ -408,15 +440,20 @@ class _Stage:
         # where the uniforms of every batch of pupil points sit in the stack's flat block of draws (stack_uniform_layout)
         from .focal_stack import stack_uniform_layout
         per, o_main, o_chief, per_l = stack_uniform_layout(spp, L)
+        if phase == "focus":                                 # the draws of a refocus call alone / of a psf_map call alone
+            per = 2 * GEO_SPP
+        elif phase == "psf":
+            per, o_main, o_chief = L * per_l, 0, 2 * spp
         sl = (np.arange(S, dtype=np.int64)[:, None] * per + np.arange(L, dtype=np.int64)[None, :] * per_l).reshape(-1)
         self.off_focus = np.arange(S, dtype=np.int64) * per
         self.off_main, self.off_chief = sl + o_main, sl + o_chief
 
     @staticmethod
-    def of(lens, dev, S, L, N, spp, t_green):
-        st = lens._table_cache.get("strict-stage")
-        if st is None or st.key != (S, L, N, spp, t_green) or st.d_pupil.device != dev:
-            st = lens._table_cache["strict-stage"] = _Stage(dev, S, L, N, spp, t_green)
+    def of(lens, dev, S, L, N, spp, t_green, phase="all"):
+        name = "strict-stage" if phase == "all" else "strict-stage-" + phase
+        st = lens._table_cache.get(name)
+        if st is None or st.key != (S, L, N, spp, t_green, phase) or st.d_pupil.device != dev:
+            st = lens._table_cache[name] = _Stage(dev, S, L, N, spp, t_green, phase)
         return st
 
     def submit(self, i, n_up, n_down, launch, stream):
@@ -501,10 +538,13 @@ def strict_psf_maps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None):
         return done.value
 
 
-def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None):
+def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=None, phase="all"):
     """`strict_psf_maps` as a generator: every host wait of the fused form - the round trips of the two short levels, the psf_map
     launch, its re-launches - is a `yield` of the event to wait for.  `strict_psf_maps` waits right there; `StrictPipeline` goes on
-    with whichever other stack's event has happened.  Returns the maps (StopIteration.value)."""
+    with whichever other stack's event has happened.  Returns the maps (StopIteration.value).
+    `phase`: "all" = a stack (refocus -> calc_fov -> psf_map per slice); "focus" = the refocus / calc_fov half only (the lens state is
+    set, None returned) and "psf" = the psf_map half only at the lens's current state - what `Lensgroup.refocus` and `.psf_map` of a
+    strict lens call (one state each): the same kernels, tables and checks, the draws of each call in the reference's order."""
     from .focal_stack import stack_uniform_layout
     if ks > _abi.MAX_KS:
         raise ValueError(f"ks={ks} exceeds the kernels' limit {_abi.MAX_KS}")
@@ -522,16 +562,25 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
     counts = StrictCounts.of(lens)
     curved = _curved(lens)
     f32 = torch.float32
+    assert phase in ("all", "focus", "psf")
     keys = (("focus", S), ("fov", S), ("psf", B, N, spp))
-    fused = fused and all(k in counts.rows for k in keys)      # no table yet: this call is the seed run (round-4 form throughout)
+    need = keys if phase == "all" else (keys[:2] if phase == "focus" else keys[2:])
+    fused = fused and all(k in counts.rows for k in need)      # no table yet: this call is the seed run (round-4 form throughout)
 
-    # ---- the stack's draws, in the reference's order (one flat draw = the same generator stream as call by call)
+    # ---- the draws, in the reference's order (one flat draw = the same generator stream as call by call)
     per, o_main, o_chief, per_l = stack_uniform_layout(spp, L)
+    if phase == "focus":
+        per = 2 * GEO_SPP
+    elif phase == "psf":
+        per = L * per_l
     u = lens.sampler.rand_block([S * per]).cpu().reshape(S, per)
-    uf = u[:, :2 * GEO_SPP].reshape(S, 2, GEO_SPP)
-    rest = u[:, 2 * GEO_SPP:].reshape(S, L, per_l)
-    um = rest[:, :, :2 * spp].reshape(S, L, 2, spp)
-    uc = rest[:, :, 2 * spp:].reshape(S, L, 2, GEO_SPP)
+    uf = um = uc = None
+    if phase != "psf":
+        uf = u[:, :2 * GEO_SPP].reshape(S, 2, GEO_SPP)
+    if phase != "focus":
+        rest = u[:, (2 * GEO_SPP if phase == "all" else 0):].reshape(S, L, per_l)
+        um = rest[:, :, :2 * spp].reshape(S, L, 2, spp)
+        uc = rest[:, :, 2 * spp:].reshape(S, L, 2, GEO_SPP)
 
     marks = [("start", time.perf_counter())] if os.environ.get("AADFF_STRICT_TIMING") == "1" else None
     mark = (lambda name: marks.append((name, time.perf_counter()))) if marks is not None else (lambda name: None)
@@ -543,28 +592,17 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
         pts = lens.point_source_grid(depth=depth_plane_mm, grid=grid, quater=False).reshape(-1, 3).float()
         fwd_order, bwd_order = list(range(n_surf)), list(range(n_surf - 1, -1, -1))
         st = None
+        bt_green = None
         if fused:
-            st = _Stage.of(lens, dev, S, L, N, spp, t_green)
-            # every pupil point of the stack comes from the reference's host calls; the focus ones ride in front of level 1
+            st = _Stage.of(lens, dev, S, L, N, spp, t_green, phase)
             hp = st.h_pupil
             vec = _sleef()
-            if vec is not None:
-                _pupil_rows(vec, u, st.off_focus, st.off_focus + GEO_SPP, GEO_SPP, s0.r, s0.d.item(), hp[:st.n_pf])
-            else:
-                hp[:st.n_pf].view(S, GEO_SPP, 3).copy_(_pupil_points(uf[:, 0], uf[:, 1], s0.r, s0.d.item()))
             # the two short levels may run on a stream of their own (StrictPipeline: a high-priority one, so that they do not queue
             # behind the psf_map launch of the stack in front); every level ends with a host wait, which orders them with level 3
             s12 = getattr(lens, "_strict_fast_stream", None)
             s12 = stream if s12 is None else s12
             sp12 = C.c_void_p(s12.cuda_stream)
-            with torch.cuda.stream(s12):
-                st.d_pupil[:st.n_pf].copy_(hp[:st.n_pf], non_blocking=True)
-            mark("level 1 rays")
-            # ---- level 1: refocus (deeplens/optics.py:1155-1180) - rays from the first surface's aperture points away from (0, 0, focus)
-            t = st.h_par[0][:S * 3].view(f32).view(S, 3)
-            t.zero_()
-            t[:, 2] = torch.tensor([float(f) for f in focus], dtype=f32)
-
+        if fused and phase != "focus":
             def psf_pupils():
                 # the psf_map pupil points are not needed before level 3: a worker thread evaluates them (torch releases the GIL in
                 # sqrt / cos / sin) while this thread goes through levels 1 and 2, which are launch and round-trip latency.  Slice by
@@ -581,6 +619,23 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                     pc_h[k].copy_(_pupil_points(uc[k, :, 0], uc[k, :, 1], enp_rr * 0.5, enp_z))
 
             pupils_ready = _WORKER.submit(psf_pupils)
+        if phase == "psf":                                   # psf_map at the lens's current state (the reference reads self.d_sensor / self.hfov)
+            hs0 = lens._state_sync()
+            d_sensor, hfov, foclen, fnum = [float(hs0.d_sensor)] * S, [float(hs0.hfov)] * S, [float(hs0.foclen)] * S, [float(hs0.fnum)] * S
+        got = None
+        if fused and phase != "psf":
+            # every pupil point of the stack comes from the reference's host calls; the focus ones ride in front of level 1
+            if vec is not None:
+                _pupil_rows(vec, u, st.off_focus, st.off_focus + GEO_SPP, GEO_SPP, s0.r, s0.d.item(), hp[:st.n_pf])
+            else:
+                hp[:st.n_pf].view(S, GEO_SPP, 3).copy_(_pupil_points(uf[:, 0], uf[:, 1], s0.r, s0.d.item()))
+            with torch.cuda.stream(s12):
+                st.d_pupil[:st.n_pf].copy_(hp[:st.n_pf], non_blocking=True)
+            mark("level 1 rays")
+            # ---- level 1: refocus (deeplens/optics.py:1155-1180) - rays from the first surface's aperture points away from (0, 0, focus)
+            t = st.h_par[0][:S * 3].view(f32).view(S, 3)
+            t.zero_()
+            t[:, 2] = torch.tensor([float(f) for f in focus], dtype=f32)
 
             def launch1(J, par, res):
                 G = st.G[0]
@@ -591,17 +646,18 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
             got = yield from _speculate_small(counts, keys[0], st, 0, S, GEO_SPP, curved, fwd_order, launch1, s12)
             if got is not None:
                 fd_all, alive = got[0], got[1] > 0
-        if not fused or got is None:
+        bt_green = st.bt_green if st is not None else torch.full((B,), t_green, dtype=torch.int32, device=dev)
+        if phase != "psf" and (not fused or got is None):
             if fused:
                 counts.stats["per_surface_replays"] += 1
-            bt_green = st.bt_green if st is not None else torch.full((B,), t_green, dtype=torch.int32, device=dev)
             fd_all, alive, cnt = _level1_batched(lens, uf, focus, S, tabs, len(wv), n_surf, bt_green[:S], dev)
             counts.learn(keys[0], cnt)
         mark("level 1 back on the host")
-        d_sensor = _d_sensor_of(fd_all, alive)
+        if phase != "psf":
+            d_sensor = _d_sensor_of(fd_all, alive)
         mark("d_sensor")
         # ---- level 2: calc_fov (deeplens/optics.py:1187-1217) - S batches of 100 rays from the sensor corner, backward
-        if fused:
+        if fused and phase != "psf":
             o1, o2 = _fov_geometry(lens, d_sensor)
             M = o2.shape[0]
             backward = not bool(o2[0, 2] - o1[0, 2] > 0)
@@ -620,14 +676,23 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                 tan_fov, rra = torch.from_numpy(got[0]), torch.from_numpy(got[1])
         else:
             mark("level 2 rays")
-        if not fused or got is None:
+        if phase != "psf" and (not fused or got is None):
             if fused:
                 counts.stats["per_surface_replays"] += 1
-            tan_fov, rra, cnt = _level2_batched(lens, d_sensor, S, tabs, len(wv), n_surf, bt_green[:S] if not fused else st.bt_green[:S], dev)
+            tan_fov, rra, cnt = _level2_batched(lens, d_sensor, S, tabs, len(wv), n_surf, bt_green[:S], dev)
             counts.learn(keys[1], cnt)
         mark("level 2 back on the host")
-        hfov, foclen, fnum = _fov_of(lens, tan_fov, rra)
+        if phase != "psf":
+            hfov, foclen, fnum = _fov_of(lens, tan_fov, rra)
         mark("hfov")
+        if phase == "focus":                                 # refocus + calc_fov of the per-call API: the state is set, no PSFs
+            lens._state_sync()
+            hs = lens._state_host
+            hs.d_sensor, hs.hfov, hs.tan_hfov = float(d_sensor[-1]), float(hfov[-1]), float(np.tan(hfov[-1]))
+            hs.foclen, hs.fnum = float(foclen[-1]), float(fnum[-1])
+            if lens._state_dev is not None:
+                lens._state_upload()
+            return None
         # ---- level 3: psf_map (deeplens/optics.py:888-1026) - per slice and wavelength spp x N main rays and 2048 x N chief rays
         pobj = _object_points(lens, pts, hfov)                                                     # [S,N,3]
         if fused:
@@ -719,6 +784,8 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
         if marks is not None:
             lens._strict_timing = [("draws and setup", round((marks[0][1] - t_enter) * 1e3, 3))] + [(b[0], round((b[1] - a[1]) * 1e3, 3)) for a, b in zip(marks, marks[1:])]
     assert bool(any_valid.bool().all()), "No sampled rays is valid."
+    if phase == "psf":
+        return maps
     # the lens is left focused at the last distance
     lens._state_sync()
     hs = lens._state_host

@@ -375,6 +375,9 @@ class Lensgroup(DeepObj):
         and refresh hfov/foclen/fnum (reference: optics.py:1155-1180).  One kernel, no
         host sync; host RNG order = surface_sample: theta then r (surfaces.py:192-193)."""
         if self.parity == "strict":
+            from aadff import strict_stack
+            if strict_stack.calls_fused(self):
+                return strict_stack.strict_refocus_call(self, depth)
             return self._refocus_strict(depth)
         st, lc = self._state_device(), self._lens_const()
         with _abi.on_device(st.device):
@@ -725,6 +728,10 @@ class Lensgroup(DeepObj):
                 cache.clear()
             pts = cache[(float(depth), int(grid))] = self.point_source_grid(depth=depth, grid=grid, quater=False).reshape(-1, 3).float().contiguous()
         if self.parity == "strict":
+            from aadff import strict_stack
+            if center and strict_stack.calls_fused(self):
+                out = strict_stack.strict_psf_map_call(self, depth, grid, ks, spp)
+                return out.to(self.device) if self.device.type != "cuda" else out
             return make_grid(self.psf_rgb(pts, ks=ks, spp=spp, center=center), nrow=grid, padding=0)
         return self._psf_launch(pts, WAVE_RGB, ks, spp, center, True)
 

@@ -538,6 +538,42 @@ def test_bf16_train_step_runs_and_tracks_fp32(repo_root, margin):
     margin("bf16 train step: |loss_bf16/loss_fp32 - 1| after 12 steps", abs(losses[True][-1] / losses[False][-1] - 1), 0.05)
 
 
+def test_strict_per_call_api_fused_equals_per_surface(repo_root, margin, monkeypatch):
+    """`refocus` / `psf_map` of a strict lens (the reference's own slice loop, deeplens/optics.py:779-783 per slice) run the refocus +
+    calc_fov levels and the psf_map level of the fused strict stack for ONE state each (round 5; `AADFF_STRICT_CALLS_FUSED=0`: every
+    trace a chain of per-surface launches, round 3): same draws in the same order, d_sensor / hfov / foclen / fnum equal to the last
+    bit after every refocus, PSF maps equal to the histograms' float atomics, the generator left at the same position - over focus
+    distances whose batch-wide Newton counts differ (the count table's candidate rows and re-launches are exercised)."""
+    import time
+    H = W = 256
+    grid, ks, spp = 5, 11, 512
+    depth = synth_depth_mm(H, W, seed=5678)
+    dbar, fds = -float(depth.mean()), [float(f) for f in -np.linspace(depth.min(), depth.max(), 6)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("AADFF_STRICT_CALLS_FUSED", mode)
+        lens = Lensgroup(lp(repo_root), sensor_res=(H, W), device=DEV, parity="strict")
+        torch.manual_seed(33)
+        outs, t0 = [], time.perf_counter()
+        for rep in range(2):                                 # second pass: every (level, shape) has its count table
+            for f in fds:
+                lens.refocus(f)
+                outs.append(torch.tensor([lens.d_sensor, lens.hfov, lens.foclen, lens.fnum], dtype=torch.float64))
+                outs.append(lens.psf_map(depth=dbar, grid=grid, ks=ks, spp=spp).cpu().double())
+        res[mode] = (outs, torch.rand(1).item(), time.perf_counter() - t0)
+    monkeypatch.delenv("AADFF_STRICT_CALLS_FUSED")
+    assert res["0"][1] == res["1"][1]
+    worst = 0.0
+    for a, b in zip(res["1"][0], res["0"][0]):
+        if a.numel() == 4:
+            assert torch.equal(a, b), (a, b)
+        else:
+            assert a.shape == b.shape == (3, grid * ks, grid * ks)
+            worst = max(worst, float((a - b).abs().max() / b.abs().max()))
+    margin("strict per-call API: fused halves vs per-surface calls, PSF maps max |d| / max", worst, 2e-6)
+    print(f"strict per-call loop, 12 slices at 256^2 / grid 5 / spp 512: per-surface {res['0'][2]:.3f} s, fused {res['1'][2]:.3f} s")
+
+
 def test_strict_pipeline_equals_the_sequential_loop(repo_root, margin):
     """aadff.strict_stack.StrictPipeline (round 5): two / four strict stacks in flight (as many lenses / streams, one host thread: at every
     host wait of a stack the host goes on with another one whose awaited launch has finished).  The host draws are taken at submission, so every
