@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AADFF_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libaadff.so")   # AADFF_LIB: A/B builds (tools/)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_GRID, MAX_KS, MAX_SURF, MAX_AI = 64, 51, 32, 8
 SURF_STOP, SURF_SPHERIC, SURF_ASPHERIC = 0, 1, 2
 
@@ -86,6 +86,9 @@ PROTOTYPES = {
     "aadff_psf_points": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _L, _L, _P, _I, _L, _L, _I, _I, _I, _P, _P, _P, _P],
     "aadff_psf_points_staged": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _L, _L, _P, _I, _L, _L, _I, _I, _I, _P, _P, _P,
                                 C.POINTER(Stage), _P],
+    "aadff_psf_points_edge": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _L, _L, _P, _I, _L, _L, _I, _F, _P, _P, _P, _P, _I, _P, _P],
+    "aadff_strict_edge_retrace": [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _I, _P, _F, _I, _P, _P, _P, _I, _P, _P, _P],
+    "aadff_psf_normalise": [_P, _I, _I, _I, _F, _I, _I, _P, _P],
     "aadff_psfnet_forward": [_P, _L, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "aadff_psfnet_render_rgbd": [_P, _P, _P, _P, _F, _F, _L, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "aadff_refocus": [_P, _I, _P, _I, _L, _P, LensConst, _P, _P],

@@ -104,6 +104,15 @@ def gpu_numa_cpus(local_rank, sysfs="/sys"):
     """(pci address, NUMA node, CPUs of that node) of the local_rank-th AMD GPU in PCI-bus order - the order HIP enumerates in -
     read from sysfs WITHOUT touching the GPU; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES index lists are honoured.  None when the
     tree does not say (no amdgpu devices, NUMA node -1, ...)."""
+    # Pin only when the mapping local_rank -> PCI device is unambiguous: CUDA_VISIBLE_DEVICES (HIP honours it too), UUID or other
+    # non-numeric visible-device lists and emulated ranks (every LOCAL_RANK on GPU 0) are not decoded here, and a rank pinned to
+    # the WRONG node is worse off than an unpinned one.
+    if emulated() or os.environ.get("CUDA_VISIBLE_DEVICES", "").strip():
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+        vis = os.environ.get(var, "").strip()
+        if vis and not all(v.strip().isdigit() for v in vis.split(",")):
+            return None
     base = os.path.join(sysfs, "bus", "pci", "drivers", "amdgpu")
     try:
         addrs = sorted(a for a in os.listdir(base) if a.count(":") == 2)
@@ -182,17 +191,18 @@ def init_from_env(backend=None, device=None):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(free_port()))
         # A rendezvous that does not complete (a peer that never started, a wrong MASTER_ADDR, RCCL stuck bringing a link up) must
-        # end the job with a message and a non-zero status, not hang the launcher: the store timeout covers the TCP rendezvous, the
-        # watchdog the communicator bring-up behind it.  The process EXITS (a fresh child is the launcher's business); it never
-        # re-executes itself - it may already have touched the GPU.
-        import datetime
+        # end the job with a message and a non-zero status, not hang the launcher: a watchdog thread bounds the BRING-UP (TCP
+        # rendezvous + first communicator) and nothing else.  No `timeout=` goes to init_process_group: in torch that value is the
+        # default timeout of EVERY later collective on the group (a rank-0-only CPU baseline or checkpoint that keeps the peers in
+        # a barrier for more than AADFF_INIT_TIMEOUT_S would be aborted by the backend's own watchdog); the backend defaults
+        # (10 min RCCL, 30 min gloo) stay.  The process EXITS (a fresh child is the launcher's business); it never re-executes
+        # itself - it may already have touched the GPU.
         import threading
         limit = float(os.environ.get("AADFF_INIT_TIMEOUT_S", "120"))
-        kw["timeout"] = datetime.timedelta(seconds=limit)
         done = threading.Event()
 
         def watchdog():
-            if not done.wait(limit + 5.0):
+            if not done.wait(limit):
                 print(f"aadff: rank {rank} of {world}: process group ({backend}) not up after {limit:.0f} s "
                       f"(MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')}); giving up", file=sys.stderr, flush=True)
                 os._exit(INIT_EXIT_CODE)

@@ -121,12 +121,16 @@ __global__ __launch_bounds__(256) void fused_flat_kernel(float* o_io, float* d_i
             o.x = o.x + d.x * t; o.y = o.y + d.y * t; o.z = o.z + d.z * t;
         }
         f2 v0, v1 = ra;
+        // The two epilogue quotients use the compiler's full IEEE division (with v_div_scale_f32), not div2: their operands are
+        // NOT confined to the range div2 is exact on - dx^2 + dy^2 of a nearly axial ray can be tiny or denormal (its reciprocal
+        // overflows), dx can be below 2^-104.  One division per ray: no cost beside the trace.
         if (out_mode == 1) {                                                     // refocus: where the ray crosses the axis (optics.py:1171-1174)
-            f2 tt = div2(d.x * o.x + d.y * o.y, d.x * d.x + d.y * d.y);
+            const f2 num = d.x * o.x + d.y * o.y, den = d.x * d.x + d.y * d.y;
+            f2 tt = (f2){num.x / den.x, num.y / den.y};
             tt = tt * ra;
             v0 = o.z - d.z * tt;
         } else if (out_mode == 2) {                                              // calc_fov: tan of the ray's angle (optics.py:1205)
-            v0 = div2(d.x, d.z);
+            v0 = (f2){d.x.x / d.z.x, d.x.y / d.z.y};
         }
         if (out_mode != 0) {
             out0[base + i0] = v0.x; out1[base + i0] = v1.x;
@@ -347,6 +351,82 @@ __global__ __launch_bounds__(kPsfThreads) void fused_psf_kernel(PsfArgs a) {
     flush_bits(w[1], gb + 2 * AADFF_MAX_SURF, gb + 3 * AADFF_MAX_SURF);
 }
 
+// ---- edge-exact PSF grid: the deferred border rays of aadff_psf_points_edge in the reference's arithmetic ---------------------------
+// The fast kernel (csrc/trace.hip) leaves every live ray whose hit lies within delta of the histogram's window edge
+// (deeplens/monte_carlo.py:37) undecided and lists it per (focus state, wavelength) batch as (point << 16 | sample).  This kernel
+// re-traces exactly those rays the way fused_psf_kernel's phase 2 traces ALL rays - ray built from the host-exact pupil point and the
+// host-exact object point (sample_from_points + Ray.__init__), every surface in the float32 operation order of csrc/strict_math.h
+// under the batch's Newton counts (the main row of the psf_map count table), propagate_to - and applies forward_integral's window
+// test and bilinear taps to THAT hit, with the fast kernel's chief-ray centre (a centre error shifts the window by ~1e-7 mm:
+// tools/edge_sim.py).  Taps are added to the fast kernel's unnormalised histograms; aadff_psf_normalise divides.
+// Counts are taken from the table without verification (a few dozen rays per batch cannot confirm a batch-wide count): the
+// main-batch rows do not change from draw to draw (tools/strict_count_stability.py: the entries that flip belong to the focus and
+// chief batches), and a wrong count moves a hit by a fraction of an ulp.
+struct EdgeRetraceArgs {
+    const float* points;            // [P][N][3] object points (host arithmetic of optics.py:945-950)
+    const int* point_set;           // [B]
+    const aadff_surface_t* tables;  // [n_tables][n_surf] (device)
+    const int* table_main;          // [B]
+    const float* z_sensor;          // [B]
+    const float* pupil_main;        // [B][spp][3]
+    const int* pred;                // [B][2][AADFF_MAX_SURF]: row [b][1] = main
+    const float* centre;            // [B][N][2] (the fast kernel's)
+    const unsigned* count;          // [B]
+    const unsigned* list;           // [B][cap]
+    float* raw;                     // [B][N][ks*ks]
+    int* flags;                     // bit 4: a batch's list overflowed its capacity (the caller falls back to the strict psf_map)
+    int N, n_surf, spp, ks, cap;
+    float lo, hi, lim, den_row, den_col;
+};
+
+struct NullSink {
+    __device__ __forceinline__ void operator()(int, unsigned) const {}
+};
+
+__global__ __launch_bounds__(256) void edge_retrace_kernel(EdgeRetraceArgs a) {
+    const int b = blockIdx.y;
+    const unsigned have = a.count[b];
+    if (have > (unsigned)a.cap && blockIdx.x == 0 && threadIdx.x == 0 && a.flags) atomicOr(a.flags, 16);
+    const int cnt = (int)(have < (unsigned)a.cap ? have : (unsigned)a.cap);
+    const int i0 = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (i0 >= cnt) return;
+    const int i1 = i0 + 1 < cnt ? i0 + 1 : i0;          // a lone last ray is traced in both halves, splatted once
+    const unsigned e0 = a.list[(size_t)b * a.cap + i0], e1 = a.list[(size_t)b * a.cap + i1];
+    const int pt0 = (int)(e0 >> 16), pt1 = (int)(e1 >> 16), s0 = (int)(e0 & 0xffffu), s1 = (int)(e1 & 0xffffu);
+    const float* prow = a.points + (size_t)a.point_set[b] * a.N * 3;
+    const f3p oa = *reinterpret_cast<const f3p*>(prow + (size_t)pt0 * 3), ob = *reinterpret_cast<const f3p*>(prow + (size_t)pt1 * 3);
+    const f3p pa = *reinterpret_cast<const f3p*>(a.pupil_main + ((size_t)b * a.spp + s0) * 3);
+    const f3p pb = *reinterpret_cast<const f3p*>(a.pupil_main + ((size_t)b * a.spp + s1) * 3);
+    R32 o = {(f2){oa.x, ob.x}, (f2){oa.y, ob.y}, (f2){oa.z, ob.z}};
+    R32 d = {(f2){pa.x, pb.x} - o.x, (f2){pa.y, pb.y} - o.y, (f2){pa.z, pb.z} - o.z};
+    normalize32(d.x, d.y, d.z);
+    f2 ra = f2s(1.f);
+    const csurf_t tab = (csurf_t)(a.tables + (size_t)a.table_main[b] * a.n_surf);
+    trace_ray_fused2(tab, 0, a.n_surf, 1, (cpred_t)(a.pred + ((size_t)b * 2 + 1) * AADFF_MAX_SURF), o, d, ra, NullSink{});
+    const f2 t = div2(a.z_sensor[b] - o.z, d.z);
+    o.x = o.x + d.x * t; o.y = o.y + d.y * t;
+    const int ks = a.ks, kk = ks * ks;
+    const float km1 = (float)(ks - 1);
+    auto splat = [&](float ox, float oy, float w, int pt) {
+        const float cx = a.centre[((size_t)b * a.N + pt) * 2], cy = a.centre[((size_t)b * a.N + pt) * 2 + 1];
+        const float X = -ox - cx, Y = -oy - cy;                                                         // monte_carlo.py:24-38
+        if ((fabsf(X) < a.lim) && (fabsf(Y) < a.lim) && (w > 0.f)) {
+            float* hist = a.raw + ((size_t)b * a.N + pt) * kk;
+            const float rowf = ((Y - a.hi) / a.den_row) * km1, colf = ((X - a.lo) / a.den_col) * km1;   // monte_carlo.py:86-92
+            const float fr = floorf(rowf), fc = floorf(colf);
+            const float wb = rowf - fr, wr = colf - fc;
+            const int r0 = (int)fr, c0 = (int)fc;
+            const int r1 = (int)floorf(rowf + 1.f), c1 = (int)floorf(colf + 1.f);
+            atomicAdd(&hist[r0 * ks + c0], ((1.f - wb) * (1.f - wr)) * w);
+            atomicAdd(&hist[r0 * ks + c1], ((1.f - wb) * wr) * w);
+            atomicAdd(&hist[r1 * ks + c0], (wb * (1.f - wr)) * w);
+            atomicAdd(&hist[(r0 + 1) * ks + (c0 + 1)], (wb * wr) * w);
+        }
+    };
+    splat(o.x.x, o.y.x, ra.x, pt0);
+    if (i1 != i0) splat(o.x.y, o.y.y, ra.y, pt1);
+}
+
 // self test of the packed primitives against the compiler's IEEE forms (tests/test_gpu_parity.py)
 __global__ void selftest_ops_kernel(const float* __restrict__ num, const float* __restrict__ den, int n, int op, unsigned* __restrict__ mism) {
     const int i = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
@@ -444,6 +524,28 @@ extern "C" int aadff_strict_psf_points(const float* points, int N, int B, const 
     a.lo = (float)lo; a.hi = (float)hi; a.lim = (float)(hi - 0.01 * ps); a.den_row = (float)(lo - hi); a.den_col = (float)(hi - lo);
     if ((long)N * B >= 1024 || g_replay_threads.load(std::memory_order_relaxed) == 256) hipLaunchKernelGGL(strict::fused_psf_kernel<256>, dim3(N, B), dim3(256), lds, st, a);
     else hipLaunchKernelGGL(strict::fused_psf_kernel<1024>, dim3(N, B), dim3(1024), lds, st, a);
+    AADFF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int aadff_strict_edge_retrace(const float* points, int N, int B, const int* point_set, const aadff_surface_t* tables_dev, int n_tables, int n_surf,
+                                         const int* table_main, const float* z_sensor, const float* pupil_main, int spp, const int* pred,
+                                         float pixel_size, int ks, const float* centre, const unsigned* edge_count, const unsigned* edge_list,
+                                         int edge_cap, float* raw, int* flags_or_null, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(points && point_set && tables_dev && table_main && z_sensor && pupil_main && pred && centre && edge_count && edge_list && raw,
+                    "strict_edge_retrace: NULL pointer");
+    AADFF_CHECK_ARG(N >= 1 && N <= 65535 && B >= 1 && B <= 65535 && spp >= 1 && spp <= 65536, "strict_edge_retrace: N=%d B=%d spp=%d", N, B, spp);
+    AADFF_CHECK_ARG(n_tables >= 1 && n_surf >= 1 && n_surf <= AADFF_MAX_SURF, "strict_edge_retrace: n_tables=%d n_surf=%d", n_tables, n_surf);
+    AADFF_CHECK_ARG(ks >= 1 && ks <= AADFF_MAX_KS && (ks & 1), "strict_edge_retrace: ks=%d", ks);
+    AADFF_CHECK_ARG(edge_cap >= 1, "strict_edge_retrace: capacity %d", edge_cap);
+    strict::EdgeRetraceArgs a{};
+    a.points = points; a.point_set = point_set; a.tables = tables_dev; a.table_main = table_main; a.z_sensor = z_sensor; a.pupil_main = pupil_main;
+    a.pred = pred; a.centre = centre; a.count = edge_count; a.list = edge_list; a.raw = raw; a.flags = flags_or_null;
+    a.N = N; a.n_surf = n_surf; a.spp = spp; a.ks = ks; a.cap = edge_cap;
+    const double ps = (double)pixel_size;                                        // monte_carlo.py:24: Python floats, rounded once
+    const double lo = (-ks / 2.0 + 0.5) * ps, hi = (ks / 2.0 - 0.5) * ps;
+    a.lo = (float)lo; a.hi = (float)hi; a.lim = (float)(hi - 0.01 * ps); a.den_row = (float)(lo - hi); a.den_col = (float)(hi - lo);
+    hipLaunchKernelGGL(strict::edge_retrace_kernel, dim3((edge_cap + 511) / 512, B), dim3(256), 0, (hipStream_t)stream, a);
     AADFF_CHECK_LAUNCH();
     return 0;
 }

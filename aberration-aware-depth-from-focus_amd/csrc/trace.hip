@@ -791,6 +791,33 @@ __device__ __forceinline__ void splat_hit(float* hist, const SplatGeom& g, float
     atomicAdd(&hist[(r0 + 1) * ks + (c0 + 1)], wb * wr * ra);
 }
 
+// "Edge-exact" PSF grid (Lensgroup(parity="edge"), aadff_psf_points_edge): the only discontinuity of the histogram is the window
+// test of deeplens/monte_carlo.py:37 - a hit within the float32 noise of the window's edge lands inside or outside depending on
+// the LAST BIT of the trace, and one flipped border ray changes a cropped PSF by 1 / (rays inside).  The fast kernel therefore does
+// not decide such rays: a live ray whose hit lies within `delta` of the edge (and not further outside than delta in the other
+// coordinate) is not splatted but appended as (point << 16 | sample) to the list of its (focus state, wavelength) job;
+// aadff_strict_edge_retrace (csrc/strict_fused.hip) re-traces exactly those rays in the reference's own float32 operation
+// order, decides them and adds their taps, and aadff_psf_normalise divides.  Every other ray is the fast kernel's.
+struct EdgeArgs {
+    float delta;              // half-width of the undecided band around the window edge [mm]
+    unsigned* count;          // [S*L] rays appended per job (zeroed by the caller)
+    unsigned* list;           // [S*L][cap]
+    int cap;
+    float* raw;               // [S*L][N][ks*ks] unnormalised histograms (every element written)
+};
+
+// returns true when the hit was left to the re-trace (appended or, beyond cap, counted: the host sees count > cap)
+__device__ __forceinline__ bool edge_defer(const SplatGeom& g, const EdgeArgs& e, float ox, float oy, bool alive, float cx, float cy, int job, int n,
+                                           int sample) {
+    const float ax = fabsf(-ox - cx), ay = fabsf(-oy - cy);
+    const float out = g.lim + e.delta;
+    const bool near = (fabsf(ax - g.lim) < e.delta) || (fabsf(ay - g.lim) < e.delta);
+    if (!(alive && near && ax < out && ay < out)) return false;
+    const unsigned slot = atomicAdd(e.count + job, 1u);
+    if (slot < (unsigned)e.cap) e.list[(size_t)job * e.cap + slot] = ((unsigned)n << 16) | (unsigned)sample;
+    return true;
+}
+
 __global__ __launch_bounds__(256) void psf_splat_kernel(const float* __restrict__ o, const float* __restrict__ ra,
                                                          const float* __restrict__ centre, int spp, int N,
                                                          SplatGeom g, float* psf_raw, float* psf) {
@@ -841,9 +868,35 @@ struct StageArgs {
 #endif
 constexpr int kPsfThreads = AADFF_PSF_THREADS, kPsfWaves = kPsfThreads / 64;
 constexpr int kCompactMax = 2048;         // rays per compaction chunk of the main pass (48 KB of LDS)
-// TIMED: the same code under a second name for the launches that carry aadff_time_next_launch's events (see conv.hip)
-template <bool TIMED>
-__global__ __launch_bounds__(kPsfThreads, 6) void psf_points_kernel(const float* __restrict__ points, int N, int L,
+// sum of the histogram and the normalised write (deeplens/optics.py:978, psf_map tiling :1025): the tail of the fused kernel and the
+// whole of psf_normalise_kernel - one summation order, so a PSF without deferred rays is bit for bit the fused kernel's
+__device__ __forceinline__ void normalise_and_write(const float* hist, float* red, const SplatGeom& g, int map_grid, float* psf, int s, int l, int n, int N,
+                                                    int L) {
+    const int tid = threadIdx.x, kk = g.ks * g.ks;
+    float part = 0.f;
+    for (int e = tid; e < kk; e += kPsfThreads) part += hist[e];
+    part = wave_sum(part);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    float total = 0.f;
+#pragma unroll
+    for (int w = 0; w < kPsfWaves; ++w) total += red[w];
+    const int ks = g.ks;
+    for (int e = tid; e < kk; e += kPsfThreads) {
+        const float v = hist[e] / total;
+        if (map_grid > 0) {
+            const int gi = n / map_grid, gj = n - gi * map_grid, u = e / ks, w = e - u * ks;
+            const int G = map_grid * ks;
+            psf[((size_t)(s * L + l) * G + gi * ks + u) * G + gj * ks + w] = v;
+        } else {
+            psf[(((size_t)s * N + n) * L + l) * kk + e] = v;
+        }
+    }
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void psf_points_body(const float* __restrict__ points, int N, int L,
                                                           const aadff_surface_t* __restrict__ surf_main,
                                                           const aadff_surface_t* __restrict__ surf_chief,
                                                           aadff_lens_const_t lc,
@@ -851,12 +904,13 @@ __global__ __launch_bounds__(kPsfThreads, 6) void psf_points_kernel(const float*
                                                           const float* __restrict__ u_main, int spp, long main_ss,
                                                           long main_sl, const float* __restrict__ u_chief,
                                                           int spp_chief, long chief_ss, long chief_sl, SplatGeom g, int centre_mode, int map_grid, float* psf,
-                                                          float* centre_out, int* flags, StageArgs stage) {
+                                                          float* centre_out, int* flags, StageArgs stage, const EdgeArgs& edge) {
     extern __shared__ float hist[];                      // ks * ks floats (dynamic: ks up to AADFF_MAX_KS = 51)
     __shared__ float red[3 * kPsfWaves];
     __shared__ int stage_late;
 #if !defined(AADFF_PSF_SCALAR) && !defined(AADFF_PSF_NO_COMPACT)
     __shared__ float cbuf[6][kCompactMax];               // survivors of the first surfaces: origin and direction
+    __shared__ unsigned short cidx[EDGE ? kCompactMax : 1];   // EDGE: and which sample each of them is
     __shared__ int c_count;
 #endif
     const int n = blockIdx.x, l = blockIdx.y;
@@ -1002,10 +1056,12 @@ __global__ __launch_bounds__(kPsfThreads, 6) void psf_points_kernel(const float*
             if (r.alive.x) {
                 const int k = base + __popcll(bx & below);
                 cbuf[0][k] = r.ox.x; cbuf[1][k] = r.oy.x; cbuf[2][k] = r.oz.x; cbuf[3][k] = r.dx.x; cbuf[4][k] = r.dy.x; cbuf[5][k] = r.dz.x;
+                if (EDGE) cidx[k] = (unsigned short)(c0 + i);
             }
             if (r.alive.y) {
                 const int k = base + nx + __popcll(by & below);
                 cbuf[0][k] = r.ox.y; cbuf[1][k] = r.oy.y; cbuf[2][k] = r.oz.y; cbuf[3][k] = r.dx.y; cbuf[4][k] = r.dy.y; cbuf[5][k] = r.dz.y;
+                if (EDGE) cidx[k] = (unsigned short)(c0 + j1);
             }
         }
         __syncthreads();
@@ -1020,8 +1076,10 @@ __global__ __launch_bounds__(kPsfThreads, 6) void psf_points_kernel(const float*
             trace_part2(tab, split, lc.n_surf, r, nan_flag);
             const f2 t = (st.d_sensor - r.oz) * vrcp(r.dz);
             r.ox += r.dx * t; r.oy += r.dy * t;
-            splat_hit(hist, g, r.ox.x, r.oy.x, r.alive.x ? 1.f : 0.f, cx, cy);
-            splat_hit(hist, g, r.ox.y, r.oy.y, r.alive.y ? 1.f : 0.f, cx, cy);
+            if (!(EDGE && edge_defer(g, edge, r.ox.x, r.oy.x, r.alive.x != 0, cx, cy, s * L + l, n, cidx[EDGE ? k0 : 0])))
+                splat_hit(hist, g, r.ox.x, r.oy.x, r.alive.x ? 1.f : 0.f, cx, cy);
+            if (!(EDGE && edge_defer(g, edge, r.ox.y, r.oy.y, r.alive.y != 0, cx, cy, s * L + l, n, cidx[EDGE ? k1 : 0])))
+                splat_hit(hist, g, r.ox.y, r.oy.y, r.alive.y ? 1.f : 0.f, cx, cy);
         }
         __syncthreads();                                  // cbuf / c_count are reused by the next chunk
     }
@@ -1033,8 +1091,8 @@ __global__ __launch_bounds__(kPsfThreads, 6) void psf_points_kernel(const float*
         f2 x2, y2;
         disc_sample2((f2){ut[i], ut[j1]}, (f2){ur[i], ur[j1]}, lc.enp_r2, x2, y2);
         const Ray2 r = trace_pair_to_sensor(px, py, depth, x2, y2, lc.enp_z, act, tab, lc.n_surf, st.d_sensor, nan_flag);
-        splat_hit(hist, g, r.ox.x, r.oy.x, r.ra.x, cx, cy);
-        splat_hit(hist, g, r.ox.y, r.oy.y, r.ra.y, cx, cy);
+        if (!(EDGE && edge_defer(g, edge, r.ox.x, r.oy.x, r.ra.x > 0.f, cx, cy, s * L + l, n, i))) splat_hit(hist, g, r.ox.x, r.oy.x, r.ra.x, cx, cy);
+        if (!(EDGE && edge_defer(g, edge, r.ox.y, r.oy.y, r.ra.y > 0.f, cx, cy, s * L + l, n, j1))) splat_hit(hist, g, r.ox.y, r.oy.y, r.ra.y, cx, cy);
     }
 #endif
 #else
@@ -1044,31 +1102,57 @@ __global__ __launch_bounds__(kPsfThreads, 6) void psf_points_kernel(const float*
         Ray r = ray_to(px, py, depth, x2, y2, lc.enp_z);
         trace_range<false>(tab, 0, lc.n_surf, true, r, nan_flag);
         propagate_to(r, st.d_sensor);
-        splat_hit(hist, g, r.ox, r.oy, r.ra, cx, cy);
+        if (!(EDGE && edge_defer(g, edge, r.ox, r.oy, r.ra > 0.f, cx, cy, s * L + l, n, i))) splat_hit(hist, g, r.ox, r.oy, r.ra, cx, cy);
     }
 #endif
     __syncthreads();
-    float part = 0.f;
-    for (int e = tid; e < kk; e += kPsfThreads) part += hist[e];
-    part = wave_sum(part);
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = part;
-    __syncthreads();
-    float total = 0.f;
-#pragma unroll
-    for (int w = 0; w < kPsfWaves; ++w) total += red[w];
-    const int ks = g.ks;
-    for (int e = tid; e < kk; e += kPsfThreads) {
-        const float v = hist[e] / total;
-        if (map_grid > 0) {
-            const int gi = n / map_grid, gj = n - gi * map_grid, u = e / ks, w = e - u * ks;
-            const int G = map_grid * ks;
-            psf[((size_t)(s * L + l) * G + gi * ks + u) * G + gj * ks + w] = v;
-        } else {
-            psf[(((size_t)s * N + n) * L + l) * kk + e] = v;
-        }
+    if (EDGE) {                                          // unnormalised: the re-trace adds the deferred rays, aadff_psf_normalise divides
+        float* raw = edge.raw + ((size_t)(s * L + l) * N + n) * kk;
+        for (int e = tid; e < kk; e += kPsfThreads) raw[e] = hist[e];
+    } else {
+        normalise_and_write(hist, red, g, map_grid, psf, s, l, n, N, L);
     }
     if (nan_flag && flags) atomicOr(flags, 1);
+}
+
+// TIMED: the same code under a second name for the launches that carry aadff_time_next_launch's events (see conv.hip)
+template <bool TIMED>
+__global__ __launch_bounds__(kPsfThreads, 6) void psf_points_kernel(const float* __restrict__ points, int N, int L,
+                                                          const aadff_surface_t* __restrict__ surf_main,
+                                                          const aadff_surface_t* __restrict__ surf_chief,
+                                                          aadff_lens_const_t lc,
+                                                          const aadff_lens_state_t* __restrict__ states,
+                                                          const float* __restrict__ u_main, int spp, long main_ss,
+                                                          long main_sl, const float* __restrict__ u_chief,
+                                                          int spp_chief, long chief_ss, long chief_sl, SplatGeom g, int centre_mode, int map_grid, float* psf,
+                                                          float* centre_out, int* flags, StageArgs stage) {
+    psf_points_body<false>(points, N, L, surf_main, surf_chief, lc, states, u_main, spp, main_ss, main_sl, u_chief, spp_chief, chief_ss, chief_sl, g,
+                           centre_mode, map_grid, psf, centre_out, flags, stage, EdgeArgs{});
+}
+
+// the edge-exact form: band rays deferred to aadff_strict_edge_retrace, histograms left unnormalised in edge.raw
+__global__ __launch_bounds__(kPsfThreads, 6) void psf_points_edge_kernel(const float* __restrict__ points, int N, int L,
+                                                          const aadff_surface_t* __restrict__ surf_main,
+                                                          const aadff_surface_t* __restrict__ surf_chief,
+                                                          aadff_lens_const_t lc,
+                                                          const aadff_lens_state_t* __restrict__ states,
+                                                          const float* __restrict__ u_main, int spp, long main_ss,
+                                                          long main_sl, const float* __restrict__ u_chief,
+                                                          int spp_chief, long chief_ss, long chief_sl, SplatGeom g, int centre_mode,
+                                                          float* centre_out, int* flags, EdgeArgs edge) {
+    psf_points_body<true>(points, N, L, surf_main, surf_chief, lc, states, u_main, spp, main_ss, main_sl, u_chief, spp_chief, chief_ss, chief_sl, g,
+                          centre_mode, 0, nullptr, centre_out, flags, StageArgs{}, edge);
+}
+
+// raw [S*L][N][ks*ks] -> normalised PSFs in either layout of aadff_psf_points (grid: N x L x S)
+__global__ __launch_bounds__(kPsfThreads) void psf_normalise_kernel(const float* __restrict__ raw, int N, int L, SplatGeom g, int map_grid, float* psf) {
+    extern __shared__ float hist[];
+    __shared__ float red[3 * kPsfWaves];
+    const int n = blockIdx.x, l = blockIdx.y, s = blockIdx.z, kk = g.ks * g.ks;
+    const float* src = raw + ((size_t)(s * L + l) * N + n) * kk;
+    for (int e = threadIdx.x; e < kk; e += kPsfThreads) hist[e] = src[e];
+    __syncthreads();
+    normalise_and_write(hist, red, g, map_grid, psf, s, l, n, N, L);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1372,6 +1456,49 @@ int aadff_psf_points_staged(const float* points, int S, int N, int L, const aadf
     return psf_points_launch(points, S, N, L, surf_main, surf_chief, lc, states, u_main, spp, main_stride_s, main_stride_l,
                              u_chief, spp_chief, chief_stride_s, chief_stride_l, ks, centre_mode, map_layout, psf,
                              centre_out_or_null, flags_or_null, stage, stream);
+}
+
+int aadff_psf_points_edge(const float* points, int S, int N, int L, const aadff_surface_t* surf_main,
+                          const aadff_surface_t* surf_chief, aadff_lens_const_t lc, const aadff_lens_state_t* states,
+                          const float* u_main, int spp, long main_stride_s, long main_stride_l, const float* u_chief,
+                          int spp_chief, long chief_stride_s, long chief_stride_l, int ks, float delta_mm, float* raw,
+                          float* centre_out, unsigned* edge_count, unsigned* edge_list, int edge_cap, int* flags_or_null,
+                          aadff_stream_t stream) {
+#if defined(AADFF_PSF_SCALAR) || defined(AADFF_PSF_NO_COMPACT) || defined(AADFF_PSF_SWITCH_LOOP)
+    set_error("psf_points_edge: not part of the measurement builds of the trace kernels");
+    return AADFF_EUNSUPPORTED;
+#else
+    AADFF_CHECK_ARG(points && surf_main && surf_chief && states && u_main && u_chief && raw && centre_out && edge_count && edge_list,
+                    "psf_points_edge: NULL pointer");
+    AADFF_CHECK_ARG(S > 0 && S <= 65535 && N > 0 && N <= 65535 && L > 0 && L <= 65535 && spp > 0 && spp <= 65536 && spp_chief > 0,
+                    "psf_points_edge: bad sizes S=%d N=%d L=%d spp=%d spp_chief=%d (point and sample ids are 16 bits each)", S, N, L, spp, spp_chief);
+    AADFF_CHECK_ARG(ks >= 1 && ks <= AADFF_MAX_KS, "psf_points_edge: ks %d outside [1,%d]", ks, AADFF_MAX_KS);
+    AADFF_CHECK_ARG(lc.n_surf > 0 && lc.n_surf <= AADFF_MAX_SURF, "psf_points_edge: n_surf %d", lc.n_surf);
+    AADFF_CHECK_ARG(delta_mm >= 0.f && edge_cap >= 1, "psf_points_edge: delta %g mm, capacity %d", (double)delta_mm, edge_cap);
+    hipStream_t st = (hipStream_t)stream;
+    AADFF_CHECK_HIP(hipMemsetAsync(edge_count, 0, (size_t)S * L * sizeof(unsigned), st));
+    EdgeArgs e{};
+    e.delta = delta_mm; e.count = edge_count; e.list = edge_list; e.cap = edge_cap; e.raw = raw;
+    hipLaunchKernelGGL(psf_points_edge_kernel, dim3(N, L, S), dim3(kPsfThreads), (size_t)ks * ks * sizeof(float), st, points, N, L, surf_main, surf_chief, lc,
+                       states, u_main, spp, main_stride_s, main_stride_l, u_chief, spp_chief, chief_stride_s, chief_stride_l,
+                       make_splat_geom(lc.pixel_size, ks), 1, centre_out, flags_or_null, e);
+    AADFF_CHECK_LAUNCH();
+    return 0;
+#endif
+}
+
+int aadff_psf_normalise(const float* raw, int S, int N, int L, float pixel_size, int ks, int map_layout, float* psf, aadff_stream_t stream) {
+    AADFF_CHECK_ARG(raw && psf, "psf_normalise: NULL pointer");
+    AADFF_CHECK_ARG(S > 0 && S <= 65535 && N > 0 && L > 0 && L <= 65535 && ks >= 1 && ks <= AADFF_MAX_KS, "psf_normalise: bad sizes S=%d N=%d L=%d ks=%d", S, N, L, ks);
+    int map_grid = 0;
+    if (map_layout) {
+        map_grid = (int)lround(std::sqrt((double)N));
+        AADFF_CHECK_ARG(map_grid * map_grid == N, "psf_normalise: psf_map layout needs N = g*g, got %d", N);
+    }
+    hipLaunchKernelGGL(psf_normalise_kernel, dim3(N, L, S), dim3(kPsfThreads), (size_t)ks * ks * sizeof(float), (hipStream_t)stream, raw, N, L,
+                       make_splat_geom(pixel_size, ks), map_grid, psf);
+    AADFF_CHECK_LAUNCH();
+    return 0;
 }
 
 int aadff_refocus(const float* depth, int S, const float* u, int spp, long u_stride_s,

@@ -119,6 +119,14 @@ class _CallRing:
         self.events[k].record(stream)
         self.used[k] = True
 
+    def drain(self):
+        """wait for every launch that still reads a block of this ring (before the ring is dropped: with the zero-copy path the
+        kernels read the PINNED block itself, which no copy_ - hence no allocator event - protects from being handed out again)"""
+        for k in range(self.SLOTS):
+            if self.used[k]:
+                self.events[k].synchronize()
+                self.used[k] = False
+
 
 def raise_psf_flags(bits):
     """Flags word of aadff_psf_points -> the reference's errors (bit 0: NaN in a Newton residual, surfaces.py:555-558;
@@ -133,6 +141,36 @@ def raise_psf_flags(bits):
         import warnings
         warnings.warn("aadff: a staged upload of pupil samples arrived late; those PSF workgroups read their samples from "
                       "pinned host memory (correct, slower)", RuntimeWarning, stacklevel=2)
+
+
+_LIVE_LENSES = None
+
+
+def _track_lens(lens):
+    """Deferred errors must not vanish with the process: the per-call API is asynchronous (`Lensgroup.check_flags`), so a script
+    whose LAST call is a psf / psf_map and which never reads the lens state would otherwise end with NaN PSFs and no message.
+    At interpreter exit every live lens with kernels on record is checked once; what the reference would have raised inside the
+    call is written to stderr (an exception cannot stop a script that has already ended)."""
+    global _LIVE_LENSES
+    if _LIVE_LENSES is None:
+        import atexit
+        import weakref
+        _LIVE_LENSES = weakref.WeakSet()
+
+        def _report():
+            import sys
+            for l in list(_LIVE_LENSES):
+                try:
+                    if l._state_dev is not None and l._psf_calls:
+                        l.check_flags()
+                except (AssertionError, FloatingPointError) as e:
+                    print(f"aadff: an earlier asynchronous call on lens {getattr(l, 'lens_name', '?')!r} failed and was never checked: {e}",
+                          file=sys.stderr, flush=True)
+                except Exception:
+                    pass                                     # the GPU runtime may already be shutting down
+
+        atexit.register(_report)
+    _LIVE_LENSES.add(lens)
 
 
 class Lensgroup(DeepObj):
@@ -159,6 +197,7 @@ class Lensgroup(DeepObj):
         self.sync_flags = os.environ.get("AADFF_SYNC_FLAGS", "0") == "1"      # True: every psf call waits for its flags (the round-4 behaviour)
         self.surfaces, self.materials = [], []
         self.sensor_res = sensor_res
+        _track_lens(self)
         if filename is not None:
             self.lens_name = filename
             self.load_file(filename, use_roc, sensor_res, post_computation)
@@ -405,6 +444,8 @@ class Lensgroup(DeepObj):
 
     def _call_ring(self, dev, words):
         if self._ring is None or self._ring.words < words or self._ring.dev.device != dev:
+            if self._ring is not None:
+                self._ring.drain()                           # queued launches may still read the old ring's pinned blocks
             self._ring = _CallRing(dev, max(words, 3 * (2 * GEO_SPP + 2 * GEO_SPP) + 3 * 128 * 3))
         return self._ring
 

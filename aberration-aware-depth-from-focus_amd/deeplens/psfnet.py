@@ -381,12 +381,13 @@ class PSFNet(Lensgroup):
         rand x, rand y, randn z, psf draws).  Returns device tensors (inp [bs,4], psf [bs,ks*ks]).
         With wavelength DEFAULT_WAVE and host sampling this runs through the pipelined producer
         (aadff/training.py: two launches, no copies); the reference's asserts are raised here, synchronously
-        (set `self.check_flags = False` to defer them to the producer's periodic poll)."""
+        (set `self.defer_flag_check = True` to defer them to the producer's periodic poll; `check_flags()` is the lens's
+        synchronous check, a METHOD - optics.py - and must not be shadowed by an attribute)."""
         plan = self._training_plan(bs, spp)
         if plan is None:
             return self._get_training_data_unpipelined(bs, spp)
         inp, psf = plan.next(prefetch=False)
-        if getattr(self, "check_flags", True):
+        if not getattr(self, "defer_flag_check", False):
             plan.check_flags()
         return inp.clone(), psf.clone()
 

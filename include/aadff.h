@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AADFF_ABI_VERSION 7
+#define AADFF_ABI_VERSION 8
 
 #define AADFF_EINVAL      (-1)   /* bad shape / size / NULL pointer                  */
 #define AADFF_EUNSUPPORTED (-2)  /* parameter outside what the kernels were built for */
@@ -343,6 +343,37 @@ int aadff_psf_points_staged(const float* points, int S, int N, int L,
                      const float* u_chief, int spp_chief, long chief_stride_s, long chief_stride_l,
                      int ks, int centre_mode, int map_layout, float* psf, float* centre_out_or_null,
                      int* flags_or_null, const aadff_stage_t* stage, aadff_stream_t stream);
+
+/* "Edge-exact" PSF grid (ABI v8; Lensgroup(parity="edge")): aadff_psf_points with the one decision the float32 noise of a trace
+ * can flip taken out of the fast kernel.  The histogram's only discontinuity is the window test of deeplens/monte_carlo.py:37
+ * (`|s| < R - 0.01 ps`): a hit within the noise of that edge lands inside or outside depending on the last bit of the trace
+ * (deeplens/surfaces.py:523-586: the batch-wide Newton loop), and a flipped border ray changes a cropped PSF by 1 / (rays inside).
+ * Three calls on one stream replace Lensgroup.psf_map, deeplens/optics.py:888-1026, for S focus states whose d_sensor / hfov the
+ * caller computed in the reference's arithmetic (aadff_trace_rays_strict_fused levels, aadff/strict_stack.py):
+ *   1. aadff_psf_points_edge: arguments as aadff_psf_points (chief-ray centres, centre_mode 1).  A live ray whose hit lies within
+ *      delta_mm of the window edge is NOT splatted but appended as (point << 16 | sample) to edge_list[s*L + l][edge_cap], its job's
+ *      edge_count[s*L + l] incremented (zeroed by the call; a count above edge_cap means rays were dropped).  raw [S*L][N][ks*ks]
+ *      receives the UNNORMALISED histograms of all other rays, centre_out [S,L,N,2] the centres.
+ *   2. aadff_strict_edge_retrace (csrc/strict_fused.hip): re-traces the listed rays of the B = S*L batches in the reference's float32
+ *      operation order - arguments as aadff_strict_psf_points (object points and pupil points from the reference's host arithmetic,
+ *      pred[b][1] = the main batch's Newton counts) - applies forward_integral's window test and bilinear taps to that hit with
+ *      `centre` = step 1's centres, and adds the taps to raw.  flags bit 4: a list overflowed.
+ *   3. aadff_psf_normalise: raw -> psf in either layout of aadff_psf_points (the division of optics.py:978; same summation order as
+ *      aadff_psf_points: a PSF none of whose rays was deferred is bit for bit what aadff_psf_points writes for the same states). */
+int aadff_psf_points_edge(const float* points, int S, int N, int L,
+                          const aadff_surface_t* surf_main, const aadff_surface_t* surf_chief,
+                          aadff_lens_const_t lc, const aadff_lens_state_t* states,
+                          const float* u_main, int spp, long main_stride_s, long main_stride_l,
+                          const float* u_chief, int spp_chief, long chief_stride_s, long chief_stride_l,
+                          int ks, float delta_mm, float* raw, float* centre_out,
+                          unsigned* edge_count, unsigned* edge_list, int edge_cap,
+                          int* flags_or_null, aadff_stream_t stream);
+int aadff_strict_edge_retrace(const float* points, int N, int B, const int* point_set, const aadff_surface_t* tables_dev, int n_tables,
+                              int n_surf, const int* table_main, const float* z_sensor, const float* pupil_main, int spp,
+                              const int* pred, float pixel_size, int ks, const float* centre, const unsigned* edge_count,
+                              const unsigned* edge_list, int edge_cap, float* raw, int* flags_or_null, aadff_stream_t stream);
+int aadff_psf_normalise(const float* raw, int S, int N, int L, float pixel_size, int ks, int map_layout, float* psf,
+                        aadff_stream_t stream);
 
 /* Fused PSF-surrogate network: P rows of (x, y, z, foc_z) -> MLP (Linear+ReLU ..., Linear+Sigmoid) -> L1-normalise
  * -> mode 0: psf_out[P][n_out] (PSFNet.pred, deeplens/psfnet.py:375-390, psfnet_arch.py:24-47), or

@@ -97,6 +97,31 @@ def test_config3_sharding_world_8_160_units(tmp_path):
     assert os.path.exists(os.path.join(tmp_path, "ok8"))
 
 
+def _worker_slow_peer(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AADFF_INIT_TIMEOUT_S="2")
+    import time
+    torch.set_num_threads(1)
+    init_from_env(backend="gloo")
+    if rank == 1:
+        time.sleep(5.0)                    # e.g. a rank-0-only CPU baseline: the peers sit in the collective meanwhile
+    t = torch.full((4,), float(rank + 1))
+    dist.all_reduce(t)
+    assert torch.equal(t, torch.full((4,), 3.0))
+    dist.barrier()
+    if rank == 0:
+        open(os.path.join(out_dir, "ok_slow"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_init_timeout_bounds_only_the_bring_up(tmp_path):
+    """AADFF_INIT_TIMEOUT_S limits the rendezvous / bring-up, NOT the collectives behind it (a `timeout=` handed to
+    init_process_group is the default timeout of every collective of the group): a rank that waits in an all_reduce for longer
+    than the limit still completes."""
+    mp.spawn(_worker_slow_peer, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(tmp_path, "ok_slow"))
+
+
 def test_single_process_path_needs_no_group():
     render, n, shape = _unit_renderer()
     full, mine = render_sharded(n, render, shape, gather=True)
