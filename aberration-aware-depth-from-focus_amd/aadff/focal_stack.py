@@ -247,7 +247,7 @@ def render_focal_stack_m1(lens, img, depth_plane_mm, focus_mm, grid=11, ks=11, s
     S = len(focus)
     B, C_, H, W = img.shape
     assert tuple(lens.sensor_res) == (H, W), "lens.sensor_res must match the image"
-    if getattr(lens, "parity", "fast") == "strict":
+    if getattr(lens, "parity", "fast") != "fast":
         # verification mode: the reference's own loop (refocus -> psf_map per slice, 2_aber_aware_dff_aif.py:104-114) with the
         # strict trace behind every call; only the convolution is shared with the fast path (deterministic to 2e-6 abs)
         dev = lens._gpu()

@@ -408,6 +408,19 @@ _WORKER = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefi
 JOBS_PER_BATCH = 4          # candidate count rows per batch of a cheap level (levels 1, 2)
 FUSED_ROUNDS = 4            # corrected re-launches before a batch goes back to the per-surface form
 
+# parity="edge" (round 6): levels 1 and 2 as above - d_sensor and hfov must be the reference's to the last bit, an ulp in either
+# re-draws the rounding noise of every ray behind it (tools/edge_sim.py: a re-trace from an hfov one ulp off is worth nothing) -
+# and level 3 on the FAST kernel, which leaves the one discontinuous decision of the histogram (the window test of
+# deeplens/monte_carlo.py:37) open for the rays within EDGE_DELTA_MM of the window edge; those few rays (0.1-0.5 % of the rays
+# inside the window, a few hundred per slice) are re-traced in the strict arithmetic from the reference's host-exact pupil and
+# object points and decided there (aadff_psf_points_edge -> aadff_strict_edge_retrace -> aadff_psf_normalise).
+EDGE_DELTA_MM = float(os.environ.get("AADFF_EDGE_DELTA_MM", "2e-4"))    # 5 x the largest fast-vs-reference hit distance measured (4.1e-5 mm, G2)
+EDGE_CAP = int(os.environ.get("AADFF_EDGE_CAP", "8192"))               # deferred rays per (slice, wavelength) batch; more: strict psf_map for that stack
+
+
+def is_edge(lens):
+    return getattr(lens, "parity", "fast") == "edge"
+
 
 class _Stage:
     """Pinned host blocks and their device twins for one stack shape (S, L, N, spp): ONE upload of all pupil points in front of
@@ -447,6 +460,25 @@ class _Stage:
         sl = (np.arange(S, dtype=np.int64)[:, None] * per + np.arange(L, dtype=np.int64)[None, :] * per_l).reshape(-1)
         self.off_focus = np.arange(S, dtype=np.int64) * per
         self.off_main, self.off_chief = sl + o_main, sl + o_chief
+
+    def edge_buffers(self, dev, S, L, N, per, ks):
+        """buffers of the edge-exact level 3 (allocated at the first use, re-allocated when ks changes): the stack's uniforms (the fast
+        kernel samples the pupil itself), the S lens states and normalised field points, the deferred-ray lists and raw histograms"""
+        e = getattr(self, "edge", None)
+        if e is None or e["ks"] != ks:
+            B, i32, f32 = S * L, torch.int32, torch.float32
+            nst = S * (C.sizeof(_abi.LensState) // 4)
+            e = self.edge = {
+                "ks": ks, "nst": nst,
+                "h_u": torch.empty(S * per, dtype=f32, pin_memory=True), "d_u": torch.empty(S * per, dtype=f32, device=dev),
+                "h_in": torch.empty(nst + S * N * 3, dtype=i32, pin_memory=True), "d_in": torch.empty(nst + S * N * 3, dtype=i32, device=dev),
+                "count": torch.zeros(B + 1, dtype=i32, device=dev),                 # [B] counts | flags word
+                "list": torch.empty(B * EDGE_CAP, dtype=i32, device=dev),
+                "raw": torch.empty(B * N * ks * ks, dtype=f32, device=dev),
+                "h_back": torch.zeros(B + 1, dtype=i32, pin_memory=True),
+                "uploaded": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False,
+            }
+        return e
 
     @staticmethod
     def of(lens, dev, S, L, N, spp, t_green, phase="all"):
@@ -573,7 +605,17 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
         per = 2 * GEO_SPP
     elif phase == "psf":
         per = L * per_l
-    u = lens.sampler.rand_block([S * per]).cpu().reshape(S, per)
+    edge = is_edge(lens) and fused and phase != "focus"
+    eb = None
+    if edge:
+        # the fast kernel of level 3 samples the pupil itself from the raw uniforms: they are drawn straight into the pinned block
+        # its upload starts from (the previous stack's upload out of that block has long completed - its event is checked all the same)
+        eb = _Stage.of(lens, dev, S, L, N, spp, t_green, phase).edge_buffers(dev, S, L, N, per, ks)
+        if eb["busy"]:
+            eb["uploaded"].synchronize()
+        u = lens.sampler.rand_into(eb["h_u"]).view(S, per)
+    else:
+        u = lens.sampler.rand_block([S * per]).cpu().reshape(S, per)
     uf = um = uc = None
     if phase != "psf":
         uf = u[:, :2 * GEO_SPP].reshape(S, 2, GEO_SPP)
@@ -608,15 +650,18 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                 # sqrt / cos / sin) while this thread goes through levels 1 and 2, which are launch and round-trip latency.  Slice by
                 # slice: below ATen's grain size (32768 elements) an element-wise op stays on the calling thread - a second OpenMP
                 # team next to the main thread's oversubscribes a CPU quota (spinning workers: 60-80 ms stalls were measured)
+                # (edge: the chief rays stay with the fast kernel, only the main points are needed in the reference's arithmetic)
                 if vec is not None:                      # two calls into the library, no interpreter lock held
                     _pupil_rows(vec, u, st.off_main, st.off_main + spp, spp, enp_rr, enp_z, hp[st.n_pf:st.n_pf + st.n_pm])
-                    _pupil_rows(vec, u, st.off_chief, st.off_chief + GEO_SPP, GEO_SPP, enp_rr * 0.5, enp_z, hp[st.n_pf + st.n_pm:])
+                    if not edge:
+                        _pupil_rows(vec, u, st.off_chief, st.off_chief + GEO_SPP, GEO_SPP, enp_rr * 0.5, enp_z, hp[st.n_pf + st.n_pm:])
                     return
                 pm_h = hp[st.n_pf:st.n_pf + st.n_pm].view(S, L, spp, 3)
                 pc_h = hp[st.n_pf + st.n_pm:].view(S, L, GEO_SPP, 3)
                 for k in range(S):
                     pm_h[k].copy_(_pupil_points(um[k, :, 0], um[k, :, 1], enp_rr, enp_z))
-                    pc_h[k].copy_(_pupil_points(uc[k, :, 0], uc[k, :, 1], enp_rr * 0.5, enp_z))
+                    if not edge:
+                        pc_h[k].copy_(_pupil_points(uc[k, :, 0], uc[k, :, 1], enp_rr * 0.5, enp_z))
 
             pupils_ready = _WORKER.submit(psf_pupils)
         if phase == "psf":                                   # psf_map at the lens's current state (the reference reads self.d_sensor / self.hfov)
@@ -695,7 +740,69 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
             return None
         # ---- level 3: psf_map (deeplens/optics.py:888-1026) - per slice and wavelength spp x N main rays and 2048 x N chief rays
         pobj = _object_points(lens, pts, hfov)                                                     # [S,N,3]
-        if fused:
+        edge_done = False
+        if edge:
+            # ---- level 3, edge-exact: fast kernel + strict re-trace of the rays at the window edge + normalisation, no host wait in between
+            pred3 = counts.rows[keys[2]]
+            kk = ks * ks
+            maps = torch.empty((S, L, grid * ks, grid * ks), dtype=f32, device=dev)
+            centre = torch.empty((B, N, 2), dtype=f32, device=dev)
+            h = st.h_par[2]
+            h[:B].view(f32).copy_(torch.tensor(d_sensor, dtype=f32).repeat_interleave(L))
+            h[B:B + S * N * 3].view(f32).view(S, N, 3).copy_(pobj)
+            h[B + S * N * 3:].view(B, 2, MS).copy_(torch.from_numpy(pred3))
+            hin, nst = eb["h_in"], eb["nst"]
+            states = (_abi.LensState * S).from_buffer(hin.numpy())
+            for k in range(S):
+                states[k].d_sensor, states[k].hfov, states[k].tan_hfov = d_sensor[k], hfov[k], float(np.tan(hfov[k]))
+                states[k].foclen, states[k].fnum, states[k].n_focus_rays, states[k].flags, states[k].pad = foclen[k], fnum[k], GEO_SPP, 0, 0
+            hin[nst:].view(f32).view(S, N, 3).copy_(pts.unsqueeze(0).expand(S, N, 3))
+            pupils_ready.result()
+            par, din, du, cnt = st.d_par[2], eb["d_in"], eb["d_u"], eb["count"]
+            par.copy_(h, non_blocking=True)
+            din.copy_(hin, non_blocking=True)
+            du.copy_(eb["h_u"], non_blocking=True)
+            st.d_pupil[st.n_pf:st.n_pf + st.n_pm].copy_(hp[st.n_pf:st.n_pf + st.n_pm], non_blocking=True)
+            eb["uploaded"].record(stream)
+            eb["busy"] = True
+            cnt[B:].zero_()
+            mark("level 3 inputs")
+            o_main_w = 0 if phase == "psf" else 2 * GEO_SPP
+            surf_bytes = C.sizeof(_abi.Surface)
+            lc = lens._lens_const()
+            _abi.call("aadff_psf_points_edge", _ptr_at(din, nst), S, N, L, _abi.ptr(tab_dev), C.c_void_p(tab_dev.data_ptr() + t_green * n_surf * surf_bytes), lc,
+                      _ptr_at(din, 0), _ptr_at(du, o_main_w), spp, per, per_l, _ptr_at(du, o_main_w + 2 * spp), GEO_SPP, per, per_l, ks, EDGE_DELTA_MM,
+                      _abi.ptr(eb["raw"]), _abi.ptr(centre), _ptr_at(cnt, 0), _abi.ptr(eb["list"]), EDGE_CAP, _ptr_at(cnt, B), sp)
+            _abi.call("aadff_strict_edge_retrace", _ptr_at(par, B), N, B, _abi.ptr(st.pset), _abi.ptr(tab_dev), len(wv), n_surf, _abi.ptr(st.bt_main),
+                      _ptr_at(par, 0), _ptr_at(st.d_pupil, st.n_pf), spp, _ptr_at(par, B + S * N * 3), float(lens.pixel_size), ks, _abi.ptr(centre),
+                      _ptr_at(cnt, 0), _abi.ptr(eb["list"]), EDGE_CAP, _abi.ptr(eb["raw"]), _ptr_at(cnt, B), sp)
+            _abi.call("aadff_psf_normalise", _abi.ptr(eb["raw"]), S, N, L, float(lens.pixel_size), ks, 1, _abi.ptr(maps), sp)
+            eb["h_back"].copy_(cnt, non_blocking=True)
+            eb["done"].record(stream)
+            yield eb["done"]
+            back = eb["h_back"].numpy()
+            bits = int(back[B])
+            counts.stats["edge"] = counts.stats.get("edge", 0) + 1
+            counts.stats["edge_rays"] = counts.stats.get("edge_rays", 0) + int(back[:B].sum())
+            lens._edge_last = {"rays": back[:B].copy(), "flags": bits}
+            mark("level 3 (edge) waited for")
+            if bits & 1:
+                raise FloatingPointError("found nan in ft in non-diff newton method.")
+            assert not bits & 2, "No sampled rays is valid."
+            if bits & 16:                                       # a list overflowed (a caustic along the window edge): the strict psf_map decides every ray
+                counts.stats["edge_overflows"] = counts.stats.get("edge_overflows", 0) + 1
+                if vec is not None:
+                    _pupil_rows(vec, u, st.off_chief, st.off_chief + GEO_SPP, GEO_SPP, enp_rr * 0.5, enp_z, hp[st.n_pf + st.n_pm:])
+                else:
+                    hp[st.n_pf + st.n_pm:].view(S, L, GEO_SPP, 3).copy_(_pupil_points(uc[:, :, 0], uc[:, :, 1], enp_rr * 0.5, enp_z))
+                pupils_ready = concurrent.futures.Future()
+                pupils_ready.set_result(None)
+            else:
+                edge_done = True
+                any_valid = torch.ones(B, dtype=torch.int32)
+        if edge_done:
+            pass
+        elif fused:
             pred3 = counts.rows[keys[2]]
             maps = torch.empty((S, L, grid * ks, grid * ks), dtype=f32, device=dev)
             centre = torch.empty((B, N, 2), dtype=f32, device=dev)
@@ -822,7 +929,7 @@ class StrictPipeline:
     def __init__(self, make_lens, depth=4):
         self.depth = int(depth)
         self.lenses = [make_lens() for _ in range(self.depth)]
-        assert all(getattr(l, "parity", "") == "strict" for l in self.lenses), "StrictPipeline renders strict-parity lenses"
+        assert all(getattr(l, "parity", "") in ("strict", "edge") for l in self.lenses), "StrictPipeline renders strict- / edge-parity lenses"
         dev = self.lenses[0]._gpu()
         self.streams = [torch.cuda.Stream(dev) for _ in range(self.depth)]
         self.chain = [None]                                  # the event behind the newest psf_map launch, shared by the lenses

@@ -179,10 +179,14 @@ class Lensgroup(DeepObj):
     and everything the reference computes on the host with torch / numpy - pupil sampling (sin, cos, sqrt), ray
     normalisation, the focus-distance mean, the field-of-view sum and arctangent, the chief-ray centroid - is computed on the
     host with the same torch / numpy calls.  What that buys, what it cannot, and why it is not the default: DESIGN.md section 2.
-    0.24 s per 10-slice 1024^2 stack against 0.34 ms for the fused kernels: a verification mode."""
+    0.24 s per 10-slice 1024^2 stack against 0.34 ms for the fused kernels: a verification mode (round 5: 5 ms, aadff/strict_stack.py).
+    `parity="edge"` (round 6): the strict lens with ONE difference - `psf_map` / a focal stack trace their 7.4 M PSF rays with the
+    fast kernel and re-trace in the strict arithmetic only the few hundred rays per slice that land within 2e-4 mm of the
+    histogram's window edge (deeplens/monte_carlo.py:37), the one place where the last bit of a hit decides anything; refocus and
+    calc_fov (d_sensor, hfov) are the strict ones, every other call (psf, trace, pupils) behaves as with "strict"."""
 
     def __init__(self, filename=None, sensor_res=(1024, 1024), use_roc=False, post_computation=True, device=DEVICE, parity="fast"):
-        assert parity in ("fast", "strict"), "parity is 'fast' or 'strict'"
+        assert parity in ("fast", "strict", "edge"), "parity is 'fast', 'strict' or 'edge'"
         self.parity = parity
         self.device = torch.device(device) if not isinstance(device, torch.device) else device
         self.sampler = HostSampler()
@@ -389,7 +393,7 @@ class Lensgroup(DeepObj):
     # ------------------------------------------------------------------ derived quantities
     def post_computation(self):
         """hfov, foclen, fnum for the current d_sensor (reference: optics.py:178-187)."""
-        if self.parity == "strict":
+        if self.parity != "fast":
             return self._post_computation_strict()
         self.find_aperture()
         st, lc = self._state_device(), self._lens_const()
@@ -413,7 +417,7 @@ class Lensgroup(DeepObj):
         """Move the sensor to the green-light focus of an on-axis point at `depth` (mm < 0)
         and refresh hfov/foclen/fnum (reference: optics.py:1155-1180).  One kernel, no
         host sync; host RNG order = surface_sample: theta then r (surfaces.py:192-193)."""
-        if self.parity == "strict":
+        if self.parity != "fast":
             from aadff import strict_stack
             if strict_stack.calls_fused(self):
                 return strict_stack.strict_refocus_call(self, depth)
@@ -512,7 +516,7 @@ class Lensgroup(DeepObj):
             dz = -torch.cos(phi) if entrance else torch.cos(phi)
             d = torch.stack((torch.sin(phi), torch.zeros_like(phi), dz), axis=-1)
             rng = range(0, self.aper_idx) if entrance else range(self.aper_idx + 1, len(self.surfaces))
-            ray, _, _ = self.trace(Ray(o, d, device="cpu" if self.parity == "strict" else self._gpu()), lens_range=rng)
+            ray, _, _ = self.trace(Ray(o, d, device="cpu" if self.parity != "fast" else self._gpu()), lens_range=rng)
             ro, rd, ra = ray.o.cpu().numpy(), ray.d.cpu().numpy(), ray.ra.cpu().numpy()
             ii, jj = np.triu_indices(M, 1)
             keep = (ra[ii] != 0) & (ra[jj] != 0)
@@ -547,7 +551,7 @@ class Lensgroup(DeepObj):
         theta = self.sampler.rand(spp) * 2 * np.pi
         r = torch.sqrt(self.sampler.rand(spp) * pupilr ** 2)
         o2 = torch.stack((r * torch.cos(theta), r * torch.sin(theta), torch.full_like(r, pupilz)), 1)
-        return Ray(o, o2.unsqueeze(1) - o.cpu(), wvln=wvln, device="cpu" if self.parity == "strict" else self.device)
+        return Ray(o, o2.unsqueeze(1) - o.cpu(), wvln=wvln, device="cpu" if self.parity != "fast" else self.device)
 
     def _trace_strict(self, ray, first, last, forward, z_sensor=None):
         """`ray` (any device, any leading shape) through surfaces [first, last) in the reference's operation order; the
@@ -581,7 +585,7 @@ class Lensgroup(DeepObj):
         is_forward = bool(ray.d.reshape(-1, 3)[0, 2] > 0)
         rng = range(0, len(self.surfaces)) if lens_range is None else lens_range
         first, last = (rng.start, rng.stop) if len(rng) else (0, 0)
-        if self.parity == "strict":
+        if self.parity != "fast":
             out = self._trace_strict(ray, first, last, is_forward)
             return out, (out.ra == 1), None
         out = trace_ray_object(ray, self.surfaces, first, last, is_forward, None, table=self._table([ray.wvln]))
@@ -592,7 +596,7 @@ class Lensgroup(DeepObj):
         if record:
             raise NotImplementedError("record=True is a plotting aid outside the hot path")
         is_forward = bool(ray.d.reshape(-1, 3)[0, 2] > 0)
-        if self.parity == "strict":
+        if self.parity != "fast":
             return self._trace_strict(ray, 0, len(self.surfaces), is_forward, z_sensor=self.d_sensor)
         return trace_ray_object(ray, self.surfaces, 0, len(self.surfaces), is_forward, self._state_device(),
                                 table=self._table([ray.wvln]))
@@ -738,7 +742,7 @@ class Lensgroup(DeepObj):
         single = len(points.shape) == 1
         if single:
             points = points.unsqueeze(0)
-        if self.parity == "strict":
+        if self.parity != "fast":
             out = self._psf_strict(points.float(), wvln, ks, spp, center)
             return out.squeeze(0) if single else out
         out = self._psf_launch(points.float(), [wvln], ks, spp, center, False)[:, 0]
@@ -751,7 +755,7 @@ class Lensgroup(DeepObj):
         single = len(points.shape) == 1
         if single:
             points = points.unsqueeze(0)
-        if self.parity == "strict":
+        if self.parity != "fast":
             out = torch.stack([self._psf_strict(points.float(), w, ks, spp, center) for w in WAVE_RGB], dim=-3)
             return out.squeeze(0) if single else out
         out = self._psf_launch(points.float(), WAVE_RGB, ks, spp, center, False)
@@ -768,7 +772,7 @@ class Lensgroup(DeepObj):
             if len(cache) >= 64:
                 cache.clear()
             pts = cache[(float(depth), int(grid))] = self.point_source_grid(depth=depth, grid=grid, quater=False).reshape(-1, 3).float().contiguous()
-        if self.parity == "strict":
+        if self.parity != "fast":
             from aadff import strict_stack
             if center and strict_stack.calls_fused(self):
                 out = strict_stack.strict_psf_map_call(self, depth, grid, ks, spp)

@@ -359,7 +359,8 @@ int aadff_psf_points_staged(const float* points, int S, int N, int L,
  *      pred[b][1] = the main batch's Newton counts) - applies forward_integral's window test and bilinear taps to that hit with
  *      `centre` = step 1's centres, and adds the taps to raw.  flags bit 4: a list overflowed.
  *   3. aadff_psf_normalise: raw -> psf in either layout of aadff_psf_points (the division of optics.py:978; same summation order as
- *      aadff_psf_points: a PSF none of whose rays was deferred is bit for bit what aadff_psf_points writes for the same states). */
+ *      aadff_psf_points: a PSF none of whose rays was deferred is what aadff_psf_points writes for the same states, up to the
+ *      order of the float atomics of its LDS histogram, which no two launches share). */
 int aadff_psf_points_edge(const float* points, int S, int N, int L,
                           const aadff_surface_t* surf_main, const aadff_surface_t* surf_chief,
                           aadff_lens_const_t lc, const aadff_lens_state_t* states,
