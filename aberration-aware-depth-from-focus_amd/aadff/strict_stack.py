@@ -194,6 +194,8 @@ def check_counts(any_bits, pred, curved, order):
     short = (m & low) != low
     more = ~short & (n < MAX_ITER) & (((m >> (n - 1)) & 1) == 1)
     bad = (short | more) & np.asarray(curved, dtype=bool)[idx]
+    if not bad.any():                                     # the usual case: every prediction of the launch holds
+        return np.ones(bad.shape[:-1], dtype=bool), pred
     ok = ~bad.any(-1)
     fix = pred.copy()
     if not ok.all():
@@ -292,26 +294,91 @@ def _level1_batched(lens, uf, focus, S, tabs, n_tables, n_surf, bt, dev):
     return (ro[..., 2] - rd[..., 2] * tt).numpy(), (rra > 0).numpy(), _masks_to_counts(scratch, S)
 
 
-def _d_sensor_of(fd_all, alive):
-    """np.mean of the valid positive crossing distances per slice (optics.py:1175-1178)."""
+class _HostFast:
+    """The per-slice host reductions of a stack as ONE array operation each where that gives the reference's bits: numpy's mean along
+    the contiguous axis and ATen's sum(1) run the same pairwise / vectorised inner loop per row as the 1-D calls the reference makes,
+    and the element-wise float32 operations of psf_diff's object points do not depend on the batch shape.  That is a property of
+    the installed numpy / torch builds, so it is CHECKED, not assumed: the first CHECKS uses of each form also run the reference's
+    call-by-call form and compare bit for bit; a mismatch switches the form off for the process (with a warning) and the
+    call-by-call result is used.  AADFF_HOST_FAST=0 switches all of them off (0.5 ms of Python per stack)."""
+    CHECKS = 3
+    on = os.environ.get("AADFF_HOST_FAST", "1") != "0"
+    left = {"mean": CHECKS, "fov": CHECKS, "points": CHECKS}
+
+    @classmethod
+    def use(cls, what):
+        return cls.on and cls.left[what] >= 0
+
+    @classmethod
+    def verify(cls, what, same):
+        """called with the comparison of the two forms while checks are left; returns True when the fast result may be used"""
+        if not same:
+            import warnings
+            cls.left[what] = -1
+            warnings.warn(f"aadff: vectorised host form '{what}' differs from the call-by-call form on this numpy / torch build; switched off",
+                          RuntimeWarning, stacklevel=3)
+            return False
+        cls.left[what] -= 1
+        if cls.left[what] < 0:
+            cls.left[what] = 0
+        return True
+
+
+def _d_sensor_loop(fd_all, alive):
+    """np.mean of the valid positive crossing distances per slice (optics.py:1175-1178), the reference's calls slice by slice."""
     out = []
     for k in range(fd_all.shape[0]):
         focus_d = fd_all[k][alive[k]]
         focus_d = focus_d[~np.isnan(focus_d) & (focus_d > 0)]
         with np.errstate(all="ignore"):
             z = float(np.mean(focus_d)) if len(focus_d) else float("nan")
-        assert z > 0, "sensor position is negative."
         out.append(z)
+    return out
+
+
+_MEAN_CHECKED = [0]
+
+
+def _d_sensor_of(fd_all, alive):
+    """np.mean of the valid positive crossing distances per slice (optics.py:1175-1178).  Slices all of whose rays count (the usual
+    case: every ray of the first surface's aperture reaches the sensor) are averaged by one mean along the contiguous axis - the
+    same pairwise float32 summation per row as the 1-D call (`_HostFast`); the others go through the reference's filtering."""
+    S = fd_all.shape[0]
+    if not _HostFast.use("mean"):
+        out = _d_sensor_loop(fd_all, alive)
+    else:
+        with np.errstate(all="ignore"):
+            keep = alive & (fd_all > 0)                          # NaN > 0 is False
+            full = keep.all(axis=1)
+            out = [None] * S
+            if full.any():
+                rows = np.ascontiguousarray(fd_all[full]) if not full.all() else fd_all
+                for k, v in zip(np.nonzero(full)[0], rows.mean(axis=1)):
+                    out[k] = float(v)
+            for k in np.nonzero(~full)[0]:
+                sel = fd_all[k][keep[k]]
+                out[k] = float(np.mean(sel)) if len(sel) else float("nan")
+        if _MEAN_CHECKED[0] < _HostFast.CHECKS:
+            _MEAN_CHECKED[0] += 1
+            want = _d_sensor_loop(fd_all, alive)
+            same = all((a == b) or (a != a and b != b) for a, b in zip(out, want))
+            if not _HostFast.verify("mean", same):
+                out = want
+    for z in out:
+        assert z > 0, "sensor position is negative."
     return out
 
 
 def _fov_geometry(lens, d_sensor):
     """calc_fov's rays (optics.py:1187-1204): o1 [S,3] sensor corners, o2 [100,3] points across the shrunk exit pupil."""
     M = 100
-    pupilz, pupilx = lens.exit_pupil(shrink_pupil=True)
-    x2 = torch.linspace(-pupilx, pupilx, M)
-    o2 = torch.stack((x2, torch.full_like(x2, 0), torch.full_like(x2, pupilz)), axis=-1)
-    o1 = torch.stack([torch.tensor([lens.r_last, 0, z]).to(torch.float32) for z in d_sensor])     # [S,3]
+    o2 = lens._table_cache.get("strict-fov-o2")                 # depends on the surfaces only (`Lensgroup.invalidate()` drops the cache)
+    if o2 is None:
+        pupilz, pupilx = lens.exit_pupil(shrink_pupil=True)
+        x2 = torch.linspace(-pupilx, pupilx, M)
+        o2 = lens._table_cache["strict-fov-o2"] = torch.stack((x2, torch.full_like(x2, 0), torch.full_like(x2, pupilz)), axis=-1)
+    # one tensor of Python floats -> float32, as torch.tensor([r_last, 0, z]) rounds each of them
+    o1 = torch.tensor([[lens.r_last, 0, z] for z in d_sensor], dtype=torch.float32)                # [S,3]
     return o1, o2
 
 
@@ -332,21 +399,38 @@ def _level2_batched(lens, d_sensor, S, tabs, n_tables, n_surf, bt, dev):
     return rd[..., 0] / rd[..., 2], rra, _masks_to_counts(scratch, S)
 
 
-def _fov_of(lens, tan_fov, rra):
-    """hfov / foclen / fnum per slice from the traced tangents (optics.py:1205-1217, 1097-1102, 186-187)."""
-    _, enp_r = lens.entrance_pupil()
-    hfov, foclen, fnum = [], [], []
+def _fov_loop(tan_fov, rra):
+    out = []
     for k in range(tan_fov.shape[0]):
         fov = torch.atan(torch.sum(tan_fov[k] * rra[k]) / torch.sum(rra[k]))
-        h = 0.5 if torch.isnan(fov) else fov.item()
-        hfov.append(h)
-        foclen.append(lens.r_last / np.tan(h))
-        fnum.append(foclen[-1] / enp_r / 2)
+        out.append(0.5 if torch.isnan(fov) else fov.item())
+    return out
+
+
+_FOV_CHECKED = [0]
+
+
+def _fov_of(lens, tan_fov, rra):
+    """hfov / foclen / fnum per slice from the traced tangents (optics.py:1205-1217, 1097-1102, 186-187).  The S sums and arctangents
+    are one sum(1) and one atan over [S] (the same vectorised inner loop per row / the same element-wise routine; `_HostFast`)."""
+    _, enp_r = lens.entrance_pupil()
+    if _HostFast.use("fov") and tan_fov.is_contiguous() and rra.is_contiguous():
+        fov = torch.atan((tan_fov * rra).sum(1) / rra.sum(1))
+        hfov = [0.5 if v != v else v for v in fov.tolist()]
+        if _FOV_CHECKED[0] < _HostFast.CHECKS:
+            _FOV_CHECKED[0] += 1
+            want = _fov_loop(tan_fov, rra)
+            if not _HostFast.verify("fov", hfov == want):
+                hfov = want
+    else:
+        hfov = _fov_loop(tan_fov, rra)
+    foclen = [lens.r_last / np.tan(h) for h in hfov]
+    fnum = [f / enp_r / 2 for f in foclen]
     return hfov, foclen, fnum
 
 
-def _object_points(lens, pts, hfov):
-    """psf_diff's object points per slice (optics.py:945-950): [S,N,3] float32 on the host."""
+def _object_points_loop(lens, pts, hfov):
+    """psf_diff's object points per slice (optics.py:945-950), the reference's tensor operations slice by slice."""
     pobj = []
     for h in hfov:
         scale = -pts[:, 2] * np.tan(h) / lens.r_last
@@ -355,6 +439,31 @@ def _object_points(lens, pts, hfov):
         p[..., 1] = pts[..., 1] * scale * lens.sensor_size[0] / 2
         pobj.append(p)
     return torch.stack(pobj)
+
+
+_POINTS_CHECKED = [0]
+
+
+def _object_points(lens, pts, hfov):
+    """psf_diff's object points per slice (optics.py:945-950): [S,N,3] float32 on the host.  Every operation of the reference is an
+    element-wise float32 one between a tensor and a Python scalar (which ATen rounds to float32 once): the S slices are one
+    broadcast of the same operations in the same order, the scalars rounded the same way (`_HostFast` checks it)."""
+    if not (_HostFast.use("points") and pts.dtype == torch.float32):
+        return _object_points_loop(lens, pts, hfov)
+    f32 = torch.float32
+    tanh = torch.tensor([float(np.tan(h)) for h in hfov], dtype=torch.float64).to(f32).unsqueeze(1)       # [S,1]: the scalar as ATen rounds it
+    r_last, sw, sh = (torch.tensor(float(v), dtype=torch.float64).to(f32) for v in (lens.r_last, lens.sensor_size[1], lens.sensor_size[0]))
+    two = torch.tensor(2.0, dtype=f32)
+    scale = ((-pts[:, 2]).unsqueeze(0) * tanh) / r_last                                                   # [S,N]
+    out = pts.unsqueeze(0).repeat(len(hfov), 1, 1)
+    out[..., 0] = ((pts[:, 0].unsqueeze(0) * scale) * sw) / two
+    out[..., 1] = ((pts[:, 1].unsqueeze(0) * scale) * sh) / two
+    if _POINTS_CHECKED[0] < _HostFast.CHECKS:
+        _POINTS_CHECKED[0] += 1
+        want = _object_points_loop(lens, pts, hfov)
+        if not _HostFast.verify("points", torch.equal(out.view(torch.int32), want.view(torch.int32))):
+            out = want
+    return out
 
 
 def _level3_batched(lens, sel, points, pset, pc, pm, zs, bt_chief, bt_main, tabs, n_tables, n_surf, N, spp, ks, dev):
@@ -748,15 +857,22 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
             maps = torch.empty((S, L, grid * ks, grid * ks), dtype=f32, device=dev)
             centre = torch.empty((B, N, 2), dtype=f32, device=dev)
             h = st.h_par[2]
-            h[:B].view(f32).copy_(torch.tensor(d_sensor, dtype=f32).repeat_interleave(L))
+            hn = h.numpy()
+            hn[:B].view(np.float32)[:] = np.repeat(np.asarray(d_sensor, dtype=np.float32), L)
             h[B:B + S * N * 3].view(f32).view(S, N, 3).copy_(pobj)
-            h[B + S * N * 3:].view(B, 2, MS).copy_(torch.from_numpy(pred3))
+            if eb.get("pred_ref") is not pred3:                 # the table's rows are replaced, never edited: same object = same counts
+                hn[B + S * N * 3:].reshape(B, 2, MS)[:] = pred3
+                eb["pred_ref"] = pred3
             hin, nst = eb["h_in"], eb["nst"]
-            states = (_abi.LensState * S).from_buffer(hin.numpy())
-            for k in range(S):
-                states[k].d_sensor, states[k].hfov, states[k].tan_hfov = d_sensor[k], hfov[k], float(np.tan(hfov[k]))
-                states[k].foclen, states[k].fnum, states[k].n_focus_rays, states[k].flags, states[k].pad = foclen[k], fnum[k], GEO_SPP, 0, 0
-            hin[nst:].view(f32).view(S, N, 3).copy_(pts.unsqueeze(0).expand(S, N, 3))
+            # the S lens states as the fast kernel reads them (aadff_lens_state_t: 5 floats, 3 ints per state)
+            sw = hin.numpy()[:nst].reshape(S, nst // S)
+            sf = sw.view(np.float32)
+            sf[:, 0], sf[:, 1], sf[:, 2] = d_sensor, hfov, [float(np.tan(v)) for v in hfov]
+            sf[:, 3], sf[:, 4] = foclen, fnum
+            sw[:, 5], sw[:, 6], sw[:, 7] = GEO_SPP, 0, 0
+            if eb.get("pts_key") != (float(depth_plane_mm), grid):
+                hin[nst:].view(f32).view(S, N, 3).copy_(pts.unsqueeze(0).expand(S, N, 3))
+                eb["pts_key"] = (float(depth_plane_mm), grid)
             pupils_ready.result()
             par, din, du, cnt = st.d_par[2], eb["d_in"], eb["d_u"], eb["count"]
             par.copy_(h, non_blocking=True)

@@ -764,3 +764,59 @@ def test_two_pass_row_draws_equal_one_pass_bit_exactly():
         assert torch.equal(out.view(S, per)[:, :head], want.view(S, per)[:, :head]) and bool((out.view(S, per)[:, head:] == -1).all())
         assert lib.aadff_host_mt19937_rows(None, 5056, S, per, head, C.c_void_p(out.data_ptr()), C.c_void_p(snaps.data_ptr()), 1) == 0
         assert torch.equal(out, want)
+
+
+def test_vectorised_host_reductions_equal_the_call_by_call_forms(monkeypatch):
+    """Round 6: the per-slice host arithmetic of a strict / edge stack (np.mean per slice, torch.sum / atan per slice, psf_diff's
+    object points per slice: deeplens/optics.py:1175-1178, :1205-1217, :945-950) as one array operation each.  Bit for bit the
+    call-by-call forms - also with slices that need the reference's filtering (dead rays, NaN, non-positive distances) - and the
+    self-check switches a form off (keeping the call-by-call result) when a build of numpy / torch does not agree."""
+    from aadff import strict_stack as ss
+    rng = np.random.default_rng(11)
+
+    class FakeLens:
+        r_last, sensor_size = 21.64, [30.60358, 30.60358]
+
+        def entrance_pupil(self):
+            return 19.809343, 13.351469
+
+    lens = FakeLens()
+    S = 10
+    for trial in range(60):
+        fd = (59.6 + rng.random((S, 2048), dtype=np.float32) * 0.05).astype(np.float32)
+        alive = np.ones((S, 2048), dtype=bool)
+        if trial % 3:
+            alive[rng.integers(S), rng.integers(2048, size=40)] = False
+            fd[rng.integers(S), rng.integers(2048)] = np.nan
+            fd[rng.integers(S), rng.integers(2048)] = -1.0
+        assert ss._d_sensor_of(fd, alive) == ss._d_sensor_loop(fd, alive)
+        tan = torch.from_numpy(rng.random((S, 100), dtype=np.float32) * 0.9 - 0.45)
+        ra = (torch.from_numpy(rng.random((S, 100), dtype=np.float32)) > 0.15).float()
+        h, f, n = ss._fov_of(lens, tan, ra)
+        assert h == ss._fov_loop(tan, ra) and f == [lens.r_last / np.tan(v) for v in h]
+        pts = torch.from_numpy(rng.random((121, 3), dtype=np.float32) * 2 - 1)
+        pts[:, 2] = -float(400 + rng.random() * 6000)
+        hf = [float(np.float32(0.3 + rng.random() * 0.2)) for _ in range(S)]
+        a, b = ss._object_points(lens, pts, hf), ss._object_points_loop(lens, pts, hf)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # a slice with no countable ray: NaN mean -> the reference's assertion
+    fd = np.full((2, 2048), 59.0, dtype=np.float32)
+    alive = np.ones((2, 2048), dtype=bool)
+    alive[1] = False
+    with pytest.raises(AssertionError, match="sensor position is negative"):
+        ss._d_sensor_of(fd, alive)
+    # all-NaN tangent sums fall back to 0.5 rad like the reference
+    tan, ra = torch.full((2, 100), 0.3), torch.ones(2, 100)
+    ra[1] = 0
+    assert ss._fov_of(lens, tan, ra)[0][1] == 0.5 == ss._fov_loop(tan, ra)[1]
+    # a build on which a vectorised form disagrees: switched off with a warning, the call-by-call result is what comes back
+    monkeypatch.setattr(ss, "_POINTS_CHECKED", [0])
+    monkeypatch.setitem(ss._HostFast.left, "points", ss._HostFast.CHECKS)
+    real = ss._object_points_loop
+    monkeypatch.setattr(ss, "_object_points_loop", lambda *a: real(*a) + 1.0)
+    with pytest.warns(RuntimeWarning, match="switched off"):
+        got = ss._object_points(lens, pts, hf)
+    assert torch.equal(got, real(lens, pts, hf) + 1.0) and not ss._HostFast.use("points")
+    monkeypatch.setattr(ss, "_object_points_loop", real)
+    assert torch.equal(ss._object_points(lens, pts, hf), real(lens, pts, hf))
+    monkeypatch.setitem(ss._HostFast.left, "points", 0)
