@@ -360,6 +360,19 @@ def main():
             return None, (f"stale: profiles/{name} was collected on another build of csrc/{source} (digest "
                           f"{str(dj.get('code_sha256', {}).get(source))[:12]}, this tree {have[:12]}); re-run tools/prof_r05.sh + tools/summarise_profiles.py")
         return dj, f"profiles/{name} (rocprofv3 PMC passes of this command on this build of csrc/{source}, sha256 {have[:12]}; not measured in this run)"
+
+    def digest_multi(name, sources):
+        """the same for a kernel compiled from several sources: quoted only while EVERY one of them still has the hash it was collected on"""
+        path = os.path.join(REPO, "profiles", name)
+        if not os.path.exists(path):
+            return None, f"profiles/{name} missing"
+        dj = json.load(open(path))
+        for src in sources:
+            have = file_sha256(os.path.join(REPO, "aberration-aware-depth-from-focus_amd", "csrc", src))
+            if dj.get("code_sha256", {}).get(src) != have:
+                return None, (f"stale: profiles/{name} was collected on another build of csrc/{src} (digest {str(dj.get('code_sha256', {}).get(src))[:12]}, "
+                              f"this tree {have[:12]}); re-run tools/prof_r06.sh + tools/summarise_profiles.py")
+        return dj, f"profiles/{name} (rocprofv3 passes of tools/strict_profile.py on this build of {', '.join(sources)}; not measured in this run)"
     tj, traffic_source = digest("conv_traffic.json", "conv.hip")
     traffic = tj.get("hbm_bytes_per_launch") if tj else None
     unique = (1 + S) * 3 * H * W * 4                     # bytes that MUST move per launch: the image once + S output slices (13.2 B/pixel/slice)
@@ -609,6 +622,11 @@ def main():
                 try:
                     res["parity"][_key], _f = guaranteed_mode(_name, _what)
                     strict_fail = strict_fail or _f
+                    if _name == "strict":
+                        sj, ssrc = digest_multi("strict_kernel_pmc.json", ("strict_fused.hip", "strict_math2.h", "strict_math.h", "strict.hip"))
+                        res["parity"][_key]["psf_map_kernel"] = {"us_per_launch_rocprof": sj.get("us_per_launch_rocprof") if sj else None,
+                                                                 "SQ_INSTS_VALU": sj.get("SQ_INSTS_VALU") if sj else None,
+                                                                 "valu_busy": sj.get("valu_busy") if sj else None, "source": ssrc}
                 except Exception as e:                   # the contract line must not depend on the verification modes
                     res["parity"][_key] = {"error": repr(e)}
             fpath = os.path.join(REPO, "tests", "golden", "g13_fp32_floor.npz")

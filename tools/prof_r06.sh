@@ -1,4 +1,4 @@
-# Round-5 evidence for profiles/ (run on the GPU box: gpurun -- 'bash tools/prof_r05.sh r05_a'); every rocprofv3 pass is its own run.
+# Round-6 evidence for profiles/ (run on the GPU box: gpurun -- 'bash tools/prof_r06.sh r06_a'); every rocprofv3 pass is its own run.
 # The hashes of the sources and of the library that ran are recorded FIRST (collection time), tools/summarise_profiles.py stamps the
 # digests with them.
 R=$GRAFT_REPO_ROOT; TAG=${1:-r05_a}
@@ -7,6 +7,7 @@ python3 - <<PY
 import hashlib, json, os
 R = "$R"; c = os.path.join(R, "aberration-aware-depth-from-focus_amd", "csrc")
 files = {"conv.hip": os.path.join(c, "conv.hip"), "trace.hip": os.path.join(c, "trace.hip"), "strict_fused.hip": os.path.join(c, "strict_fused.hip"),
+         "strict.hip": os.path.join(c, "strict.hip"), "strict_math.h": os.path.join(c, "strict_math.h"), "strict_math2.h": os.path.join(c, "strict_math2.h"),
          "psfnet.hip": os.path.join(c, "psfnet.hip"), "common.h": os.path.join(c, "common.h"), "aadff.h": os.path.join(R, "include", "aadff.h"),
          "libaadff.so": os.path.join(c, "libaadff.so")}
 json.dump({k: hashlib.sha256(open(v, "rb").read()).hexdigest() for k, v in files.items()}, open(os.path.join(R, "gpurun_out", "${TAG}_code_sha256.json"), "w"), indent=1)
@@ -17,6 +18,7 @@ $RP -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py --no-cpu-baseline --ste
 $RP -d $R/gpurun_out/${TAG}_stats_s1 -- python3 $R/bench.py --no-cpu-baseline --streams 1 --steps 200 --warmup 20 > /dev/null 2>&1
 $RP -d $R/gpurun_out/${TAG}_single_stats -- python3 $R/tools/kbench.py --rounds 5 --iters 20 > /dev/null 2>&1
 $RP -d $R/gpurun_out/${TAG}_strict_stats -- python3 $R/tools/strict_profile.py 12 --render > $R/gpurun_out/${TAG}_strict_profile.txt 2>&1
+$RP -d $R/gpurun_out/${TAG}_edge_stats -- python3 $R/tools/edge_bench.py 12 > $R/gpurun_out/${TAG}_edge_bench_under_rocprof.txt 2>&1
 $RP -d $R/gpurun_out/${TAG}_m1l_stats -- python3 $R/bench.py --mode m1l --no-cpu-baseline --steps 20 > $R/gpurun_out/${TAG}_bench_m1l_under_rocprof.json 2>/dev/null
 $RP -d $R/gpurun_out/${TAG}_dropin_stats -- python3 $R/tools/dropin_bench.py 20 > $R/gpurun_out/${TAG}_dropin.txt 2>/dev/null
 PM="timeout 300 rocprofv3 --kernel-trace --output-format csv"
@@ -39,4 +41,5 @@ timeout 300 python tools/conv_blkw_probe.py 2>/dev/null | tail -22 > gpurun_out/
 timeout 200 python tools/conv_single_timeline.py --ks 21 --grid 7 --json gpurun_out/${TAG}_conv_blkw_timeline_ks21.json > /dev/null 2>&1
 AADFF_CONV_BLKW_RB=24 timeout 200 python tools/conv_single_timeline.py --ks 21 --grid 7 --json gpurun_out/${TAG}_conv_blkw_timeline_ks21_rb24.json > /dev/null 2>&1
 PROBE_DEPTHS=3 timeout 300 python tools/strict_pipe_probe.py 30 2>/dev/null | grep -v "^/opt" > gpurun_out/${TAG}_strict_pipe_probe.txt
+PROBE_DEPTHS=2,4 timeout 300 python tools/edge_bench.py 40 2>/dev/null | grep -v "^/opt" > gpurun_out/${TAG}_edge_bench.txt
 AADFF_CALL_ZERO_COPY=0 timeout 300 python tools/dropin_bench.py 20 > gpurun_out/${TAG}_dropin_with_copies.txt 2>/dev/null

@@ -63,7 +63,7 @@ def write_pmc(dst, sources, keep):
 
 for name, sub in (("kernel_stats", "stats"), ("kernel_stats_1stream", "stats_s1"), ("fit_kernel_stats", "fit_stats"), ("local_psf_kernel_stats", "lp_stats"),
                   ("single_kernel_stats", "single_stats"), ("strict_kernel_stats", "strict_stats"), ("m1l_kernel_stats", "m1l_stats"),
-                  ("dropin_kernel_stats", "dropin_stats")):
+                  ("dropin_kernel_stats", "dropin_stats"), ("edge_kernel_stats", "edge_stats")):
     src = one(f"{tag}_{sub}/**/*_kernel_stats.csv")
     if src:
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.csv"))
@@ -75,13 +75,30 @@ for name in ("bench", "bench_fit", "bench_m2", "bench_2streams", "bench_refocus_
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.json"))
 
-for name in ("conv_ks_sweep", "strict_profile", "kbench", "dropin", "conv_blkw_probe", "strict_pipe_probe", "dropin_with_copies"):
+for name in ("conv_ks_sweep", "strict_profile", "kbench", "dropin", "conv_blkw_probe", "strict_pipe_probe", "dropin_with_copies", "edge_bench",
+             "edge_bench_under_rocprof"):
     src = os.path.join(G, f"{tag}_{name}.txt")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}.txt"))
+STRICT_SOURCES = ("strict_fused.hip", "strict_math2.h", "strict_math.h", "strict.hip")
 sp_ = one(f"{tag}_strict_pmc/**/*counter_collection.csv")
 if sp_:
-    write_pmc(os.path.join(P, f"{tag}_strict_kernel_pmc.csv"), [sp_], ("fused_psf_kernel", "fused_flat_kernel"))
+    srows = write_pmc(os.path.join(P, f"{tag}_strict_kernel_pmc.csv"), [sp_], ("fused_psf_kernel", "fused_flat_kernel"))
+    # digest of the strict psf_map kernel, stamped with the hashes of EVERY source it is compiled from: bench.py quotes
+    # it under parity.strict_mode only while the tree still holds those sources
+    sstats = one(f"{tag}_strict_stats/**/*_kernel_stats.csv")
+    us = None
+    if sstats:
+        for r in csv.DictReader(open(sstats)):
+            if "fused_psf_kernel<256>" in r["Name"]:
+                us = float(r["AverageNs"]) / 1e3
+    for k, (v, n, meta) in srows.items():
+        if "fused_psf_kernel<256>" in k and "SQ_INSTS_VALU" in v:
+            json.dump({"kernel": "strict::fused_psf_kernel<256> (psf_map level of a strict stack: S=10, N=121, L=3, spp 2048 + 2048 chief)",
+                       "code_sha256": code_sha256(*STRICT_SOURCES), "source": f"profiles/{tag}_strict_kernel_pmc.csv, profiles/{tag}_strict_kernel_stats.csv",
+                       "us_per_launch_rocprof": us, "SQ_INSTS_VALU": v["SQ_INSTS_VALU"], "SQ_INSTS_VALU_TRANS": v.get("SQ_INSTS_VALU_TRANS"),
+                       "valu_busy": round(min(1.0, v["SQ_ACTIVE_INST_VALU"] * 4 / (us * 1e-6 * 2.4e9 * 1024)), 3) if us and "SQ_ACTIVE_INST_VALU" in v else None},
+                      open(os.path.join(P, "strict_kernel_pmc.json"), "w"), indent=1)
 
 rows = write_pmc(os.path.join(P, f"{tag}_psf_kernel_pmc.csv"),
                  [one(f"{tag}_psf_pmc1/**/*counter_collection.csv"), one(f"{tag}_psf_pmc2/**/*counter_collection.csv")], ("psf_points_kernel",))
