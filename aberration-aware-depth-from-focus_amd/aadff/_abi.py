@@ -86,8 +86,8 @@ PROTOTYPES = {
     "aadff_psf_points": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _L, _L, _P, _I, _L, _L, _I, _I, _I, _P, _P, _P, _P],
     "aadff_psf_points_staged": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _L, _L, _P, _I, _L, _L, _I, _I, _I, _P, _P, _P,
                                 C.POINTER(Stage), _P],
-    "aadff_psf_points_edge": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _L, _L, _P, _I, _L, _L, _I, _F, _P, _P, _P, _P, _I, _P, _P],
-    "aadff_strict_edge_retrace": [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _I, _P, _F, _I, _P, _P, _P, _I, _P, _P, _P],
+    "aadff_psf_points_edge": [_P, _I, _I, _I, _P, _P, LensConst, _P, _P, _I, _L, _L, _P, _I, _L, _L, _I, _F, _P, _P, _P, _P, _P, _I, _P, _P],
+    "aadff_strict_edge_retrace": [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _I, _P, _F, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "aadff_psf_normalise": [_P, _I, _I, _I, _F, _I, _I, _P, _P],
     "aadff_psfnet_forward": [_P, _L, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "aadff_psfnet_render_rgbd": [_P, _P, _P, _P, _F, _F, _L, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],

@@ -584,6 +584,9 @@ class _Stage:
                 "count": torch.zeros(B + 1, dtype=i32, device=dev),                 # [B] counts | flags word
                 "list": torch.empty(B * EDGE_CAP, dtype=i32, device=dev),
                 "raw": torch.empty(B * N * ks * ks, dtype=f32, device=dev),
+                "slope": torch.empty(B * N * 2, dtype=f32, device=dev),
+                "states_prov": torch.zeros(nst, dtype=i32, device=dev),          # the fast refocus kernel's states (provisional pass)
+                "h_focus": torch.empty(2 * S, dtype=f32, pin_memory=True), "d_focus": torch.empty(2 * S, dtype=f32, device=dev),   # [focus S | tan_exact S]
                 "h_back": torch.zeros(B + 1, dtype=i32, pin_memory=True),
                 "uploaded": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False,
             }
@@ -751,8 +754,44 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
             # the two short levels may run on a stream of their own (StrictPipeline: a high-priority one, so that they do not queue
             # behind the psf_map launch of the stack in front); every level ends with a host wait, which orders them with level 3
             s12 = getattr(lens, "_strict_fast_stream", None)
+            if s12 is None and edge and phase == "all":
+                # an edge stack starts its PSF kernel BEFORE the short levels (provisional pass below): they need a stream of their
+                # own also outside a pipeline, a high-priority one (their few workgroups take the first slots the PSF kernel frees)
+                s12 = lens._table_cache.get("edge-side-stream")
+                if s12 is None:
+                    s12 = lens._table_cache["edge-side-stream"] = torch.cuda.Stream(dev, priority=-1)
             s12 = stream if s12 is None else s12
             sp12 = C.c_void_p(s12.cuda_stream)
+        prov = edge and phase == "all" and os.environ.get("AADFF_EDGE_PROVISIONAL", "1") != "0"
+        if edge:
+            maps = torch.empty((S, L, grid * ks, grid * ks), dtype=f32, device=dev)
+            centre = torch.empty((B, N, 2), dtype=f32, device=dev)
+            hin, nst, du, cnt = eb["h_in"], eb["nst"], eb["d_u"], eb["count"]
+            if eb.get("pts_key") != (float(depth_plane_mm), grid):
+                hin[nst:].view(f32).view(S, N, 3).copy_(pts.unsqueeze(0).expand(S, N, 3))
+                eb["pts_key"] = (float(depth_plane_mm), grid)
+                eb["d_in"][nst:].copy_(hin[nst:], non_blocking=True)
+            o_main_w = 0 if phase == "psf" else 2 * GEO_SPP
+            surf_bytes = C.sizeof(_abi.Surface)
+
+            def launch_edge(states_ptr, slope_ptr):
+                _abi.call("aadff_psf_points_edge", _ptr_at(eb["d_in"], nst), S, N, L, _abi.ptr(tab_dev), C.c_void_p(tab_dev.data_ptr() + t_green * n_surf * surf_bytes),
+                          lens._lens_const(), states_ptr, _ptr_at(du, o_main_w), spp, per, per_l, _ptr_at(du, o_main_w + 2 * spp), GEO_SPP, per, per_l, ks,
+                          EDGE_DELTA_MM, _abi.ptr(eb["raw"]), _abi.ptr(centre), slope_ptr, _ptr_at(cnt, 0), _abi.ptr(eb["list"]), EDGE_CAP, _ptr_at(cnt, B), sp)
+        if prov:
+            # ---- provisional pass (edge stacks): the PSF kernel needs lens states, and the exact ones come out of two host round trips
+            # (levels 1 and 2 below, ~1 ms of latency with the GPU idle).  The interior rays do not care about a few ulps of d_sensor /
+            # hfov - only the border decisions do, and those are taken by the re-trace in the exact world - so the fast refocus kernel
+            # provides PROVISIONAL states from the same draws and the fast PSF kernel starts right away, beside the short levels; the
+            # re-trace moves each centre into the exact world (csrc/strict_fused.hip: EdgeRetraceArgs).
+            du.copy_(eb["h_u"], non_blocking=True)
+            eb["h_focus"][:S] = torch.tensor([float(f) for f in focus], dtype=f32)
+            eb["d_focus"][:S].copy_(eb["h_focus"][:S], non_blocking=True)
+            cnt[B:].zero_()
+            _abi.call("aadff_refocus", _abi.ptr(eb["d_focus"]), S, _abi.ptr(du), GEO_SPP, per, C.c_void_p(tab_dev.data_ptr() + t_green * n_surf * surf_bytes),
+                      lens._lens_const(), _abi.ptr(eb["states_prov"]), sp)
+            launch_edge(_abi.ptr(eb["states_prov"]), _abi.ptr(eb["slope"]))
+            mark("provisional pass queued")
         if fused and phase != "focus":
             def psf_pupils():
                 # the psf_map pupil points are not needed before level 3: a worker thread evaluates them (torch releases the GIL in
@@ -851,11 +890,9 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
         pobj = _object_points(lens, pts, hfov)                                                     # [S,N,3]
         edge_done = False
         if edge:
-            # ---- level 3, edge-exact: fast kernel + strict re-trace of the rays at the window edge + normalisation, no host wait in between
+            # ---- level 3, edge-exact: fast kernel (already running on provisional states, or launched here on the exact ones) + strict
+            # re-trace of the rays at the window edge + normalisation, no host wait in between
             pred3 = counts.rows[keys[2]]
-            kk = ks * ks
-            maps = torch.empty((S, L, grid * ks, grid * ks), dtype=f32, device=dev)
-            centre = torch.empty((B, N, 2), dtype=f32, device=dev)
             h = st.h_par[2]
             hn = h.numpy()
             hn[:B].view(np.float32)[:] = np.repeat(np.asarray(d_sensor, dtype=np.float32), L)
@@ -863,35 +900,32 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
             if eb.get("pred_ref") is not pred3:                 # the table's rows are replaced, never edited: same object = same counts
                 hn[B + S * N * 3:].reshape(B, 2, MS)[:] = pred3
                 eb["pred_ref"] = pred3
-            hin, nst = eb["h_in"], eb["nst"]
-            # the S lens states as the fast kernel reads them (aadff_lens_state_t: 5 floats, 3 ints per state)
-            sw = hin.numpy()[:nst].reshape(S, nst // S)
-            sf = sw.view(np.float32)
-            sf[:, 0], sf[:, 1], sf[:, 2] = d_sensor, hfov, [float(np.tan(v)) for v in hfov]
-            sf[:, 3], sf[:, 4] = foclen, fnum
-            sw[:, 5], sw[:, 6], sw[:, 7] = GEO_SPP, 0, 0
-            if eb.get("pts_key") != (float(depth_plane_mm), grid):
-                hin[nst:].view(f32).view(S, N, 3).copy_(pts.unsqueeze(0).expand(S, N, 3))
-                eb["pts_key"] = (float(depth_plane_mm), grid)
+            par = st.d_par[2]
+            if prov:
+                eb["h_focus"][S:] = torch.tensor([float(np.tan(v)) for v in hfov], dtype=torch.float64).to(f32)
+                eb["d_focus"][S:].copy_(eb["h_focus"][S:], non_blocking=True)
+            else:
+                # the S lens states as the fast kernel reads them (aadff_lens_state_t: 5 floats, 3 ints per state)
+                sw = hin.numpy()[:nst].reshape(S, nst // S)
+                sf = sw.view(np.float32)
+                sf[:, 0], sf[:, 1], sf[:, 2] = d_sensor, hfov, [float(np.tan(v)) for v in hfov]
+                sf[:, 3], sf[:, 4] = foclen, fnum
+                sw[:, 5], sw[:, 6], sw[:, 7] = GEO_SPP, 0, 0
+                eb["d_in"][:nst].copy_(hin[:nst], non_blocking=True)
+                du.copy_(eb["h_u"], non_blocking=True)
+                cnt[B:].zero_()
             pupils_ready.result()
-            par, din, du, cnt = st.d_par[2], eb["d_in"], eb["d_u"], eb["count"]
             par.copy_(h, non_blocking=True)
-            din.copy_(hin, non_blocking=True)
-            du.copy_(eb["h_u"], non_blocking=True)
             st.d_pupil[st.n_pf:st.n_pf + st.n_pm].copy_(hp[st.n_pf:st.n_pf + st.n_pm], non_blocking=True)
             eb["uploaded"].record(stream)
             eb["busy"] = True
-            cnt[B:].zero_()
             mark("level 3 inputs")
-            o_main_w = 0 if phase == "psf" else 2 * GEO_SPP
-            surf_bytes = C.sizeof(_abi.Surface)
-            lc = lens._lens_const()
-            _abi.call("aadff_psf_points_edge", _ptr_at(din, nst), S, N, L, _abi.ptr(tab_dev), C.c_void_p(tab_dev.data_ptr() + t_green * n_surf * surf_bytes), lc,
-                      _ptr_at(din, 0), _ptr_at(du, o_main_w), spp, per, per_l, _ptr_at(du, o_main_w + 2 * spp), GEO_SPP, per, per_l, ks, EDGE_DELTA_MM,
-                      _abi.ptr(eb["raw"]), _abi.ptr(centre), _ptr_at(cnt, 0), _abi.ptr(eb["list"]), EDGE_CAP, _ptr_at(cnt, B), sp)
+            if not prov:
+                launch_edge(_ptr_at(eb["d_in"], 0), None)
             _abi.call("aadff_strict_edge_retrace", _ptr_at(par, B), N, B, _abi.ptr(st.pset), _abi.ptr(tab_dev), len(wv), n_surf, _abi.ptr(st.bt_main),
                       _ptr_at(par, 0), _ptr_at(st.d_pupil, st.n_pf), spp, _ptr_at(par, B + S * N * 3), float(lens.pixel_size), ks, _abi.ptr(centre),
-                      _ptr_at(cnt, 0), _abi.ptr(eb["list"]), EDGE_CAP, _abi.ptr(eb["raw"]), _ptr_at(cnt, B), sp)
+                      _ptr_at(cnt, 0), _abi.ptr(eb["list"]), EDGE_CAP, _abi.ptr(eb["raw"]), _ptr_at(cnt, B),
+                      _abi.ptr(eb["states_prov"]) if prov else None, _ptr_at(eb["d_focus"], S) if prov else None, _abi.ptr(eb["slope"]) if prov else None, sp)
             _abi.call("aadff_psf_normalise", _abi.ptr(eb["raw"]), S, N, L, float(lens.pixel_size), ks, 1, _abi.ptr(maps), sp)
             eb["h_back"].copy_(cnt, non_blocking=True)
             eb["done"].record(stream)

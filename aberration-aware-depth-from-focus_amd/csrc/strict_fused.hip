@@ -375,6 +375,15 @@ struct EdgeRetraceArgs {
     const unsigned* list;           // [B][cap]
     float* raw;                     // [B][N][ks*ks]
     int* flags;                     // bit 4: a batch's list overflowed its capacity (the caller falls back to the strict psf_map)
+    // The edge launch may have run on PROVISIONAL lens states (the fast refocus kernel's, a few ulps from the reference's: it then
+    // overlaps the strict refocus / calc_fov round trips instead of waiting for them).  Its centre belongs to that world; the
+    // re-traced hit to the exact one.  The centre is moved over: the sensor plane shifted by dd = d_exact - d_prov moves every
+    // chief hit by its direction tangent times dd (exactly linear), and the object height scales with tan(hfov) (the image height
+    // with it, to first order - the correction is ~5e-6 mm, its own error a few per cent of that: tools/edge_sim.py shows a centre
+    // off by 1e-7 mm changes nothing).  NULL: the launch ran on the exact states.
+    const aadff_lens_state_t* states_prov;   // [P]
+    const float* tan_exact;                  // [P] float(tan(hfov)) of the exact states
+    const float* slope;                      // [B][N][2] mean direction tangents of the valid chief rays (aadff_psf_points_edge)
     int N, n_surf, spp, ks, cap;
     float lo, hi, lim, den_row, den_col;
 };
@@ -408,7 +417,13 @@ __global__ __launch_bounds__(256) void edge_retrace_kernel(EdgeRetraceArgs a) {
     const int ks = a.ks, kk = ks * ks;
     const float km1 = (float)(ks - 1);
     auto splat = [&](float ox, float oy, float w, int pt) {
-        const float cx = a.centre[((size_t)b * a.N + pt) * 2], cy = a.centre[((size_t)b * a.N + pt) * 2 + 1];
+        float cx = a.centre[((size_t)b * a.N + pt) * 2], cy = a.centre[((size_t)b * a.N + pt) * 2 + 1];
+        if (a.states_prov) {
+            const int ps = a.point_set[b];
+            const float dd = a.z_sensor[b] - a.states_prov[ps].d_sensor, rt = a.tan_exact[ps] / a.states_prov[ps].tan_hfov;
+            cx = (cx - a.slope[((size_t)b * a.N + pt) * 2] * dd) * rt;
+            cy = (cy - a.slope[((size_t)b * a.N + pt) * 2 + 1] * dd) * rt;
+        }
         const float X = -ox - cx, Y = -oy - cy;                                                         // monte_carlo.py:24-38
         if ((fabsf(X) < a.lim) && (fabsf(Y) < a.lim) && (w > 0.f)) {
             float* hist = a.raw + ((size_t)b * a.N + pt) * kk;
@@ -531,16 +546,19 @@ extern "C" int aadff_strict_psf_points(const float* points, int N, int B, const 
 extern "C" int aadff_strict_edge_retrace(const float* points, int N, int B, const int* point_set, const aadff_surface_t* tables_dev, int n_tables, int n_surf,
                                          const int* table_main, const float* z_sensor, const float* pupil_main, int spp, const int* pred,
                                          float pixel_size, int ks, const float* centre, const unsigned* edge_count, const unsigned* edge_list,
-                                         int edge_cap, float* raw, int* flags_or_null, aadff_stream_t stream) {
+                                         int edge_cap, float* raw, int* flags_or_null, const aadff_lens_state_t* states_prov_or_null,
+                                         const float* tan_exact, const float* slope, aadff_stream_t stream) {
     AADFF_CHECK_ARG(points && point_set && tables_dev && table_main && z_sensor && pupil_main && pred && centre && edge_count && edge_list && raw,
                     "strict_edge_retrace: NULL pointer");
     AADFF_CHECK_ARG(N >= 1 && N <= 65535 && B >= 1 && B <= 65535 && spp >= 1 && spp <= 65536, "strict_edge_retrace: N=%d B=%d spp=%d", N, B, spp);
     AADFF_CHECK_ARG(n_tables >= 1 && n_surf >= 1 && n_surf <= AADFF_MAX_SURF, "strict_edge_retrace: n_tables=%d n_surf=%d", n_tables, n_surf);
     AADFF_CHECK_ARG(ks >= 1 && ks <= AADFF_MAX_KS && (ks & 1), "strict_edge_retrace: ks=%d", ks);
     AADFF_CHECK_ARG(edge_cap >= 1, "strict_edge_retrace: capacity %d", edge_cap);
+    AADFF_CHECK_ARG(!states_prov_or_null || (tan_exact && slope), "strict_edge_retrace: provisional states need tan_exact and slope");
     strict::EdgeRetraceArgs a{};
     a.points = points; a.point_set = point_set; a.tables = tables_dev; a.table_main = table_main; a.z_sensor = z_sensor; a.pupil_main = pupil_main;
     a.pred = pred; a.centre = centre; a.count = edge_count; a.list = edge_list; a.raw = raw; a.flags = flags_or_null;
+    a.states_prov = states_prov_or_null; a.tan_exact = tan_exact; a.slope = slope;
     a.N = N; a.n_surf = n_surf; a.spp = spp; a.ks = ks; a.cap = edge_cap;
     const double ps = (double)pixel_size;                                        // monte_carlo.py:24: Python floats, rounded once
     const double lo = (-ks / 2.0 + 0.5) * ps, hi = (ks / 2.0 - 0.5) * ps;

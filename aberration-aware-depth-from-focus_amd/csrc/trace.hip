@@ -804,6 +804,9 @@ struct EdgeArgs {
     unsigned* list;           // [S*L][cap]
     int cap;
     float* raw;               // [S*L][N][ks*ks] unnormalised histograms (every element written)
+    float* slope;             // [S*L][N][2] or NULL: mean direction tangents (dx/dz, dy/dz) of the valid chief rays at the sensor - what
+                              // moves the centre when the sensor plane moves (the re-trace corrects the centre for the caller's exact
+                              // d_sensor when this launch ran on provisional lens states, aadff_strict_edge_retrace)
 };
 
 // returns true when the hit was left to the re-trace (appended or, beyond cap, counted: the host sees count > cap)
@@ -906,7 +909,7 @@ __device__ __forceinline__ void psf_points_body(const float* __restrict__ points
                                                           int spp_chief, long chief_ss, long chief_sl, SplatGeom g, int centre_mode, int map_grid, float* psf,
                                                           float* centre_out, int* flags, StageArgs stage, const EdgeArgs& edge) {
     extern __shared__ float hist[];                      // ks * ks floats (dynamic: ks up to AADFF_MAX_KS = 51)
-    __shared__ float red[3 * kPsfWaves];
+    __shared__ float red[(EDGE ? 5 : 3) * kPsfWaves];
     __shared__ int stage_late;
 #if !defined(AADFF_PSF_SCALAR) && !defined(AADFF_PSF_NO_COMPACT)
     __shared__ float cbuf[6][kCompactMax];               // survivors of the first surfaces: origin and direction
@@ -974,6 +977,7 @@ __device__ __forceinline__ void psf_points_body(const float* __restrict__ points
         const float* ut = u_chief + (size_t)s * chief_ss + (size_t)l * chief_sl;
         const float* ur = ut + spp_chief;
         float sx = 0.f, sy = 0.f, sw = 0.f;
+        [[maybe_unused]] float tx = 0.f, ty = 0.f;       // EDGE: sums of the direction tangents of the valid chief rays
 #ifndef AADFF_PSF_SCALAR
         for (int i = tid; i < spp_chief; i += 2 * kPsfThreads) {
             const int i1 = i + kPsfThreads;
@@ -984,6 +988,11 @@ __device__ __forceinline__ void psf_points_body(const float* __restrict__ points
             const Ray2 r = trace_pair_to_sensor(px, py, depth, x2, y2, lc.enp_z, act, surf_chief, lc.n_surf, st.d_sensor, nan_flag);
             const f2 wx = r.ox * r.ra, wy = r.oy * r.ra;
             sx += wx.x + wx.y; sy += wy.x + wy.y; sw += r.ra.x + r.ra.y;
+            if (EDGE) {
+                const f2 iz = vrcp(r.dz);
+                const f2 ax = vsel(r.alive, r.dx * iz, f2s(0.f)), ay = vsel(r.alive, r.dy * iz, f2s(0.f));
+                tx += ax.x + ax.y; ty += ay.x + ay.y;
+            }
         }
 #else
         for (int i = tid; i < spp_chief; i += kPsfThreads) {
@@ -996,8 +1005,10 @@ __device__ __forceinline__ void psf_points_body(const float* __restrict__ points
         }
 #endif
         sx = wave_sum(sx); sy = wave_sum(sy); sw = wave_sum(sw);
+        if (EDGE) { tx = wave_sum(tx); ty = wave_sum(ty); }
         if ((tid & 63) == 0) {
             red[(tid >> 6) * 3] = sx; red[(tid >> 6) * 3 + 1] = sy; red[(tid >> 6) * 3 + 2] = sw;
+            if (EDGE) { red[3 * kPsfWaves + (tid >> 6) * 2] = tx; red[3 * kPsfWaves + (tid >> 6) * 2 + 1] = ty; }
         }
         __syncthreads();
         sx = sy = sw = 0.f;
@@ -1005,6 +1016,12 @@ __device__ __forceinline__ void psf_points_body(const float* __restrict__ points
         for (int w = 0; w < kPsfWaves; ++w) { sx += red[3 * w]; sy += red[3 * w + 1]; sw += red[3 * w + 2]; }
         cx = -(sx / (sw + kEps));
         cy = -(sy / (sw + kEps));
+        if (EDGE && edge.slope && tid == 0) {
+            tx = ty = 0.f;
+            for (int w = 0; w < kPsfWaves; ++w) { tx += red[3 * kPsfWaves + 2 * w]; ty += red[3 * kPsfWaves + 2 * w + 1]; }
+            float* so = edge.slope + ((size_t)(s * L + l) * N + n) * 2;
+            so[0] = tx / (sw + kEps); so[1] = ty / (sw + kEps);
+        }
         if (sw == 0.f && tid == 0 && flags) atomicOr(flags, 2);      // "No sampled rays is valid." (optics.py:901)
     } else {
         cx = xn * (lc.sensor_w / 2.f);                               // optics.py:972-974
@@ -1462,8 +1479,8 @@ int aadff_psf_points_edge(const float* points, int S, int N, int L, const aadff_
                           const aadff_surface_t* surf_chief, aadff_lens_const_t lc, const aadff_lens_state_t* states,
                           const float* u_main, int spp, long main_stride_s, long main_stride_l, const float* u_chief,
                           int spp_chief, long chief_stride_s, long chief_stride_l, int ks, float delta_mm, float* raw,
-                          float* centre_out, unsigned* edge_count, unsigned* edge_list, int edge_cap, int* flags_or_null,
-                          aadff_stream_t stream) {
+                          float* centre_out, float* slope_out_or_null, unsigned* edge_count, unsigned* edge_list, int edge_cap,
+                          int* flags_or_null, aadff_stream_t stream) {
 #if defined(AADFF_PSF_SCALAR) || defined(AADFF_PSF_NO_COMPACT) || defined(AADFF_PSF_SWITCH_LOOP)
     set_error("psf_points_edge: not part of the measurement builds of the trace kernels");
     return AADFF_EUNSUPPORTED;
@@ -1478,7 +1495,7 @@ int aadff_psf_points_edge(const float* points, int S, int N, int L, const aadff_
     hipStream_t st = (hipStream_t)stream;
     AADFF_CHECK_HIP(hipMemsetAsync(edge_count, 0, (size_t)S * L * sizeof(unsigned), st));
     EdgeArgs e{};
-    e.delta = delta_mm; e.count = edge_count; e.list = edge_list; e.cap = edge_cap; e.raw = raw;
+    e.delta = delta_mm; e.count = edge_count; e.list = edge_list; e.cap = edge_cap; e.raw = raw; e.slope = slope_out_or_null;
     hipLaunchKernelGGL(psf_points_edge_kernel, dim3(N, L, S), dim3(kPsfThreads), (size_t)ks * ks * sizeof(float), st, points, N, L, surf_main, surf_chief, lc,
                        states, u_main, spp, main_stride_s, main_stride_l, u_chief, spp_chief, chief_stride_s, chief_stride_l,
                        make_splat_geom(lc.pixel_size, ks), 1, centre_out, flags_or_null, e);

@@ -358,6 +358,11 @@ int aadff_psf_points_staged(const float* points, int S, int N, int L,
  *      operation order - arguments as aadff_strict_psf_points (object points and pupil points from the reference's host arithmetic,
  *      pred[b][1] = the main batch's Newton counts) - applies forward_integral's window test and bilinear taps to that hit with
  *      `centre` = step 1's centres, and adds the taps to raw.  flags bit 4: a list overflowed.
+ *      PROVISIONAL STATES: step 1 may run on lens states that are only close to the exact ones (the fast refocus kernel's, a few
+ *      ulps off) so that it overlaps the strict refocus / calc_fov round trips; it then also writes slope_out [S,L,N,2], the mean
+ *      direction tangents of the valid chief rays, and step 2 - given states_prov [P] (what step 1 ran on), tan_exact [P] =
+ *      float(tan(hfov)) and z_sensor of the exact states - moves each centre into the exact world before the window test:
+ *      c = (c - slope * (d_exact - d_prov)) * tan_exact / tan_prov.  states_prov_or_null = NULL: step 1 ran on the exact states.
  *   3. aadff_psf_normalise: raw -> psf in either layout of aadff_psf_points (the division of optics.py:978; same summation order as
  *      aadff_psf_points: a PSF none of whose rays was deferred is what aadff_psf_points writes for the same states, up to the
  *      order of the float atomics of its LDS histogram, which no two launches share). */
@@ -366,13 +371,15 @@ int aadff_psf_points_edge(const float* points, int S, int N, int L,
                           aadff_lens_const_t lc, const aadff_lens_state_t* states,
                           const float* u_main, int spp, long main_stride_s, long main_stride_l,
                           const float* u_chief, int spp_chief, long chief_stride_s, long chief_stride_l,
-                          int ks, float delta_mm, float* raw, float* centre_out,
+                          int ks, float delta_mm, float* raw, float* centre_out, float* slope_out_or_null,
                           unsigned* edge_count, unsigned* edge_list, int edge_cap,
                           int* flags_or_null, aadff_stream_t stream);
 int aadff_strict_edge_retrace(const float* points, int N, int B, const int* point_set, const aadff_surface_t* tables_dev, int n_tables,
                               int n_surf, const int* table_main, const float* z_sensor, const float* pupil_main, int spp,
                               const int* pred, float pixel_size, int ks, const float* centre, const unsigned* edge_count,
-                              const unsigned* edge_list, int edge_cap, float* raw, int* flags_or_null, aadff_stream_t stream);
+                              const unsigned* edge_list, int edge_cap, float* raw, int* flags_or_null,
+                              const aadff_lens_state_t* states_prov_or_null, const float* tan_exact, const float* slope,
+                              aadff_stream_t stream);
 int aadff_psf_normalise(const float* raw, int S, int N, int L, float pixel_size, int ks, int map_layout, float* psf,
                         aadff_stream_t stream);
 

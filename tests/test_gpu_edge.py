@@ -74,13 +74,25 @@ def test_edge_mode_meets_1e_4_on_every_fixture_stack_and_slice(golden_dir, repo_
     margin(f"case {case} edge: PSF maps rel-L2, whole stack", rel(maps.cpu().numpy(), g["psf_maps"]), 2e-3)
     margin(f"case {case} edge: re-traced rays per stack / all main rays", float(rays.sum()) / (S * 3 * 121 * 2048), 0.02)
     margin(f"case {case} edge: seconds per stack, sequential call (informative)", dt, 5.0)
+    if case == 0:
+        # the same stack with the PSF kernel started only AFTER the strict refocus levels (on the exact states, no provisional pass)
+        os.environ["AADFF_EDGE_PROVISIONAL"] = "0"
+        try:
+            torch.manual_seed(case)
+            out2 = render_focal_stack_m1(lens, img, dbar, fds, 11, 11, 2048)
+        finally:
+            del os.environ["AADFF_EDGE_PROVISIONAL"]
+        d2 = out2[0].double() - ref
+        margin("case 0 edge WITHOUT the provisional pass: whole stack rel-L2 vs the reference", float(np.sqrt(float((d2 * d2).sum()) / den)), 1e-4)
+        margin("case 0 edge: provisional pass vs exact-state pass, whole stack rel-L2 between the two", float(np.sqrt(float(((out2 - out) ** 2).sum()) / den)), 3e-5)
     assert lens.d_sensor == pytest.approx(float(g["d_sensor"][-1]), rel=2e-7)
     if "hfov" in g.files:
         assert lens.hfov == pytest.approx(float(g["hfov"][-1]), rel=2e-7)
 
 
-def _edge_calls(lens, S, N, L, spp, ks, u, states, pts_norm, pobj, pupil_main, pred, delta, cap=8192):
-    """the three ABI calls of the edge level on caller-built inputs; returns (maps [S,L,G,G], centre, counts [B], lists, flags)"""
+def _edge_calls(lens, S, N, L, spp, ks, u, states, pts_norm, pobj, pupil_main, pred, delta, cap=8192, prov_states=None, correct=True):
+    """the three ABI calls of the edge level on caller-built inputs; returns (maps [S,L,G,G], centre, counts [B], lists, flags).
+    prov_states: the fast kernel runs on THESE states instead, the re-trace (exact world: `states`) moves the centres over (correct=True)"""
     dev = torch.device(DEV)
     B, kk, g = S * L, ks * ks, int(round(N ** 0.5))
     per, o_main, o_chief, per_l = stack_uniform_layout(spp, L)
@@ -92,21 +104,26 @@ def _edge_calls(lens, S, N, L, spp, ks, u, states, pts_norm, pobj, pupil_main, p
     cnt = torch.zeros(B + 1, dtype=torch.int32, device=dev)
     lst = torch.zeros(B * cap, dtype=torch.int32, device=dev)
     maps = torch.empty((S, L, g * ks, g * ks), dtype=torch.float32, device=dev)
+    slope = torch.zeros((B, N, 2), dtype=torch.float32, device=dev)
     st = _abi.stream_ptr(dev)
     ub = u.data_ptr()
     lc = lens._lens_const()
     _abi.call("aadff_psf_points_edge", _abi.ptr(pts_norm), S, N, L, _abi.ptr(tab), C.c_void_p(tab.data_ptr() + n_surf * C.sizeof(_abi.Surface)), lc,
-              _abi.ptr(states), C.c_void_p(ub + 4 * o_main), spp, per, per_l, C.c_void_p(ub + 4 * o_chief), GEO_SPP, per, per_l, ks, float(delta),
-              _abi.ptr(raw), _abi.ptr(centre), C.c_void_p(cnt.data_ptr()), _abi.ptr(lst), cap, C.c_void_p(cnt.data_ptr() + 4 * B), st)
+              _abi.ptr(states if prov_states is None else prov_states), C.c_void_p(ub + 4 * o_main), spp, per, per_l, C.c_void_p(ub + 4 * o_chief), GEO_SPP, per, per_l,
+              ks, float(delta), _abi.ptr(raw), _abi.ptr(centre), None if prov_states is None else _abi.ptr(slope), C.c_void_p(cnt.data_ptr()), _abi.ptr(lst), cap,
+              C.c_void_p(cnt.data_ptr() + 4 * B), st)
     pset = torch.arange(S, dtype=torch.int32).repeat_interleave(L).to(dev)
     bt_main = torch.arange(L, dtype=torch.int32).repeat(S).to(dev)
     zs = torch.tensor([s.d_sensor for s in states_host(states, S)], dtype=torch.float32).repeat_interleave(L).to(dev)
     _abi.call("aadff_strict_edge_retrace", _abi.ptr(pobj), N, B, _abi.ptr(pset), _abi.ptr(tab), len(wv), n_surf, _abi.ptr(bt_main), _abi.ptr(zs),
               _abi.ptr(pupil_main), spp, _abi.ptr(pred), float(lens.pixel_size), ks, _abi.ptr(centre), C.c_void_p(cnt.data_ptr()), _abi.ptr(lst), cap,
-              _abi.ptr(raw), C.c_void_p(cnt.data_ptr() + 4 * B), st)
+              _abi.ptr(raw), C.c_void_p(cnt.data_ptr() + 4 * B),
+              *((None, None, None) if prov_states is None or not correct else
+                (_abi.ptr(prov_states), _abi.ptr(torch.tensor([s_.tan_hfov for s_ in states_host(states, S)], dtype=torch.float32).to(dev)), _abi.ptr(slope))), st)
     _abi.call("aadff_psf_normalise", _abi.ptr(raw), S, N, L, float(lens.pixel_size), ks, 1, _abi.ptr(maps), st)
     torch.cuda.synchronize()
     c = cnt.cpu().numpy()
+    _edge_calls.slope = slope
     return maps, centre, c[:B], lst.cpu().numpy().view(np.uint32).reshape(B, cap), int(c[B])
 
 
@@ -172,6 +189,28 @@ def test_edge_psfs_without_deferred_rays_are_the_fast_kernels_bits(repo_root, ma
     assert touched.sum() > 0 and (~touched).sum() > 0
     margin("edge band 3e-3 mm (test width): PSFs with a re-traced ray vs the fast kernel's, max |d| (a border ray is 1 / rays-inside)",
            float(np.nanmax(np.abs(m1[touched] - w[touched]))), 5e-2)
+    # provisional states: the fast kernel on states 6 / 4 ulps off (d_sensor / tan hfov: about twice the fast refocus kernel's error); the
+    # re-trace moves every centre into the exact world, c = (c - slope dd) tan_exact / tan_prov: checked on the centres themselves (a
+    # float32 centroid of 2048 hits of up to 15 mm carries ~2e-6 mm of summation noise of its own, so that is the floor), and the
+    # PSFs stay those of the all-exact run up to the interior rays' own dependence on the states (single aperture-rim rays)
+    _, c_exact, _, _, _ = _edge_calls(lens, S, N, L, spp, ks, u, states, pts_norm, pobj, pupil_main, pred, 3e-3)
+    sh2 = states_host(states, S)
+    for s_ in sh2:
+        s_.d_sensor = float(np.float32(s_.d_sensor) + 6 * np.spacing(np.float32(s_.d_sensor)))
+        s_.tan_hfov = float(np.float32(s_.tan_hfov) + 4 * np.spacing(np.float32(s_.tan_hfov)))
+    prov = torch.from_numpy(np.frombuffer(bytes(sh2), dtype=np.uint8).copy()).to(dev)
+    maps_c, c_prov, c_c, l_c, f_c = _edge_calls(lens, S, N, L, spp, ks, u, states, pts_norm, pobj, pupil_main, pred, 3e-3, prov_states=prov)
+    slope = _edge_calls.slope.cpu().numpy().astype(np.float64)                                     # [B,N,2]
+    dd = np.repeat([np.float64(np.float32(a_.d_sensor)) - np.float64(np.float32(b_.d_sensor)) for a_, b_ in zip(sh, sh2)], L)[:, None, None]
+    rt = np.repeat([np.float64(np.float32(a_.tan_hfov)) / np.float64(np.float32(b_.tan_hfov)) for a_, b_ in zip(sh, sh2)], L)[:, None, None]
+    ce, cp = c_exact.cpu().numpy().astype(np.float64), c_prov.cpu().numpy().astype(np.float64)
+    raw_err, cor_err = np.abs(cp - ce).max(), np.abs((cp - slope * dd) * rt - ce).max()
+    margin("centre of the provisional world vs the exact one [mm], uncorrected (informative)", raw_err, 1.0)
+    margin("   moved over by the re-trace's formula [mm] (floor: the float32 centroid's own summation noise)", cor_err, 4e-6)
+    assert cor_err < 0.5 * raw_err and f_c == 0
+    peak = float(np.nanmax(w))
+    margin("edge on provisional states vs the all-exact run: PSF entries off by more than 2e-4 of the peak / all entries (informative)",
+           float(((maps_c - maps1).nan_to_num().abs() > 2e-4 * peak).float().mean()), 1e-3)
     # capacity: counts keep counting, the list is not written past its end, bit 4 reports it
     cap = max(1, int(c1.max()) // 2)
     _, _, c2, l2, f2 = _edge_calls(lens, S, N, L, spp, ks, u, states, pts_norm, pobj, pupil_main, pred, 3e-3, cap=cap)
