@@ -626,7 +626,7 @@ def _nan_in_run(nan_bits, pred, curved):
     return bool(((np.asarray(nan_bits).astype(np.uint32) & ran) != 0)[..., curved].any())
 
 
-def _speculate_small(counts, key, st, lvl, S, n, curved, order, launch, stream):
+def _speculate_small(counts, key, st, lvl, S, n, curved, order, launch, stream, after_first_submit=None):
     """A cheap level (S batches of n rays) on speculated counts: every batch is traced under each candidate row of the table at
     once (`StrictCounts.candidates`: 2048-ray batches cost nothing, a second round trip costs 60-100 us), the first candidate whose
     any-bits confirm it is the batch's result; batches without one are re-launched with the row `check_counts` corrected.
@@ -644,7 +644,11 @@ def _speculate_small(counts, key, st, lvl, S, n, curved, order, launch, stream):
         pred = np.stack([row for _, row in cand]).astype(np.int32)
         h[G:G + J] = [b for b, _ in cand]
         h[G + st.J:G + st.J + J * MS] = pred.reshape(-1)
-        yield st.submit(lvl, G + st.J + J * MS, 2 * J * n + J * 2 * MS, lambda par, res: launch(J, par, res), stream)
+        ev = st.submit(lvl, G + st.J + J * MS, 2 * J * n + J * 2 * MS, lambda par, res: launch(J, par, res), stream)
+        if after_first_submit is not None:                  # host work of the caller that can run while this launch is in flight
+            after_first_submit()
+            after_first_submit = None
+        yield ev
         r = st.result(lvl)
         counts.stats["fused"] += 1
         bits = r[2 * J * n:2 * J * n + J * 2 * MS].view(np.uint32).reshape(J, 2, MS)
@@ -778,7 +782,7 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                 _abi.call("aadff_psf_points_edge", _ptr_at(eb["d_in"], nst), S, N, L, _abi.ptr(tab_dev), C.c_void_p(tab_dev.data_ptr() + t_green * n_surf * surf_bytes),
                           lens._lens_const(), states_ptr, _ptr_at(du, o_main_w), spp, per, per_l, _ptr_at(du, o_main_w + 2 * spp), GEO_SPP, per, per_l, ks,
                           EDGE_DELTA_MM, _abi.ptr(eb["raw"]), _abi.ptr(centre), slope_ptr, _ptr_at(cnt, 0), _abi.ptr(eb["list"]), EDGE_CAP, _ptr_at(cnt, B), sp)
-        if prov:
+        def provisional_pass():
             # ---- provisional pass (edge stacks): the PSF kernel needs lens states, and the exact ones come out of two host round trips
             # (levels 1 and 2 below, ~1 ms of latency with the GPU idle).  The interior rays do not care about a few ulps of d_sensor /
             # hfov - only the border decisions do, and those are taken by the re-trace in the exact world - so the fast refocus kernel
@@ -792,6 +796,7 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                       lens._lens_const(), _abi.ptr(eb["states_prov"]), sp)
             launch_edge(_abi.ptr(eb["states_prov"]), _abi.ptr(eb["slope"]))
             mark("provisional pass queued")
+        # (queued right behind level 1's launch, below: the host work of queueing it then overlaps the level-1 kernel)
         if fused and phase != "focus":
             def psf_pupils():
                 # the psf_map pupil points are not needed before level 3: a worker thread evaluates them (torch releases the GIL in
@@ -836,7 +841,8 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                           _ptr_at(par, 0), _ptr_at(par, G), _abi.ptr(st.d_pupil), 1, 0, n_surf, 1, None, _ptr_at(par, G + st.J),
                           _ptr_at(res, 2 * J * GEO_SPP), 1, 1, _ptr_at(res, 0), _ptr_at(res, J * GEO_SPP), _ptr_at(par, G), sp12)
 
-            got = yield from _speculate_small(counts, keys[0], st, 0, S, GEO_SPP, curved, fwd_order, launch1, s12)
+            got = yield from _speculate_small(counts, keys[0], st, 0, S, GEO_SPP, curved, fwd_order, launch1, s12,
+                                              after_first_submit=provisional_pass if prov else None)
             if got is not None:
                 fd_all, alive = got[0], got[1] > 0
         bt_green = st.bt_green if st is not None else torch.full((B,), t_green, dtype=torch.int32, device=dev)

@@ -245,8 +245,18 @@ def test_edge_lens_per_call_api_and_pipeline(repo_root, margin):
             got.append(lens2.psf_map(depth=-2000.0, grid=grid, ks=ks, spp=spp))
     got = torch.stack(got)
     assert strict_stack.StrictCounts.of(lens2).stats.get("edge", 0) >= S
-    margin("edge per-call API (refocus + psf_map per slice) vs the edge stack: PSF maps max |d| / max (histogram atomics)",
-           float((got.to(DEV) - maps).abs().max() / maps.max()), 2e-6)
+    # (the stack's PSF kernel runs on the PROVISIONAL states of the fast refocus kernel, a per-call psf_map on the lens's exact state:
+    # the interior rays' taps differ by what a few ulps of d_sensor / hfov do to a float32 trace; the border decisions are the same)
+    margin("edge per-call API (refocus + psf_map per slice) vs the edge stack: PSF maps max |d| / max (interior rays: provisional vs exact states)",
+           float((got.to(DEV) - maps).abs().max() / maps.max()), 2e-4)
+    os.environ["AADFF_EDGE_PROVISIONAL"] = "0"
+    try:
+        torch.manual_seed(3)
+        _, maps_x = render_focal_stack_m1(lens, img, -2000.0, fds, grid, ks, spp, return_maps=True)
+    finally:
+        del os.environ["AADFF_EDGE_PROVISIONAL"]
+    margin("edge per-call API vs the edge stack WITHOUT the provisional pass: PSF maps max |d| / max (histogram atomics)",
+           float((got.to(DEV) - maps_x).abs().max() / maps_x.max()), 2e-6)
     # pipeline
     pipe = strict_stack.StrictPipeline(lambda: Lensgroup(lp(repo_root), sensor_res=(H, W), device=DEV, parity="edge"), depth=2)
     with pipe:
