@@ -109,6 +109,7 @@ PROTOTYPES = {
     "aadff_host_mt19937_rows": [_P, _L, _I, _L, _L, _P, _P, _I],
     "aadff_strict_replay_threads": [_I],
     "aadff_host_device_pointer": [_P, _P],
+    "aadff_host_masked_mean_f32": [_P, _P, _L, _L, _P, _P],
     "aadff_host_pupil_points": [_P, _L, _P, _P, _L, _F, _F, _F, _P, _P, _P, _P, _I],
 }
 OTHER_SYMBOLS = ["aadff_abi_version", "aadff_last_error", "aadff_device_info"]

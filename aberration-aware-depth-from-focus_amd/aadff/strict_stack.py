@@ -339,31 +339,29 @@ def _d_sensor_loop(fd_all, alive):
 _MEAN_CHECKED = [0]
 
 
-def _d_sensor_of(fd_all, alive):
-    """np.mean of the valid positive crossing distances per slice (optics.py:1175-1178).  Slices all of whose rays count (the usual
-    case: every ray of the first surface's aperture reaches the sensor) are averaged by one mean along the contiguous axis - the
-    same pairwise float32 summation per row as the 1-D call (`_HostFast`); the others go through the reference's filtering."""
-    S = fd_all.shape[0]
-    if not _HostFast.use("mean"):
-        out = _d_sensor_loop(fd_all, alive)
-    else:
-        with np.errstate(all="ignore"):
-            keep = alive & (fd_all > 0)                          # NaN > 0 is False
-            full = keep.all(axis=1)
-            out = [None] * S
-            if full.any():
-                rows = np.ascontiguousarray(fd_all[full]) if not full.all() else fd_all
-                for k, v in zip(np.nonzero(full)[0], rows.mean(axis=1)):
-                    out[k] = float(v)
-            for k in np.nonzero(~full)[0]:
-                sel = fd_all[k][keep[k]]
-                out[k] = float(np.mean(sel)) if len(sel) else float("nan")
+def _d_sensor_of(fd_all, alive, weights=None):
+    """np.mean of the valid positive crossing distances per slice (optics.py:1175-1178): `aadff_host_masked_mean_f32` - numpy's pairwise
+    float32 summation and float64 division restated in C, all slices in one call (the reference's filtering and np.mean slice by
+    slice are ~10 us of numpy overhead each) - checked against numpy itself on its first uses (`_HostFast`).  `weights`: the float32
+    ray weights the mask `alive` came from (rows countable where weight > 0)."""
+    S, n = fd_all.shape
+    fast = _HostFast.use("mean") and fd_all.dtype == np.float32 and fd_all.flags.c_contiguous
+    if fast:
+        w = weights if weights is not None and weights.dtype == np.float32 and weights.flags.c_contiguous else alive.astype(np.float32)
+        out_a, scratch = np.empty(S, dtype=np.float32), np.empty(max(n, 1), dtype=np.float32)
+        rc = _abi.load_library().aadff_host_masked_mean_f32(C.c_void_p(fd_all.ctypes.data), C.c_void_p(w.ctypes.data), S, n, C.c_void_p(scratch.ctypes.data),
+                                                            C.c_void_p(out_a.ctypes.data))
+        fast = rc == 0
+    if fast:
+        out = [float(v) for v in out_a]
         if _MEAN_CHECKED[0] < _HostFast.CHECKS:
             _MEAN_CHECKED[0] += 1
             want = _d_sensor_loop(fd_all, alive)
             same = all((a == b) or (a != a and b != b) for a, b in zip(out, want))
             if not _HostFast.verify("mean", same):
                 out = want
+    else:
+        out = _d_sensor_loop(fd_all, alive)
     for z in out:
         assert z > 0, "sensor position is negative."
     return out
@@ -450,14 +448,17 @@ def _object_points(lens, pts, hfov):
     broadcast of the same operations in the same order, the scalars rounded the same way (`_HostFast` checks it)."""
     if not (_HostFast.use("points") and pts.dtype == torch.float32):
         return _object_points_loop(lens, pts, hfov)
-    f32 = torch.float32
-    tanh = torch.tensor([float(np.tan(h)) for h in hfov], dtype=torch.float64).to(f32).unsqueeze(1)       # [S,1]: the scalar as ATen rounds it
-    r_last, sw, sh = (torch.tensor(float(v), dtype=torch.float64).to(f32) for v in (lens.r_last, lens.sensor_size[1], lens.sensor_size[0]))
-    two = torch.tensor(2.0, dtype=f32)
-    scale = ((-pts[:, 2]).unsqueeze(0) * tanh) / r_last                                                   # [S,N]
-    out = pts.unsqueeze(0).repeat(len(hfov), 1, 1)
-    out[..., 0] = ((pts[:, 0].unsqueeze(0) * scale) * sw) / two
-    out[..., 1] = ((pts[:, 1].unsqueeze(0) * scale) * sh) / two
+    # numpy float32 arithmetic: the same IEEE single-precision multiply / divide per element as ATen's CPU kernels, at a fifth of
+    # the per-call overhead (eight small operations per stack)
+    p = pts.numpy()
+    tanh = np.array([np.tan(h) for h in hfov], dtype=np.float64).astype(np.float32)[:, None]             # [S,1]: the scalar as ATen rounds it
+    r_last, sw, sh, two = (np.float32(v) for v in (lens.r_last, lens.sensor_size[1], lens.sensor_size[0], 2.0))
+    scale = ((-p[:, 2])[None, :] * tanh) / r_last                                                         # [S,N]
+    o = np.empty((len(hfov),) + p.shape, dtype=np.float32)
+    o[..., 0] = ((p[:, 0][None, :] * scale) * sw) / two
+    o[..., 1] = ((p[:, 1][None, :] * scale) * sh) / two
+    o[..., 2] = p[:, 2][None, :]
+    out = torch.from_numpy(o)
     if _POINTS_CHECKED[0] < _HostFast.CHECKS:
         _POINTS_CHECKED[0] += 1
         want = _object_points_loop(lens, pts, hfov)
@@ -844,16 +845,17 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
             got = yield from _speculate_small(counts, keys[0], st, 0, S, GEO_SPP, curved, fwd_order, launch1, s12,
                                               after_first_submit=provisional_pass if prov else None)
             if got is not None:
-                fd_all, alive = got[0], got[1] > 0
+                fd_all, alive, w_focus = got[0], got[1] > 0, got[1]
         bt_green = st.bt_green if st is not None else torch.full((B,), t_green, dtype=torch.int32, device=dev)
         if phase != "psf" and (not fused or got is None):
             if fused:
                 counts.stats["per_surface_replays"] += 1
             fd_all, alive, cnt = _level1_batched(lens, uf, focus, S, tabs, len(wv), n_surf, bt_green[:S], dev)
+            w_focus = None
             counts.learn(keys[0], cnt)
         mark("level 1 back on the host")
         if phase != "psf":
-            d_sensor = _d_sensor_of(fd_all, alive)
+            d_sensor = _d_sensor_of(fd_all, alive, w_focus)
         mark("d_sensor")
         # ---- level 2: calc_fov (deeplens/optics.py:1187-1217) - S batches of 100 rays from the sensor corner, backward
         if fused and phase != "psf":

@@ -278,3 +278,44 @@ extern "C" int aadff_host_pupil_points(const float* u, long n_rows, const long* 
     }
     return 0;
 }
+
+// ---- np.mean of the countable values of each row (refocus, deeplens/optics.py:1175-1178) in numpy's own arithmetic ------------------
+// numpy sums a contiguous float32 vector PAIRWISE (numpy/_core/src/umath/loops_utils.h.src: fewer than 8 elements in order; up to 128
+// in eight interleaved accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), the remainder added in order; longer vectors
+// split at n/2 rounded down to a multiple of 8) and np.mean divides that float32 sum by the count IN FLOAT64, then rounds to float32
+// (numpy/_core/_methods.py: `ret.dtype.type(ret / rcount)` with rcount an intp scalar).  Checked against numpy itself by the caller
+// (aadff/strict_stack.py: _HostFast) and in tests/test_host_logic.py.
+namespace {
+float np_pairwise_sum(const float* a, long n) {
+    if (n < 8) {
+        float res = 0.f;
+        for (long i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        long i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+}  // namespace
+
+extern "C" int aadff_host_masked_mean_f32(const float* values, const float* weights, long rows, long n, float* scratch, float* out) {
+    AADFF_CHECK_ARG(values && weights && scratch && out && rows >= 0 && n >= 0, "host_masked_mean_f32: NULL pointer or negative size");
+    for (long k = 0; k < rows; ++k) {
+        const float *v = values + k * n, *w = weights + k * n;
+        long m = 0;
+        for (long i = 0; i < n; ++i)
+            if (w[i] > 0.f && v[i] > 0.f) scratch[m++] = v[i];            // ra > 0, not NaN, > 0: the reference's three filters
+        out[k] = m ? (float)((double)np_pairwise_sum(scratch, m) / (double)m) : __builtin_nanf("");
+    }
+    return 0;
+}

@@ -562,6 +562,12 @@ int aadff_host_mt19937_discard(unsigned char* torch_state_host, long state_bytes
 int aadff_host_mt19937_rows(unsigned char* torch_state_host, long state_bytes, int n_rows, long row_len, long head, float* out_host,
                             unsigned char* snapshots_host, int phase);
 
+/* HOST routine (strict / edge parity): out[k] = np.mean of the values of row k whose weight is > 0 and which are > 0 (and not NaN) -
+ * refocus's `focus_d[ra > 0]`, `focus_d[~isnan & (focus_d > 0)]`, `np.mean` (deeplens/optics.py:1175-1178) for all slices of a stack in
+ * numpy's own arithmetic: pairwise float32 summation in numpy's blocking, the division in float64, rounded to float32; NaN for a row
+ * without a countable value.  values / weights [rows][n], scratch [n], out [rows]; all host memory. */
+int aadff_host_masked_mean_f32(const float* values, const float* weights, long rows, long n, float* scratch, float* out);
+
 /* Workgroup size (256 or 1024, default 1024) of an aadff_strict_psf_points launch with fewer than 1024 workgroups, i.e. a re-launch
  * of the few batches whose speculated Newton counts (deeplens/surfaces.py:547) were off: 1024 threads shorten it on an idle GPU,
  * 256 get scheduled beside another stack's full launch (aadff.strict_stack.StrictPipeline).  Process-wide. */

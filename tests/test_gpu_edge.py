@@ -268,3 +268,50 @@ def test_edge_lens_per_call_api_and_pipeline(repo_root, margin):
     torch.cuda.synchronize()
     for o, ev in outs[2:]:                                                            # the first stack of each lens was its seed run
         margin("edge pipeline (2 in flight) vs the sequential edge stack: max |d| / max", float((o - out).abs().max() / out.max()), 2e-6)
+
+
+def test_edge_list_overflow_falls_back_to_the_strict_psf_map(repo_root, margin, monkeypatch):
+    """A batch with more deferred rays than its list holds (a caustic along the window edge; here: a capacity of 4) is reported by the
+    re-trace (flags bit 4) and the stack's psf_map level is redone by the strict kernel: same maps as a strict lens, same lens state."""
+    H = W = 256
+    S, grid, ks, spp = 3, 5, 11, 1024
+    fds = [-600.0, -1500.0, -5000.0]
+    img = tt(synth_rgb(H, W, seed=5))[None].to(DEV)
+    monkeypatch.setattr(strict_stack, "EDGE_CAP", 4)
+    lens = Lensgroup(lp(repo_root), sensor_res=(H, W), device=DEV, parity="edge")
+    strict = Lensgroup(lp(repo_root), sensor_res=(H, W), device=DEV, parity="strict")
+    for l in (lens, strict):
+        torch.manual_seed(8)
+        render_focal_stack_m1(l, img, -900.0, fds, grid, ks, spp)                    # seed runs
+    torch.manual_seed(8)
+    out, maps = render_focal_stack_m1(lens, img, -900.0, fds, grid, ks, spp, return_maps=True)
+    stats = strict_stack.StrictCounts.of(lens).stats
+    assert stats.get("edge_overflows", 0) == 1 and lens._edge_last["flags"] & 16, (stats, lens._edge_last)
+    torch.manual_seed(8)
+    _, smaps = render_focal_stack_m1(strict, img, -900.0, fds, grid, ks, spp, return_maps=True)
+    margin("edge stack after a list overflow vs the strict stack: PSF maps max |d| / max (histogram atomics)",
+           float((maps - smaps).abs().max() / smaps.max()), 2e-6)
+    assert lens.d_sensor == strict.d_sensor and lens.hfov == strict.hfov
+
+
+def test_edge_mode_second_lens_and_other_kernel_sizes(repo_root, margin):
+    """50mm_f2.8 (all spherical, stop at index 6), ks 21 on a 7 x 7 grid (the reference's render_single_img shape): the edge stack against
+    the strict one - same d_sensor / hfov, PSF maps at the fast path's distance from the strict maps or closer."""
+    H = W = 256
+    S, grid, ks, spp = 3, 7, 21, 1024
+    fds = [-700.0, -1800.0, -6000.0]
+    img = tt(synth_rgb(H, W, seed=6))[None].to(DEV)
+    path = lp(repo_root, "50mm_f2.8")
+    lens, strict, fast = (Lensgroup(path, sensor_res=(H, W), device=DEV, **kw) for kw in ({"parity": "edge"}, {"parity": "strict"}, {}))
+    res = {}
+    for name, l in (("edge", lens), ("strict", strict), ("fast", fast)):
+        for rep in range(2):                                                          # first pass: seed runs of the count tables
+            torch.manual_seed(12)
+            res[name] = render_focal_stack_m1(l, img, -1500.0, fds, grid, ks, spp, return_maps=True)
+    assert strict_stack.StrictCounts.of(lens).stats.get("edge", 0) == 1 and strict_stack.StrictCounts.of(lens).stats.get("edge_overflows", 0) == 0
+    assert lens.d_sensor == strict.d_sensor and lens.hfov == strict.hfov
+    e, f = rel(res["edge"][1].cpu().numpy(), res["strict"][1].cpu().numpy()), rel(res["fast"][1].cpu().numpy(), res["strict"][1].cpu().numpy())
+    margin("50mm_f2.8, ks 21, grid 7: edge PSF maps vs strict, rel-L2", e, 2e-3)
+    margin("   fast PSF maps vs strict (informative)", f, 1.0)
+    margin("50mm_f2.8, ks 21, grid 7: edge stack vs strict stack, image rel-L2", rel(res["edge"][0].cpu().numpy(), res["strict"][0].cpu().numpy()), 1e-4)
+    assert e <= 1.2 * f

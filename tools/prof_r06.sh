@@ -43,3 +43,11 @@ AADFF_CONV_BLKW_RB=24 timeout 200 python tools/conv_single_timeline.py --ks 21 -
 PROBE_DEPTHS=3 timeout 300 python tools/strict_pipe_probe.py 30 2>/dev/null | grep -v "^/opt" > gpurun_out/${TAG}_strict_pipe_probe.txt
 PROBE_DEPTHS=2,4 timeout 300 python tools/edge_bench.py 40 2>/dev/null | grep -v "^/opt" > gpurun_out/${TAG}_edge_bench.txt
 AADFF_CALL_ZERO_COPY=0 timeout 300 python tools/dropin_bench.py 20 > gpurun_out/${TAG}_dropin_with_copies.txt 2>/dev/null
+# the raw rocprofv3 directories exceed what gpurun copies back (64 MiB): reduce them HERE (tools/summarise_profiles.py writes the judged
+# summaries into profiles/), ship the summaries in gpurun_out/${TAG}_profiles/ and drop the raw traces
+python3 tools/summarise_profiles.py ${TAG} > gpurun_out/${TAG}_summarise.log 2>&1
+mkdir -p gpurun_out/${TAG}_profiles
+cp profiles/${TAG}_* gpurun_out/${TAG}_profiles/ 2>/dev/null
+cp profiles/conv_traffic.json profiles/psf_kernel_pmc.json profiles/strict_kernel_pmc.json gpurun_out/${TAG}_profiles/ 2>/dev/null
+for d in stats stats_s1 single_stats strict_stats edge_stats m1l_stats dropin_stats psf_pmc1 psf_pmc2 conv_pmc fetch write strict_pmc; do rm -rf gpurun_out/${TAG}_$d; done
+du -sh gpurun_out > gpurun_out/${TAG}_size.txt
