@@ -58,6 +58,26 @@ class FitNet(C.Structure):
                 ("inp", C.c_void_p), ("target", C.c_void_p), ("pred", C.c_void_p)]
 
 
+class Levels(C.Structure):
+    """aadff_levels_t: the short levels of a strict / edge stack (csrc/stack_host.cpp)."""
+    _fields_ = [("S", C.c_int), ("n_surf", C.c_int), ("n_tables", C.c_int), ("jobs_max", C.c_int), ("fov_rays", C.c_int), ("J1", C.c_int), ("J2", C.c_int),
+                ("pad", C.c_int), ("tables_dev", C.c_void_p), ("bt_green", C.c_void_p), ("zeros", C.c_void_p),
+                ("h_par1", C.c_void_p), ("d_par1", C.c_void_p), ("h_res1", C.c_void_p), ("d_res1", C.c_void_p),
+                ("h_par2", C.c_void_p), ("d_par2", C.c_void_p), ("h_res2", C.c_void_p), ("d_res2", C.c_void_p),
+                ("h_pupil", C.c_void_p), ("d_pupil", C.c_void_p), ("curved", C.c_ubyte * MAX_SURF)]
+
+
+class EdgeStack(C.Structure):
+    """aadff_edge_stack_t: the edge-exact psf_map level of a stack."""
+    _fields_ = [("S", C.c_int), ("L", C.c_int), ("N", C.c_int), ("spp", C.c_int), ("ks", C.c_int), ("n_surf", C.c_int), ("n_tables", C.c_int),
+                ("t_green", C.c_int), ("cap", C.c_int), ("pad", C.c_int), ("per", C.c_long), ("per_l", C.c_long), ("o_main", C.c_long), ("n_pm", C.c_long),
+                ("delta", C.c_float), ("pixel_size", C.c_float), ("lc", LensConst), ("tables_dev", C.c_void_p),
+                ("h_u", C.c_void_p), ("d_u", C.c_void_p), ("h_focus", C.c_void_p), ("d_focus", C.c_void_p), ("d_pts", C.c_void_p), ("states_prov", C.c_void_p),
+                ("raw", C.c_void_p), ("slope", C.c_void_p), ("count", C.c_void_p), ("list", C.c_void_p), ("h_back", C.c_void_p),
+                ("h_par3", C.c_void_p), ("d_par3", C.c_void_p), ("pset", C.c_void_p), ("bt_main", C.c_void_p),
+                ("h_pupil_main", C.c_void_p), ("d_pupil_main", C.c_void_p)]
+
+
 assert C.sizeof(Stage) == 40
 assert C.sizeof(Surface) == 136 and C.sizeof(LensState) == 32 and C.sizeof(LensConst) == 52
 
@@ -110,6 +130,12 @@ PROTOTYPES = {
     "aadff_strict_replay_threads": [_I],
     "aadff_host_device_pointer": [_P, _P],
     "aadff_host_masked_mean_f32": [_P, _P, _L, _L, _P, _P],
+    "aadff_levels_focus_submit": [C.POINTER(Levels), _P, _P, _F, _F, _F, _P, _P, _P, _P, _I, _P, _P],
+    "aadff_levels_focus_finish": [C.POINTER(Levels), _P, _P, _P],
+    "aadff_levels_fov_submit": [C.POINTER(Levels), _P, _F, _I, _P, _P],
+    "aadff_levels_fov_finish": [C.POINTER(Levels), _P, _P, _P],
+    "aadff_edge_provisional": [C.POINTER(EdgeStack), _P, _P, _P],
+    "aadff_edge_finish": [C.POINTER(EdgeStack), _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P],
     "aadff_host_pupil_points": [_P, _L, _P, _P, _L, _F, _F, _F, _P, _P, _P, _P, _I],
 }
 OTHER_SYMBOLS = ["aadff_abi_version", "aadff_last_error", "aadff_device_info"]

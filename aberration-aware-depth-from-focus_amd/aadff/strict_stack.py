@@ -324,6 +324,17 @@ class _HostFast:
         return True
 
 
+class _HostNative:
+    """The native host driver of the short levels (csrc/stack_host.cpp).  AADFF_HOST_NATIVE=0: the Python form throughout."""
+    on = os.environ.get("AADFF_HOST_NATIVE", "1") != "0"
+
+    @classmethod
+    def switch_off(cls, what):
+        import warnings
+        cls.on = False
+        warnings.warn(f"aadff: native host driver differs from the Python form ({what}); switched off", RuntimeWarning, stacklevel=3)
+
+
 def _d_sensor_loop(fd_all, alive):
     """np.mean of the valid positive crossing distances per slice (optics.py:1175-1178), the reference's calls slice by slice."""
     out = []
@@ -548,7 +559,9 @@ class _Stage:
         # parameter blocks.  levels 1 / 2: [geometry G | job -> batch J | pred J*MS]  (G = S*3 axis points | S*3 sensor corners + M*3 pupil points)
         #                   level 3: [z_sensor B | object points S*N*3 | pred B*2*MS];  its replays: [job -> batch B | pred B*2*MS]
         self.G = [S * 3, S * 3 + M * 3]
-        sizes = [self.G[0] + J + J * MS, self.G[1] + J + J * MS, B + S * N * 3 + B * 2 * MS, B + B * 2 * MS]
+        self.replay_slots = max(1, int(os.environ.get("AADFF_REPLAY_ROTATE", "1")))      # experiment: replays rotate over several parameter regions
+        self.replay_turn = 0
+        sizes = [self.G[0] + J + J * MS, self.G[1] + J + J * MS, B + S * N * 3 + B * 2 * MS, (B + B * 2 * MS) * self.replay_slots]
         self.h_par = [torch.empty(n, dtype=i32, pin_memory=True) for n in sizes]
         self.d_par = [torch.empty(n, dtype=i32, device=dev) for n in sizes]
         # result blocks: levels 1 / 2 [value J*n | ra J*n | bits J*2*MS], level 3 and its replays [bits B*4*MS | any_valid B]
@@ -571,6 +584,50 @@ class _Stage:
         self.off_focus = np.arange(S, dtype=np.int64) * per
         self.off_main, self.off_chief = sl + o_main, sl + o_chief
 
+    def native_levels(self, lens, counts, keys, curved, tab_dev, n_tables, n_surf, S):
+        """aadff_levels_t for csrc/stack_host.cpp (the short levels' host work as one call per wait), with the candidate count rows
+        of both levels written into the parameter blocks - rewritten only when the table's rows / alternatives have changed.
+        Returns (struct, cand1, cand2): cand = [(batch, row)] in job order."""
+        nl = getattr(self, "_native", None)
+        if nl is None:
+            lv = _abi.Levels()
+            lv.S, lv.n_surf, lv.n_tables, lv.jobs_max, lv.fov_rays = S, n_surf, n_tables, self.J, 100
+            lv.tables_dev, lv.bt_green, lv.zeros = tab_dev.data_ptr(), self.bt_green.data_ptr(), self.zeros.data_ptr()
+            for i in (0, 1):
+                setattr(lv, f"h_par{i + 1}", self.h_par[i].data_ptr()); setattr(lv, f"d_par{i + 1}", self.d_par[i].data_ptr())
+                setattr(lv, f"h_res{i + 1}", self.h_res[i].data_ptr()); setattr(lv, f"d_res{i + 1}", self.d_res[i].data_ptr())
+            lv.h_pupil, lv.d_pupil = self.h_pupil.data_ptr(), self.d_pupil.data_ptr()
+            for i in range(_abi.MAX_SURF):
+                lv.curved[i] = 1 if curved[i] else 0
+            o1, o2 = _fov_geometry(lens, [1.0] * S)
+            self.h_par[1][S * 3:S * 3 + 100 * 3].view(torch.float32).view(100, 3).copy_(o2)         # constant per lens
+            ev = [torch.cuda.Event(), torch.cuda.Event()]
+            for e in ev:
+                e.record()                                   # creates the HIP event behind it: the driver records it by handle
+            nl = self._native = {"lv": lv, "ver": [None, None], "cand": [None, None], "first": [None, None], "events": ev,
+                                 "chosen": np.empty(S, dtype=np.int32), "dsens": np.empty(S, dtype=np.float32), "scratch": np.empty(GEO_SPP, dtype=np.float32),
+                                 "tan": np.empty((S, 100), dtype=np.float32), "ra": np.empty((S, 100), dtype=np.float32),
+                                 "focus": np.empty(S, dtype=np.float32), "o2z": o2[0, 2].clone(), "checked": 0}
+        lv = nl["lv"]
+        for lvl in (0, 1):
+            # the candidate rows in the parameter block stay while the table says the same (compared by content: 2 x S x 32 words)
+            rows_now, seen_now = counts.rows[keys[lvl]], counts.seen[keys[lvl]]
+            ver = nl["ver"][lvl]
+            if ver is None or not (np.array_equal(ver[0], rows_now) and np.array_equal(ver[1], seen_now)):
+                ver = (rows_now.copy(), seen_now.copy())
+                cand = [(b, row) for b in range(S) for row in counts.candidates(keys[lvl], b, JOBS_PER_BATCH)]
+                G, J = self.G[lvl], len(cand)
+                h = self.h_par[lvl].numpy()
+                h[G:G + J] = [b for b, _ in cand]
+                h[G + self.J:G + self.J + J * _abi.MAX_SURF] = np.stack([row for _, row in cand]).astype(np.int32).reshape(-1)
+                nl["cand"][lvl], nl["ver"][lvl] = cand, ver
+                first = np.full(S, -1, dtype=np.int32)
+                for j in range(J - 1, -1, -1):
+                    first[cand[j][0]] = j
+                nl["first"][lvl] = first                  # the job that carries each batch's predicted row
+                setattr(lv, "J1" if lvl == 0 else "J2", J)
+        return nl
+
     def edge_buffers(self, dev, S, L, N, per, ks):
         """buffers of the edge-exact level 3 (allocated at the first use, re-allocated when ks changes): the stack's uniforms (the fast
         kernel samples the pupil itself), the S lens states and normalised field points, the deferred-ray lists and raw histograms"""
@@ -591,6 +648,8 @@ class _Stage:
                 "h_back": torch.zeros(B + 1, dtype=i32, pin_memory=True),
                 "uploaded": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False,
             }
+            for name in ("uploaded", "done"):
+                e[name].record()                             # creates the HIP events: the native driver records them by handle
         return e
 
     @staticmethod
@@ -783,7 +842,30 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                 _abi.call("aadff_psf_points_edge", _ptr_at(eb["d_in"], nst), S, N, L, _abi.ptr(tab_dev), C.c_void_p(tab_dev.data_ptr() + t_green * n_surf * surf_bytes),
                           lens._lens_const(), states_ptr, _ptr_at(du, o_main_w), spp, per, per_l, _ptr_at(du, o_main_w + 2 * spp), GEO_SPP, per, per_l, ks,
                           EDGE_DELTA_MM, _abi.ptr(eb["raw"]), _abi.ptr(centre), slope_ptr, _ptr_at(cnt, 0), _abi.ptr(eb["list"]), EDGE_CAP, _ptr_at(cnt, B), sp)
+        def edge_struct():
+            """aadff_edge_stack_t of this stage's buffers (csrc/stack_host.cpp), built once per buffer set"""
+            es = eb.get("es")
+            if es is None:
+                es = eb["es"] = _abi.EdgeStack()
+                es.S, es.L, es.N, es.spp, es.ks, es.n_surf, es.n_tables, es.t_green, es.cap = S, L, N, spp, ks, n_surf, len(wv), t_green, EDGE_CAP
+                es.per, es.per_l, es.o_main, es.n_pm = per, per_l, o_main_w, st.n_pm
+                es.delta, es.pixel_size, es.lc = EDGE_DELTA_MM, float(lens.pixel_size), lens._lens_const()
+                es.tables_dev = tab_dev.data_ptr()
+                es.h_u, es.d_u, es.h_focus, es.d_focus = eb["h_u"].data_ptr(), du.data_ptr(), eb["h_focus"].data_ptr(), eb["d_focus"].data_ptr()
+                es.d_pts, es.states_prov = eb["d_in"].data_ptr() + 4 * nst, eb["states_prov"].data_ptr()
+                es.raw, es.slope, es.count, es.list, es.h_back = eb["raw"].data_ptr(), eb["slope"].data_ptr(), cnt.data_ptr(), eb["list"].data_ptr(), eb["h_back"].data_ptr()
+                es.h_par3, es.d_par3, es.pset, es.bt_main = st.h_par[2].data_ptr(), st.d_par[2].data_ptr(), st.pset.data_ptr(), st.bt_main.data_ptr()
+                es.h_pupil_main, es.d_pupil_main = hp.data_ptr() + 4 * st.n_pf, st.d_pupil.data_ptr() + 4 * st.n_pf
+                eb["es_keep"] = (tab_dev, hp)                    # what the struct points into beyond eb / st
+            return es
+
         def provisional_pass():
+            if native:
+                rc = lib.aadff_edge_provisional(C.byref(edge_struct()), C.c_void_p(nl["focus"].ctypes.data), _abi.ptr(centre), sp)
+                if rc != 0:
+                    raise RuntimeError("aadff_edge_provisional failed: " + lib.aadff_last_error().decode(errors="replace"))
+                mark("provisional pass queued")
+                return
             # ---- provisional pass (edge stacks): the PSF kernel needs lens states, and the exact ones come out of two host round trips
             # (levels 1 and 2 below, ~1 ms of latency with the GPU idle).  The interior rays do not care about a few ulps of d_sensor /
             # hfov - only the border decisions do, and those are taken by the re-trace in the exact world - so the fast refocus kernel
@@ -822,7 +904,65 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
             hs0 = lens._state_sync()
             d_sensor, hfov, foclen, fnum = [float(hs0.d_sensor)] * S, [float(hs0.hfov)] * S, [float(hs0.foclen)] * S, [float(hs0.fnum)] * S
         got = None
-        if fused and phase != "psf":
+        # ---- levels 1 and 2 through the native host driver (csrc/stack_host.cpp): what the Python below does between two waits, as one
+        # call each; any status != 0 (a batch no candidate row confirms, a NaN residual) falls through to the Python form of that level
+        native = fused and phase == "all" and vec is not None and _HostNative.on
+        l1_done = l2_done = prov_done = False
+        if native:
+            nl = st.native_levels(lens, counts, keys, curved, tab_dev, len(wv), n_surf, S)
+            lv, lib = nl["lv"], _abi.load_library()
+            nl["focus"][:] = focus
+            if prov and os.environ.get("AADFF_EDGE_PROV_FIRST", "1") != "0":
+                # the provisional pass needs nothing but the draws: queued FIRST, the 0.36 ms of fast refocus + PSF kernel start while this
+                # thread is still in MKL for the focus rays' aperture points (level 1 then runs beside them on its high-priority stream)
+                provisional_pass()
+                prov_done = True
+            R2_first = float(torch.ones((), dtype=f32) * s0.r ** 2)
+            prev = vec[4](1) if vec[4] is not None else None                      # MKL: one thread for this thread's calls (see _pupil_rows)
+            try:
+                rc = lib.aadff_levels_focus_submit(C.byref(lv), C.c_void_p(u.data_ptr()), C.c_void_p(st.off_focus.ctypes.data), float(np.float32(np.pi)), R2_first,
+                                                   float(np.float32(s0.d.item())), C.c_void_p(nl["focus"].ctypes.data), vec[0], vec[1], vec[2], vec[3], sp12,
+                                                   C.c_void_p(nl["events"][0].cuda_event))
+            finally:
+                if prev is not None:
+                    vec[4](prev)
+            if rc != 0:
+                raise RuntimeError("aadff_levels_focus_submit failed: " + lib.aadff_last_error().decode(errors="replace"))
+            mark("level 1 rays")
+            if prov and not prov_done:
+                provisional_pass()
+                prov_done = True
+            yield nl["events"][0]
+            if os.environ.get("AADFF_NATIVE_DEBUG_SYNC") == "1":
+                torch.cuda.synchronize()
+            elif os.environ.get("AADFF_NATIVE_DEBUG_SYNC") == "check":
+                snap = st.result(0).copy()
+                q = nl["events"][0].query()
+                torch.cuda.synchronize()
+                if not np.array_equal(snap, st.result(0)):
+                    print("PREMATURE: level-1 results changed after the event had been waited for; query() said", q, "differing words", int((snap != st.result(0)).sum()), flush=True)
+            counts.stats["fused"] += 1
+            status = lib.aadff_levels_focus_finish(C.byref(lv), C.c_void_p(nl["chosen"].ctypes.data), C.c_void_p(nl["dsens"].ctypes.data), C.c_void_p(nl["scratch"].ctypes.data))
+            if status == 0:
+                d_sensor = [float(v) for v in nl["dsens"]]
+                if nl["checked"] < _HostFast.CHECKS:                               # the driver's mean against numpy's own, on its first uses
+                    nl["checked"] += 1
+                    J1, r1 = lv.J1, st.result(0)
+                    rows_v = np.stack([r1[j * GEO_SPP:(j + 1) * GEO_SPP].view(np.float32) for j in nl["chosen"]])
+                    rows_w = np.stack([r1[(J1 + j) * GEO_SPP:(J1 + j + 1) * GEO_SPP].view(np.float32) for j in nl["chosen"]])
+                    want = _d_sensor_loop(rows_v, rows_w > 0)
+                    if not all((a == b) or (a != a and b != b) for a, b in zip(d_sensor, want)):
+                        _HostNative.switch_off("np.mean of the focus distances")
+                        d_sensor = want
+                for z in d_sensor:
+                    assert z > 0, "sensor position is negative."
+                if not np.array_equal(nl["chosen"], nl["first"][0]):                # a batch took an alternative row: it becomes the prediction
+                    counts.learn(keys[0], np.stack([nl["cand"][0][j][1] for j in nl["chosen"]]))
+                l1_done = True
+                counts.stats["native"] = counts.stats.get("native", 0) + 1
+            else:
+                counts.stats["native_fallbacks"] = counts.stats.get("native_fallbacks", 0) + 1
+        if fused and phase != "psf" and not l1_done:
             # every pupil point of the stack comes from the reference's host calls; the focus ones ride in front of level 1
             if vec is not None:
                 _pupil_rows(vec, u, st.off_focus, st.off_focus + GEO_SPP, GEO_SPP, s0.r, s0.d.item(), hp[:st.n_pf])
@@ -843,22 +983,43 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                           _ptr_at(res, 2 * J * GEO_SPP), 1, 1, _ptr_at(res, 0), _ptr_at(res, J * GEO_SPP), _ptr_at(par, G), sp12)
 
             got = yield from _speculate_small(counts, keys[0], st, 0, S, GEO_SPP, curved, fwd_order, launch1, s12,
-                                              after_first_submit=provisional_pass if prov else None)
+                                              after_first_submit=provisional_pass if prov and not prov_done else None)
             if got is not None:
                 fd_all, alive, w_focus = got[0], got[1] > 0, got[1]
         bt_green = st.bt_green if st is not None else torch.full((B,), t_green, dtype=torch.int32, device=dev)
-        if phase != "psf" and (not fused or got is None):
+        if phase != "psf" and (not fused or got is None) and not l1_done:
             if fused:
                 counts.stats["per_surface_replays"] += 1
             fd_all, alive, cnt = _level1_batched(lens, uf, focus, S, tabs, len(wv), n_surf, bt_green[:S], dev)
             w_focus = None
             counts.learn(keys[0], cnt)
         mark("level 1 back on the host")
-        if phase != "psf":
+        if phase != "psf" and not l1_done:
             d_sensor = _d_sensor_of(fd_all, alive, w_focus)
         mark("d_sensor")
+        if native and l1_done:
+            # ---- level 2, native: sensor corners into the block, launch, wait, the confirmed jobs' tangents back
+            dsa = np.asarray(d_sensor, dtype=np.float32)
+            backward = not bool(nl["o2z"] - torch.tensor(d_sensor[0], dtype=f32) > 0)
+            rc = lib.aadff_levels_fov_submit(C.byref(lv), C.c_void_p(dsa.ctypes.data), float(np.float32(lens.r_last)), int(not backward), sp12,
+                                             C.c_void_p(nl["events"][1].cuda_event))
+            if rc != 0:
+                raise RuntimeError("aadff_levels_fov_submit failed: " + lib.aadff_last_error().decode(errors="replace"))
+            mark("level 2 rays")
+            yield nl["events"][1]
+            if os.environ.get("AADFF_NATIVE_DEBUG_SYNC") == "1":
+                torch.cuda.synchronize()
+            counts.stats["fused"] += 1
+            status = lib.aadff_levels_fov_finish(C.byref(lv), C.c_void_p(nl["chosen"].ctypes.data), C.c_void_p(nl["tan"].ctypes.data), C.c_void_p(nl["ra"].ctypes.data))
+            if status == 0:
+                tan_fov, rra = torch.from_numpy(nl["tan"]), torch.from_numpy(nl["ra"])
+                if not np.array_equal(nl["chosen"], nl["first"][1]):
+                    counts.learn(keys[1], np.stack([nl["cand"][1][j][1] for j in nl["chosen"]]))
+                l2_done = True
+            else:
+                counts.stats["native_fallbacks"] = counts.stats.get("native_fallbacks", 0) + 1
         # ---- level 2: calc_fov (deeplens/optics.py:1187-1217) - S batches of 100 rays from the sensor corner, backward
-        if fused and phase != "psf":
+        if fused and phase != "psf" and not l2_done:
             o1, o2 = _fov_geometry(lens, d_sensor)
             M = o2.shape[0]
             backward = not bool(o2[0, 2] - o1[0, 2] > 0)
@@ -875,9 +1036,9 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
             got = yield from _speculate_small(counts, keys[1], st, 1, S, M, curved, bwd_order if backward else fwd_order, launch2, s12)
             if got is not None:
                 tan_fov, rra = torch.from_numpy(got[0]), torch.from_numpy(got[1])
-        else:
+        elif not l2_done:
             mark("level 2 rays")
-        if phase != "psf" and (not fused or got is None):
+        if phase != "psf" and (not fused or got is None) and not l2_done:
             if fused:
                 counts.stats["per_surface_replays"] += 1
             tan_fov, rra, cnt = _level2_batched(lens, d_sensor, S, tabs, len(wv), n_surf, bt_green[:S], dev)
@@ -895,7 +1056,9 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                 lens._state_upload()
             return None
         # ---- level 3: psf_map (deeplens/optics.py:888-1026) - per slice and wavelength spp x N main rays and 2048 x N chief rays
-        pobj = _object_points(lens, pts, hfov)                                                     # [S,N,3]
+        edge_native = bool(edge and native and prov and prov_done and l1_done and l2_done)
+        # [S,N,3] (the native edge driver computes them itself; the Python form is then only its check on the first stacks)
+        pobj = _object_points(lens, pts, hfov) if not edge_native or eb.get("pobj_checked", 0) < _HostFast.CHECKS else None
         edge_done = False
         if edge:
             # ---- level 3, edge-exact: fast kernel (already running on provisional states, or launched here on the exact ones) + strict
@@ -903,13 +1066,35 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
             pred3 = counts.rows[keys[2]]
             h = st.h_par[2]
             hn = h.numpy()
-            hn[:B].view(np.float32)[:] = np.repeat(np.asarray(d_sensor, dtype=np.float32), L)
-            h[B:B + S * N * 3].view(f32).view(S, N, 3).copy_(pobj)
             if eb.get("pred_ref") is not pred3:                 # the table's rows are replaced, never edited: same object = same counts
                 hn[B + S * N * 3:].reshape(B, 2, MS)[:] = pred3
                 eb["pred_ref"] = pred3
             par = st.d_par[2]
-            if prov:
+            if edge_native:
+                # object points, uploads, re-trace, normalisation, counts back: one call (csrc/stack_host.cpp: aadff_edge_finish)
+                pupils_ready.result()
+                pn = eb.get("pts_np")
+                if pn is None or eb.get("pts_np_key") != (float(depth_plane_mm), grid):
+                    pn = eb["pts_np"] = np.ascontiguousarray(pts.numpy(), dtype=np.float32)
+                    eb["pts_np_key"] = (float(depth_plane_mm), grid)
+                hf64, ds32 = np.asarray(hfov, dtype=np.float64), np.asarray(d_sensor, dtype=np.float32)
+                rc = lib.aadff_edge_finish(C.byref(edge_struct()), C.c_void_p(pn.ctypes.data), C.c_void_p(hf64.ctypes.data), C.c_void_p(ds32.ctypes.data),
+                                           float(np.float32(lens.r_last)), float(np.float32(lens.sensor_size[1])), float(np.float32(lens.sensor_size[0])),
+                                           _abi.ptr(centre), _abi.ptr(maps), sp, C.c_void_p(eb["uploaded"].cuda_event), C.c_void_p(eb["done"].cuda_event))
+                if rc != 0:
+                    raise RuntimeError("aadff_edge_finish failed: " + lib.aadff_last_error().decode(errors="replace"))
+                eb["busy"] = True
+                if pobj is not None:                                               # the driver's object points against the reference's tensor operations
+                    eb["pobj_checked"] = eb.get("pobj_checked", 0) + 1
+                    if not torch.equal(h[B:B + S * N * 3].view(f32).view(S, N, 3).view(torch.int32), pobj.view(torch.int32)):
+                        _HostNative.switch_off("psf_diff's object points")
+                mark("level 3 inputs")
+            else:
+                hn[:B].view(np.float32)[:] = np.repeat(np.asarray(d_sensor, dtype=np.float32), L)
+                h[B:B + S * N * 3].view(f32).view(S, N, 3).copy_(pobj)
+            if edge_native:
+                pass
+            elif prov:
                 eb["h_focus"][S:] = torch.tensor([float(np.tan(v)) for v in hfov], dtype=torch.float64).to(f32)
                 eb["d_focus"][S:].copy_(eb["h_focus"][S:], non_blocking=True)
             else:
@@ -922,21 +1107,22 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                 eb["d_in"][:nst].copy_(hin[:nst], non_blocking=True)
                 du.copy_(eb["h_u"], non_blocking=True)
                 cnt[B:].zero_()
-            pupils_ready.result()
-            par.copy_(h, non_blocking=True)
-            st.d_pupil[st.n_pf:st.n_pf + st.n_pm].copy_(hp[st.n_pf:st.n_pf + st.n_pm], non_blocking=True)
-            eb["uploaded"].record(stream)
-            eb["busy"] = True
-            mark("level 3 inputs")
-            if not prov:
-                launch_edge(_ptr_at(eb["d_in"], 0), None)
-            _abi.call("aadff_strict_edge_retrace", _ptr_at(par, B), N, B, _abi.ptr(st.pset), _abi.ptr(tab_dev), len(wv), n_surf, _abi.ptr(st.bt_main),
-                      _ptr_at(par, 0), _ptr_at(st.d_pupil, st.n_pf), spp, _ptr_at(par, B + S * N * 3), float(lens.pixel_size), ks, _abi.ptr(centre),
-                      _ptr_at(cnt, 0), _abi.ptr(eb["list"]), EDGE_CAP, _abi.ptr(eb["raw"]), _ptr_at(cnt, B),
-                      _abi.ptr(eb["states_prov"]) if prov else None, _ptr_at(eb["d_focus"], S) if prov else None, _abi.ptr(eb["slope"]) if prov else None, sp)
-            _abi.call("aadff_psf_normalise", _abi.ptr(eb["raw"]), S, N, L, float(lens.pixel_size), ks, 1, _abi.ptr(maps), sp)
-            eb["h_back"].copy_(cnt, non_blocking=True)
-            eb["done"].record(stream)
+            if not edge_native:
+                pupils_ready.result()
+                par.copy_(h, non_blocking=True)
+                st.d_pupil[st.n_pf:st.n_pf + st.n_pm].copy_(hp[st.n_pf:st.n_pf + st.n_pm], non_blocking=True)
+                eb["uploaded"].record(stream)
+                eb["busy"] = True
+                mark("level 3 inputs")
+                if not prov:
+                    launch_edge(_ptr_at(eb["d_in"], 0), None)
+                _abi.call("aadff_strict_edge_retrace", _ptr_at(par, B), N, B, _abi.ptr(st.pset), _abi.ptr(tab_dev), len(wv), n_surf, _abi.ptr(st.bt_main),
+                          _ptr_at(par, 0), _ptr_at(st.d_pupil, st.n_pf), spp, _ptr_at(par, B + S * N * 3), float(lens.pixel_size), ks, _abi.ptr(centre),
+                          _ptr_at(cnt, 0), _abi.ptr(eb["list"]), EDGE_CAP, _abi.ptr(eb["raw"]), _ptr_at(cnt, B),
+                          _abi.ptr(eb["states_prov"]) if prov else None, _ptr_at(eb["d_focus"], S) if prov else None, _abi.ptr(eb["slope"]) if prov else None, sp)
+                _abi.call("aadff_psf_normalise", _abi.ptr(eb["raw"]), S, N, L, float(lens.pixel_size), ks, 1, _abi.ptr(maps), sp)
+                eb["h_back"].copy_(cnt, non_blocking=True)
+                eb["done"].record(stream)
             yield eb["done"]
             back = eb["h_back"].numpy()
             bits = int(back[B])
@@ -949,6 +1135,8 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
             assert not bits & 2, "No sampled rays is valid."
             if bits & 16:                                       # a list overflowed (a caustic along the window edge): the strict psf_map decides every ray
                 counts.stats["edge_overflows"] = counts.stats.get("edge_overflows", 0) + 1
+                if pobj is None:
+                    pobj = _object_points(lens, pts, hfov)
                 if vec is not None:
                     _pupil_rows(vec, u, st.off_chief, st.off_chief + GEO_SPP, GEO_SPP, enp_rr * 0.5, enp_z, hp[st.n_pf + st.n_pm:])
                 else:
@@ -1007,10 +1195,12 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                 rnd += 1
                 J = len(bad)
                 rows = fix[bad] if rnd == 1 else rows_next
+                base = (st.replay_turn % st.replay_slots) * (B + B * 2 * MS)
+                st.replay_turn += 1
                 hr = st.h_par[3].numpy()
-                hr[:J] = bad
-                hr[B:B + J * 2 * MS] = rows.reshape(-1)
-                yield st.submit(3, B + J * 2 * MS, J * 4 * MS + J, lambda par, res: launch3(J, _ptr_at(par, 0), _ptr_at(par, B), res, sp12), s12)
+                hr[base:base + J] = bad
+                hr[base + B:base + B + J * 2 * MS] = rows.reshape(-1)
+                yield st.submit(3, base + B + J * 2 * MS, J * 4 * MS + J, lambda par, res: launch3(J, _ptr_at(par, base), _ptr_at(par, base + B), res, sp12), s12)
                 r = st.result(3)
                 counts.stats["fused_replays"] += 1
                 jb = r[:J * 4 * MS].view(np.uint32).reshape(J, 2, 2, MS)

@@ -39,6 +39,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Coherent read of a small PER-LAUNCH parameter (a block the host re-uploads to the SAME device address before every launch: sensor
+// planes, object points, count rows, job lists, lens states).  A plain load of such a word - the compiler makes it a scalar load when
+// the address is wave-uniform, and always for `address_space(4)` pointers - was measured to return the PREVIOUS launch's value about
+// once in 3 000 stacks when kernels of another HIP stream were running (round 6: tools/concurrency_probe.py; never on a quiet GPU):
+// a strict / edge slice then came out 1e-5 ... 2e-4 off, silently.  An agent-scope atomic load goes to the coherence point.
+// fresh_uniform(): the same for a wave-uniform address, result in a scalar register.
+template <typename T>
+__device__ __forceinline__ T fresh(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int fresh_uniform(const int* p) { return __builtin_amdgcn_readfirstlane(fresh(p)); }
+__device__ __forceinline__ unsigned fresh_uniform(const unsigned* p) { return (unsigned)__builtin_amdgcn_readfirstlane((int)fresh(p)); }
+__device__ __forceinline__ float fresh_uniform(const float* p) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fresh(p))));
+}
+
 // AdamW step scalars under the cosine schedule (torch.optim.AdamW + CosineAnnealingLR(T_max, eta_min 0) of
 // deeplens/psfnet.py:85-90), computed ONCE per step by one thread (float64 pow / cos), then the step counter advances:
 // scal = {lr / bias_correction1, sqrt(bias_correction2), 1 - lr * weight_decay, lr}.

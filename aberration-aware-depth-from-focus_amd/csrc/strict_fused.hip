@@ -24,14 +24,14 @@ namespace aadff {
 namespace strict {
 
 typedef const __attribute__((address_space(4))) aadff_surface_t* csurf_t;      // wave-uniform reads -> scalar loads
-typedef const __attribute__((address_space(4))) int* cpred_t;
+// (the predicted counts are a per-launch block: kernels copy their row into LDS with coherent loads - common.h: fresh - and hand that in)
 
 __device__ __forceinline__ Surf load_surf(csurf_t h, int forward) { return make_surf_from(h, forward); }
 
 // Two rays (the halves of a lane's float2 values, csrc/strict_math2.h) through surfaces [first, last) in travel order with the
 // predicted counts pred[surface] (1..10); any-bits / NaN-bits of curved surface i are ORed into sink(i, bits) as (nan << 16 | any).
 template <typename Sink>
-__device__ __forceinline__ void trace_ray_fused2(csurf_t tab, int first, int last, int forward, cpred_t pred, R32& o, R32& d, f2& ra, Sink sink) {
+__device__ __forceinline__ void trace_ray_fused2(csurf_t tab, int first, int last, int forward, const int* pred, R32& o, R32& d, f2& ra, Sink sink) {
     const int nsteps = last - first;
     for (int k = 0; k < nsteps; ++k) {
         const int i = forward ? first + k : last - 1 - k;
@@ -75,6 +75,8 @@ __device__ __forceinline__ void flush_bits(const unsigned* lds_w, unsigned* g_an
 }
 
 struct __attribute__((packed, aligned(4))) f3p { float x, y, z; };
+// a pupil / object point out of a block the host re-uploads to the same address before every launch: coherent loads (common.h: fresh)
+__device__ __forceinline__ f3p fresh3(const float* p) { return (f3p){fresh(p), fresh(p + 1), fresh(p + 2)}; }
 
 // ---- flat form: B batches of n rays, two rays per thread (refocus and field-of-view levels; any caller-built batch) --------------
 // bits: [B][2][AADFF_MAX_SURF] (any, nan), zeroed by the caller.
@@ -86,9 +88,13 @@ __global__ __launch_bounds__(256) void fused_flat_kernel(float* o_io, float* d_i
                                                          int origin_at_pupil, int out_mode, float* __restrict__ out0, float* __restrict__ out1,
                                                          const int* __restrict__ pupil_set) {
     __shared__ unsigned w[AADFF_MAX_SURF];
+    __shared__ int s_pred[AADFF_MAX_SURF];
     const int b = blockIdx.y;
     const int i0 = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
-    for (int k = threadIdx.x; k < AADFF_MAX_SURF; k += blockDim.x) w[k] = 0u;
+    for (int k = threadIdx.x; k < AADFF_MAX_SURF; k += blockDim.x) {
+        w[k] = 0u;
+        s_pred[k] = fresh(pred + (size_t)b * AADFF_MAX_SURF + k);      // per-launch parameters through coherent loads (common.h: fresh)
+    }
     __syncthreads();
     if (i0 < n) {
         const int i1 = i0 + 1 < n ? i0 + 1 : i0;        // a lone last ray is traced in both halves (same bits), stored once
@@ -97,10 +103,11 @@ __global__ __launch_bounds__(256) void fused_flat_kernel(float* o_io, float* d_i
         f2 ra;
         if constexpr (FROM_POINTS) {
             const int sa = i0 / N, pa = i0 - sa * N, sb = i1 / N, pb = i1 - sb * N;
-            const float* prow = pupil + (size_t)(pupil_set ? pupil_set[b] : b) * (n / N) * 3;
-            const float* qrow = points + (size_t)point_set[b] * N * 3;
-            const f3p poa = *reinterpret_cast<const f3p*>(qrow + (size_t)pa * 3), pob = *reinterpret_cast<const f3p*>(qrow + (size_t)pb * 3);
-            const f3p ppa = *reinterpret_cast<const f3p*>(prow + (size_t)sa * 3), ppb = *reinterpret_cast<const f3p*>(prow + (size_t)sb * 3);
+            const float* prow = pupil + (size_t)(pupil_set ? fresh_uniform(pupil_set + b) : b) * (n / N) * 3;
+            const float* qrow = points + (size_t)fresh_uniform(point_set + b) * N * 3;
+            const float *qa = qrow + (size_t)pa * 3, *qb = qrow + (size_t)pb * 3;
+            const f3p poa = fresh3(qa), pob = fresh3(qb);
+            const f3p ppa = fresh3(prow + (size_t)sa * 3), ppb = fresh3(prow + (size_t)sb * 3);
             o = {(f2){poa.x, pob.x}, (f2){poa.y, pob.y}, (f2){poa.z, pob.z}};
             const R32 pp = {(f2){ppa.x, ppb.x}, (f2){ppa.y, ppb.y}, (f2){ppa.z, ppb.z}};
             d = {pp.x - o.x, pp.y - o.y, pp.z - o.z};
@@ -114,10 +121,10 @@ __global__ __launch_bounds__(256) void fused_flat_kernel(float* o_io, float* d_i
             d = {(f2){da.x, db.x}, (f2){da.y, db.y}, (f2){da.z, db.z}};
             ra = (f2){ra_io[base + i0], ra_io[base + i1]};
         }
-        const csurf_t tab = (csurf_t)(tables + (size_t)batch_table[b] * n_surf);
-        trace_ray_fused2(tab, first, last, forward, (cpred_t)(pred + (size_t)b * AADFF_MAX_SURF), o, d, ra, LdsSink{w});
+        const csurf_t tab = (csurf_t)(tables + (size_t)fresh_uniform(batch_table + b) * n_surf);
+        trace_ray_fused2(tab, first, last, forward, s_pred, o, d, ra, LdsSink{w});
         if (z_sensor) {                                                          // Ray.propagate_to, basics.py:255-273
-            const f2 t = div2(z_sensor[b] - o.z, d.z);
+            const f2 t = div2(fresh_uniform(z_sensor + b) - o.z, d.z);
             o.x = o.x + d.x * t; o.y = o.y + d.y * t; o.z = o.z + d.z * t;
         }
         f2 v0, v1 = ra;
@@ -182,35 +189,40 @@ template <int kPsfThreads>
 __global__ __launch_bounds__(kPsfThreads) void fused_psf_kernel(PsfArgs a) {
     extern __shared__ float lds[];                       // rows [3][spp_c] | block sums [2][stride] | hist [ks*ks]
     __shared__ unsigned w[2][AADFF_MAX_SURF];
+    __shared__ int s_pred[2][AADFF_MAX_SURF];
     __shared__ float red[kPsfThreads / 64], cxy[2];
     __shared__ int s_valid;
-    const int pt = blockIdx.x, job = blockIdx.y, b = a.job_batch ? a.job_batch[job] : job, tid = threadIdx.x;
+    const int pt = blockIdx.x, job = blockIdx.y, b = a.job_batch ? fresh_uniform(a.job_batch + job) : job, tid = threadIdx.x;
     const int spp_c = a.spp_c, N = a.N, ks = a.ks, kk = ks * ks;
     float* rows = lds;
     // block-sum scratch of the cascade: at most 4 * (spp_c / 4 / 16 + 1) <= spp_c / 16 + 4 words per component
     const int bs_stride = spp_c / 16 + 8;
     float* bsum = rows + 3 * (size_t)spp_c;
     float* hist = bsum + 2 * bs_stride;
-    for (int k = tid; k < 2 * AADFF_MAX_SURF; k += kPsfThreads) (&w[0][0])[k] = 0u;
+    for (int k = tid; k < 2 * AADFF_MAX_SURF; k += kPsfThreads) {
+        (&w[0][0])[k] = 0u;
+        (&s_pred[0][0])[k] = fresh(a.pred + (size_t)job * 2 * AADFF_MAX_SURF + k);
+    }
     for (int e = tid; e < kk; e += kPsfThreads) hist[e] = 0.f;
     if (tid == 0) s_valid = 0;
     __syncthreads();
 
-    typedef const __attribute__((address_space(4))) float* cfloat_t;                  // workgroup-uniform: scalar loads
-    const cfloat_t pp0 = (cfloat_t)(a.points + ((size_t)a.point_set[b] * N + pt) * 3);
-    const struct { float x, y, z; } po = {pp0[0], pp0[1], pp0[2]};
-    const float zs = a.z_sensor[b];
+    // per-launch parameters through coherent loads (common.h: fresh): the batch of this job, its object point and sensor plane, and both
+    // count rows into LDS (the trace reads its count per surface from there)
+    const float* pp0 = a.points + ((size_t)fresh_uniform(a.point_set + b) * N + pt) * 3;
+    const struct { float x, y, z; } po = {fresh_uniform(pp0), fresh_uniform(pp0 + 1), fresh_uniform(pp0 + 2)};
+    const float zs = fresh_uniform(a.z_sensor + b);
 
     // ---- phase 1: chief rays
     {
-        const csurf_t tab = (csurf_t)(a.tables + (size_t)a.table_chief[b] * a.n_surf);
-        const cpred_t pred = (cpred_t)(a.pred + ((size_t)job * 2 + 0) * AADFF_MAX_SURF);
+        const csurf_t tab = (csurf_t)(a.tables + (size_t)fresh_uniform(a.table_chief + b) * a.n_surf);
+        const int* pred = s_pred[0];
         bool valid = false;
         // two rays per lane: samples smp and smp + kPsfThreads (a lone last sample is traced twice: same bits, stored once)
         for (int smp = tid; smp < spp_c; smp += 2 * kPsfThreads) {
             const int smp2 = smp + kPsfThreads < spp_c ? smp + kPsfThreads : smp;
-            const f3p pa = *reinterpret_cast<const f3p*>(a.pupil_chief + ((size_t)b * spp_c + smp) * 3);
-            const f3p pb = *reinterpret_cast<const f3p*>(a.pupil_chief + ((size_t)b * spp_c + smp2) * 3);
+            const f3p pa = fresh3(a.pupil_chief + ((size_t)b * spp_c + smp) * 3);
+            const f3p pb = fresh3(a.pupil_chief + ((size_t)b * spp_c + smp2) * 3);
             R32 o = {f2s(po.x), f2s(po.y), f2s(po.z)};
             R32 d = {(f2){pa.x, pb.x} - o.x, (f2){pa.y, pb.y} - o.y, (f2){pa.z, pb.z} - o.z};
             normalize32(d.x, d.y, d.z);
@@ -292,8 +304,8 @@ __global__ __launch_bounds__(kPsfThreads) void fused_psf_kernel(PsfArgs a) {
     __syncthreads();
     // ---- phase 2: main rays -> histogram
     {
-        const csurf_t tab = (csurf_t)(a.tables + (size_t)a.table_main[b] * a.n_surf);
-        const cpred_t pred = (cpred_t)(a.pred + ((size_t)job * 2 + 1) * AADFF_MAX_SURF);
+        const csurf_t tab = (csurf_t)(a.tables + (size_t)fresh_uniform(a.table_main + b) * a.n_surf);
+        const int* pred = s_pred[1];
         const float cx = cxy[0], cy = cxy[1];
         const float km1 = (float)(ks - 1);
         auto splat = [&](float ox, float oy, float ra) {
@@ -313,8 +325,8 @@ __global__ __launch_bounds__(kPsfThreads) void fused_psf_kernel(PsfArgs a) {
         };
         for (int smp = tid; smp < a.spp; smp += 2 * kPsfThreads) {
             const int smp2 = smp + kPsfThreads < a.spp ? smp + kPsfThreads : smp;
-            const f3p pa = *reinterpret_cast<const f3p*>(a.pupil_main + ((size_t)b * a.spp + smp) * 3);
-            const f3p pb = *reinterpret_cast<const f3p*>(a.pupil_main + ((size_t)b * a.spp + smp2) * 3);
+            const f3p pa = fresh3(a.pupil_main + ((size_t)b * a.spp + smp) * 3);
+            const f3p pb = fresh3(a.pupil_main + ((size_t)b * a.spp + smp2) * 3);
             R32 o = {f2s(po.x), f2s(po.y), f2s(po.z)};
             R32 d = {(f2){pa.x, pb.x} - o.x, (f2){pa.y, pb.y} - o.y, (f2){pa.z, pb.z} - o.z};
             normalize32(d.x, d.y, d.z);
@@ -393,34 +405,40 @@ struct NullSink {
 };
 
 __global__ __launch_bounds__(256) void edge_retrace_kernel(EdgeRetraceArgs a) {
+    __shared__ int s_pred[AADFF_MAX_SURF];
     const int b = blockIdx.y;
-    const unsigned have = a.count[b];
+    const unsigned have = fresh_uniform(a.count + b);
     if (have > (unsigned)a.cap && blockIdx.x == 0 && threadIdx.x == 0 && a.flags) atomicOr(a.flags, 16);
     const int cnt = (int)(have < (unsigned)a.cap ? have : (unsigned)a.cap);
+    if (2 * (int)(blockIdx.x * blockDim.x) >= cnt) return;                       // the whole workgroup: nothing listed for it
+    for (int k = threadIdx.x; k < AADFF_MAX_SURF; k += blockDim.x)                // per-launch parameters through coherent loads (common.h: fresh)
+        s_pred[k] = fresh(a.pred + ((size_t)b * 2 + 1) * AADFF_MAX_SURF + k);
+    __syncthreads();
     const int i0 = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
     if (i0 >= cnt) return;
     const int i1 = i0 + 1 < cnt ? i0 + 1 : i0;          // a lone last ray is traced in both halves, splatted once
     const unsigned e0 = a.list[(size_t)b * a.cap + i0], e1 = a.list[(size_t)b * a.cap + i1];
     const int pt0 = (int)(e0 >> 16), pt1 = (int)(e1 >> 16), s0 = (int)(e0 & 0xffffu), s1 = (int)(e1 & 0xffffu);
-    const float* prow = a.points + (size_t)a.point_set[b] * a.N * 3;
-    const f3p oa = *reinterpret_cast<const f3p*>(prow + (size_t)pt0 * 3), ob = *reinterpret_cast<const f3p*>(prow + (size_t)pt1 * 3);
-    const f3p pa = *reinterpret_cast<const f3p*>(a.pupil_main + ((size_t)b * a.spp + s0) * 3);
-    const f3p pb = *reinterpret_cast<const f3p*>(a.pupil_main + ((size_t)b * a.spp + s1) * 3);
+    const int ps = fresh_uniform(a.point_set + b);
+    const float *qa = a.points + ((size_t)ps * a.N + pt0) * 3, *qb = a.points + ((size_t)ps * a.N + pt1) * 3;
+    const f3p oa = fresh3(qa), ob = fresh3(qb);
+    const f3p pa = fresh3(a.pupil_main + ((size_t)b * a.spp + s0) * 3);
+    const f3p pb = fresh3(a.pupil_main + ((size_t)b * a.spp + s1) * 3);
     R32 o = {(f2){oa.x, ob.x}, (f2){oa.y, ob.y}, (f2){oa.z, ob.z}};
     R32 d = {(f2){pa.x, pb.x} - o.x, (f2){pa.y, pb.y} - o.y, (f2){pa.z, pb.z} - o.z};
     normalize32(d.x, d.y, d.z);
     f2 ra = f2s(1.f);
-    const csurf_t tab = (csurf_t)(a.tables + (size_t)a.table_main[b] * a.n_surf);
-    trace_ray_fused2(tab, 0, a.n_surf, 1, (cpred_t)(a.pred + ((size_t)b * 2 + 1) * AADFF_MAX_SURF), o, d, ra, NullSink{});
-    const f2 t = div2(a.z_sensor[b] - o.z, d.z);
+    const csurf_t tab = (csurf_t)(a.tables + (size_t)fresh_uniform(a.table_main + b) * a.n_surf);
+    trace_ray_fused2(tab, 0, a.n_surf, 1, s_pred, o, d, ra, NullSink{});
+    const float zs = fresh_uniform(a.z_sensor + b);
+    const f2 t = div2(zs - o.z, d.z);
     o.x = o.x + d.x * t; o.y = o.y + d.y * t;
     const int ks = a.ks, kk = ks * ks;
     const float km1 = (float)(ks - 1);
     auto splat = [&](float ox, float oy, float w, int pt) {
         float cx = a.centre[((size_t)b * a.N + pt) * 2], cy = a.centre[((size_t)b * a.N + pt) * 2 + 1];
         if (a.states_prov) {
-            const int ps = a.point_set[b];
-            const float dd = a.z_sensor[b] - a.states_prov[ps].d_sensor, rt = a.tan_exact[ps] / a.states_prov[ps].tan_hfov;
+            const float dd = zs - fresh_uniform(&a.states_prov[ps].d_sensor), rt = fresh_uniform(a.tan_exact + ps) / fresh_uniform(&a.states_prov[ps].tan_hfov);
             cx = (cx - a.slope[((size_t)b * a.N + pt) * 2] * dd) * rt;
             cy = (cy - a.slope[((size_t)b * a.N + pt) * 2 + 1] * dd) * rt;
         }

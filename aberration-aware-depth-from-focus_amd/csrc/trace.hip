@@ -958,7 +958,10 @@ __device__ __forceinline__ void psf_points_body(const float* __restrict__ points
             }
         }
     }
-    const aadff_lens_state_t st = states[s];
+    // (coherent loads, common.h: fresh - the per-call API and the strict / edge paths re-upload lens states to a fixed address)
+    struct { float d_sensor, tan_hfov; } st;
+    st.d_sensor = fresh_uniform(&states[s].d_sensor);
+    st.tan_hfov = fresh_uniform(&states[s].tan_hfov);
     // a focus state whose refocus found no valid ray has d_sensor = 0/0: the reference stops there with "sensor position is
     // negative." (deeplens/optics.py:1176); in a pipelined stack the condition travels in the flags word (bit 2)
     if (tid == 0 && !(st.d_sensor > 0.f) && flags) atomicOr(flags, 4);
@@ -984,7 +987,9 @@ __device__ __forceinline__ void psf_points_body(const float* __restrict__ points
             const i2 act = {-1, i1 < spp_chief ? -1 : 0};
             const int j1 = act.y ? i1 : i;
             f2 x2, y2;
-            disc_sample2((f2){ut[i], ut[j1]}, (f2){ur[i], ur[j1]}, lc.enp_r2_shrunk, x2, y2);
+            // (EDGE: the stack's uniforms are a block the host re-uploads to one address: coherent loads, common.h: fresh)
+            disc_sample2(EDGE ? (f2){fresh(ut + i), fresh(ut + j1)} : (f2){ut[i], ut[j1]}, EDGE ? (f2){fresh(ur + i), fresh(ur + j1)} : (f2){ur[i], ur[j1]},
+                         lc.enp_r2_shrunk, x2, y2);
             const Ray2 r = trace_pair_to_sensor(px, py, depth, x2, y2, lc.enp_z, act, surf_chief, lc.n_surf, st.d_sensor, nan_flag);
             const f2 wx = r.ox * r.ra, wy = r.oy * r.ra;
             sx += wx.x + wx.y; sy += wy.x + wy.y; sw += r.ra.x + r.ra.y;
@@ -1055,7 +1060,8 @@ __device__ __forceinline__ void psf_points_body(const float* __restrict__ points
             const i2 act = {-1, i1 < cn ? -1 : 0};
             const int j1 = act.y ? i1 : i;
             f2 x2, y2;
-            disc_sample2((f2){ut[c0 + i], ut[c0 + j1]}, (f2){ur[c0 + i], ur[c0 + j1]}, lc.enp_r2, x2, y2);
+            disc_sample2(EDGE ? (f2){fresh(ut + c0 + i), fresh(ut + c0 + j1)} : (f2){ut[c0 + i], ut[c0 + j1]},
+                         EDGE ? (f2){fresh(ur + c0 + i), fresh(ur + c0 + j1)} : (f2){ur[c0 + i], ur[c0 + j1]}, lc.enp_r2, x2, y2);
             Ray2 r;
             r.ox = f2s(px); r.oy = f2s(py); r.oz = f2s(depth);
             r.dx = x2 - px; r.dy = y2 - py; r.dz = f2s(lc.enp_z - depth);

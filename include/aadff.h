@@ -568,6 +568,68 @@ int aadff_host_mt19937_rows(unsigned char* torch_state_host, long state_bytes, i
  * without a countable value.  values / weights [rows][n], scratch [n], out [rows]; all host memory. */
 int aadff_host_masked_mean_f32(const float* values, const float* weights, long rows, long n, float* scratch, float* out);
 
+/* HOST DRIVER of a strict / edge focal stack (ABI v8, csrc/stack_host.cpp): the per-stack host work between two GPU waits as one call
+ * each.  A strict / edge stack is host-bound (0.6 ms of GPU work, 1.2 ms of Python between its waits); these calls do exactly what
+ * aadff/strict_stack.py does there - same parameter blocks, same launches (the entry points above), same count check, same host
+ * arithmetic - and return a status instead of deciding anything new: 0 = done; 1 = some batch was confirmed by none of its
+ * candidate count rows; 2 = a NaN residual in a run the reference makes (the caller repeats the level the slow way, which corrects the
+ * table / raises the reference's error).  Replaces the host side of Lensgroup.refocus + calc_fov (deeplens/optics.py:1155-1217) for S
+ * slices and of Lensgroup.psf_map (:888-1026) of an edge-parity lens.
+ * aadff_levels_t: blocks in the layout of aadff/strict_stack.py (_Stage): level 1 parameters [S*3 axis points | jobs_max job -> batch |
+ * J*MAX_SURF predicted rows], results [J*2048 crossing z | J*2048 ra | J*2*MAX_SURF any / nan bits]; level 2 parameters [S*3 sensor
+ * corners | M*3 pupil points | job -> batch | rows], results [J*M tan | J*M ra | bits].  The caller has written job -> batch, the rows
+ * and the M pupil points; pinned host blocks (h_*) and their device twins (d_*). */
+typedef struct aadff_levels {
+    int S, n_surf, n_tables, jobs_max, fov_rays, J1, J2, pad;
+    const aadff_surface_t* tables_dev;
+    const int* bt_green;                 /* [>= jobs_max] table index of the focus wavelength */
+    const int* zeros;                    /* [>= jobs_max] */
+    int *h_par1, *d_par1, *h_res1, *d_res1;
+    int *h_par2, *d_par2, *h_res2, *d_res2;
+    float *h_pupil, *d_pupil;            /* [S][2048][3] aperture points of the focus rays */
+    unsigned char curved[AADFF_MAX_SURF];
+} aadff_levels_t;
+/* level 1: aperture points of the first surface from the stack's uniforms (as aadff_host_pupil_points: theta row of slice k at
+ * u_host + off_focus[k], radius row 2048 floats behind), upload, launch, download, event (a hipEvent_t, or NULL) */
+int aadff_levels_focus_submit(const aadff_levels_t* p, const float* u_host, const long* off_focus, float pi_f, float R2, float z_first,
+                              const float* focus, const void* cos_fn, const void* sin_fn, const void* sqrt_fn, int width,
+                              aadff_stream_t stream, void* event_or_null);
+/* after the event: chosen[S] = the confirmed job of every slice, d_sensor[S] = np.mean of its countable crossing distances
+ * (aadff_host_masked_mean_f32; NaN for a slice without one: the reference's "sensor position is negative."); scratch [2048] */
+int aadff_levels_focus_finish(const aadff_levels_t* p, int* chosen, float* d_sensor, float* scratch);
+/* level 2: the sensor corners (r_last, 0, d_sensor[k]) into the block, upload, launch (forward = 0: the usual backward trace), download, event */
+int aadff_levels_fov_submit(const aadff_levels_t* p, const float* d_sensor, float r_last, int forward, aadff_stream_t stream, void* event_or_null);
+/* after the event: chosen[S], tan_fov [S][M] and ra [S][M] of the confirmed jobs (the caller takes torch's own sum and atan of them) */
+int aadff_levels_fov_finish(const aadff_levels_t* p, int* chosen, float* tan_fov, float* ra);
+
+/* the edge-exact psf_map level of a stack (see aadff_psf_points_edge): everything the three launches need, owned by the caller */
+typedef struct aadff_edge_stack {
+    int S, L, N, spp, ks, n_surf, n_tables, t_green, cap, pad;
+    long per, per_l, o_main, n_pm;       /* floats per slice / per wavelength of the uniform block, offset of the main rows, floats of main pupil points */
+    float delta, pixel_size;
+    aadff_lens_const_t lc;
+    const aadff_surface_t* tables_dev;
+    float *h_u, *d_u;                    /* [S*per] the stack's uniforms */
+    float *h_focus, *d_focus;            /* [2 S]: focus distances | float(tan(hfov)) of the exact states */
+    const float* d_pts;                  /* [S][N][3] normalised field points */
+    void* states_prov;                   /* aadff_lens_state_t[S] (device): written by the provisional refocus */
+    float *raw, *slope;
+    unsigned *count, *list;              /* [S*L + 1] (last word: flags), [S*L][cap] */
+    int* h_back;                         /* [S*L + 1] pinned: counts and flags come back here */
+    int *h_par3, *d_par3;                /* [S*L z_sensor | S*N*3 object points | S*L*2*MAX_SURF count rows (written by the caller)] */
+    const int *pset, *bt_main;           /* [S*L] */
+    float *h_pupil_main, *d_pupil_main;  /* [S*L][spp][3] */
+} aadff_edge_stack_t;
+/* provisional pass: uniforms and focus distances up, fast refocus -> states_prov, aadff_psf_points_edge on them (centre [S*L][N][2]) */
+int aadff_edge_provisional(const aadff_edge_stack_t* e, const float* focus, float* centre, aadff_stream_t stream);
+/* after levels 1 and 2: object points of the exact states (psf_diff's float32 arithmetic, deeplens/optics.py:945-950) from pts_norm
+ * [N][3], hfov [S] (float64, as the reference's Python floats) and d_sensor [S]; uploads (event_uploaded: the pinned blocks may be
+ * reused), re-trace with the centres moved into the exact world, normalise into maps [S][L][g ks][g ks], counts / flags to h_back,
+ * event_done */
+int aadff_edge_finish(const aadff_edge_stack_t* e, const float* pts_norm, const double* hfov, const float* d_sensor, float r_last,
+                      float sensor_w, float sensor_h, const float* centre, float* maps, aadff_stream_t stream, void* event_uploaded,
+                      void* event_done);
+
 /* Workgroup size (256 or 1024, default 1024) of an aadff_strict_psf_points launch with fewer than 1024 workgroups, i.e. a re-launch
  * of the few batches whose speculated Newton counts (deeplens/surfaces.py:547) were off: 1024 threads shorten it on an idle GPU,
  * 256 get scheduled beside another stack's full launch (aadff.strict_stack.StrictPipeline).  Process-wide. */

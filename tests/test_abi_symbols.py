@@ -36,16 +36,19 @@ def test_abi_version_and_error_string():
 
 def test_struct_layouts_match_c(tmp_path, repo_root):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "aadff.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "aadff.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    "sizeof(aadff_surface_t),sizeof(aadff_lens_state_t),sizeof(aadff_lens_const_t),"
                    "offsetof(aadff_surface_t,ai),offsetof(aadff_lens_state_t,flags),offsetof(aadff_lens_const_t,first_r2),"
-                   "sizeof(aadff_fit_net),offsetof(aadff_fit_net,off_xt),offsetof(aadff_fit_net,param_bf16));return 0;}\n")
+                   "sizeof(aadff_fit_net),offsetof(aadff_fit_net,off_xt),offsetof(aadff_fit_net,param_bf16),"
+                   "sizeof(aadff_levels_t),offsetof(aadff_levels_t,curved),sizeof(aadff_edge_stack_t),offsetof(aadff_edge_stack_t,lc),"
+                   "offsetof(aadff_edge_stack_t,h_pupil_main));return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(repo_root, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(_abi.Surface), C.sizeof(_abi.LensState), C.sizeof(_abi.LensConst),
             _abi.Surface.ai.offset, _abi.LensState.flags.offset, _abi.LensConst.first_r2.offset,
-            C.sizeof(_abi.FitNet), _abi.FitNet.off_xt.offset, _abi.FitNet.param_bf16.offset]
+            C.sizeof(_abi.FitNet), _abi.FitNet.off_xt.offset, _abi.FitNet.param_bf16.offset,
+            C.sizeof(_abi.Levels), _abi.Levels.curved.offset, C.sizeof(_abi.EdgeStack), _abi.EdgeStack.lc.offset, _abi.EdgeStack.h_pupil_main.offset]
     assert got == want
 
 

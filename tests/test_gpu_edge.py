@@ -271,13 +271,13 @@ def test_edge_lens_per_call_api_and_pipeline(repo_root, margin):
 
 
 def test_edge_list_overflow_falls_back_to_the_strict_psf_map(repo_root, margin, monkeypatch):
-    """A batch with more deferred rays than its list holds (a caustic along the window edge; here: a capacity of 4) is reported by the
+    """A batch with more deferred rays than its list holds (a caustic along the window edge; here: a capacity of 1) is reported by the
     re-trace (flags bit 4) and the stack's psf_map level is redone by the strict kernel: same maps as a strict lens, same lens state."""
     H = W = 256
     S, grid, ks, spp = 3, 5, 11, 1024
     fds = [-600.0, -1500.0, -5000.0]
     img = tt(synth_rgb(H, W, seed=5))[None].to(DEV)
-    monkeypatch.setattr(strict_stack, "EDGE_CAP", 4)
+    monkeypatch.setattr(strict_stack, "EDGE_CAP", 1)
     lens = Lensgroup(lp(repo_root), sensor_res=(H, W), device=DEV, parity="edge")
     strict = Lensgroup(lp(repo_root), sensor_res=(H, W), device=DEV, parity="strict")
     for l in (lens, strict):
@@ -315,3 +315,37 @@ def test_edge_mode_second_lens_and_other_kernel_sizes(repo_root, margin):
     margin("   fast PSF maps vs strict (informative)", f, 1.0)
     margin("50mm_f2.8, ks 21, grid 7: edge stack vs strict stack, image rel-L2", rel(res["edge"][0].cpu().numpy(), res["strict"][0].cpu().numpy()), 1e-4)
     assert e <= 1.2 * f
+
+
+@pytest.mark.parametrize("parity", ["strict", "edge"])
+def test_native_host_driver_equals_the_python_form(repo_root, margin, parity):
+    """csrc/stack_host.cpp (the host work of a strict / edge stack between two GPU waits as one call each) against the Python form it
+    restates (AADFF_HOST_NATIVE=0): d_sensor and hfov of every slice bit for bit, the generator left at the same position, PSF maps to
+    the histogram's float atomics, over stacks on fresh draws (count rows that flip take the fallback inside)."""
+    H = W = 256
+    S, grid, ks, spp = 5, 5, 11, 1024
+    fds = [-600.0, -900.0, -1500.0, -3000.0, -8000.0]
+    img = tt(synth_rgb(H, W, seed=21))[None].to(DEV)
+    res = {}
+    for native in (True, False):
+        strict_stack._HostNative.on = native
+        try:
+            lens = Lensgroup(lp(repo_root), sensor_res=(H, W), device=DEV, parity=parity)
+            torch.manual_seed(31)
+            render_focal_stack_m1(lens, img, -1800.0, fds, grid, ks, spp)              # seed run
+            rows = []
+            for rep in range(6):                                                        # the generator runs on: fresh draws every stack
+                out, maps = render_focal_stack_m1(lens, img, -1800.0, fds, grid, ks, spp, return_maps=True)
+                sc = lens._strict_stack_scalars
+                rows.append((list(sc["d_sensor"]), list(sc["hfov"]), maps.clone(), torch.get_rng_state().clone()))
+            res[native] = (rows, dict(strict_stack.StrictCounts.of(lens).stats))
+        finally:
+            strict_stack._HostNative.on = True
+    assert res[True][1].get("native", 0) >= 4, res[True][1]
+    assert res[False][1].get("native", 0) == 0
+    worst = 0.0
+    for a, b in zip(res[True][0], res[False][0]):
+        assert a[0] == b[0] and a[1] == b[1], "d_sensor / hfov differ between the native driver and the Python form"
+        assert torch.equal(a[3], b[3])
+        worst = max(worst, float((a[2] - b[2]).abs().max() / b[2].max()))
+    margin(f"native host driver vs the Python form, {parity} stacks: PSF maps max |d| / max over 6 stacks (histogram atomics)", worst, 2e-6)

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Are strict / edge stacks the same when kernels of ANOTHER HIP stream are running?  (Round 6: they were not, once in ~3 000 stacks.)
+
+Two experiments, maps compared stack by stack against a quiet sequential render of the same draws (tolerance 2e-6 of the peak: the
+histogram's float atomics):
+  load      sequential strict (or edge) stacks while a side stream runs fast 1024^2 stacks back to back
+  pipeline  StrictPipeline (2 in flight) against the sequential loop, results fetched out of order
+The cause found with this probe: per-launch parameter blocks (sensor planes, object points, count rows) are re-uploaded to the SAME
+device address before every launch and were read with scalar loads (`address_space(4)` pointers / wave-uniform addresses); with a
+second queue active such a load returned the PREVIOUS launch's value now and then - a slice 1e-5 ... 2e-4 off, silently (a stale
+count row passes the any-bits check when it is one SHORTER than the intended one).  Fixed by agent-scope atomic loads
+(csrc/common.h: fresh / fresh_uniform).  Before: load 7 of 21 000 stacks, pipeline 6-7 of 18 000; after: see profiles/r06_*_concurrency_probe.txt.
+Usage: python tools/concurrency_probe.py [iterations] ; MODE=load|pipeline ; PARITY=strict|edge"""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "aberration-aware-depth-from-focus_amd")]
+import numpy as np
+import torch
+
+from aadff import strict_stack
+from aadff.focal_stack import StackPlan, render_focal_stack_m1
+from aadff.strict_stack import StrictPipeline
+from aadff.synth import synth_depth_mm, synth_rgb
+from deeplens.optics import Lensgroup
+
+DEV = "cuda:0"
+H = W = 256
+S, grid, spp, n = 4, 5, 512, 6
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+MODE, PARITY = os.environ.get("MODE", "load"), os.environ.get("PARITY", "strict")
+depth = synth_depth_mm(H, W, seed=5678)
+dbar, fds = -float(depth.mean()), [float(f) for f in -np.linspace(depth.min(), depth.max(), S)]
+img = torch.from_numpy(synth_rgb(H, W, seed=3))[None].to(DEV)
+LP = os.path.join(REPO, "lenses", "rf50mm", "lens.json")
+make = lambda: Lensgroup(LP, sensor_res=(H, W), device=DEV, parity=PARITY)
+TOL = 2e-6 if PARITY == "strict" else 2e-6
+bad = total = 0
+quiet = make()
+render_focal_stack_m1(quiet, img, dbar, fds, grid, 11, spp)
+if MODE == "load":
+    busy = make()
+    render_focal_stack_m1(busy, img, dbar, fds, grid, 11, spp)
+    bg = Lensgroup(LP, sensor_res=(1024, 1024), device=DEV)
+    side = torch.cuda.Stream()
+    img_big = torch.rand(1, 3, 1024, 1024, device=DEV)
+    plan = StackPlan(bg, 10, 1024, 1024)
+
+    def load():
+        with torch.cuda.stream(side):
+            st = torch.get_rng_state()
+            for _ in range(3):
+                render_focal_stack_m1(bg, img_big, -3000.0, -np.linspace(500, 5000, 10), 11, 11, 2048, plan=plan, update_lens=False)
+            torch.set_rng_state(st)
+
+    for it in range(N):
+        torch.manual_seed(100 + it)
+        qa = [render_focal_stack_m1(quiet, img, dbar, fds, grid, 11, spp, return_maps=True)[1].clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        torch.manual_seed(100 + it)
+        qb = []
+        for _ in range(3):
+            load()
+            qb.append(render_focal_stack_m1(busy, img, dbar, fds, grid, 11, spp, return_maps=True)[1].clone())
+        torch.cuda.synchronize()
+        for k in range(3):
+            total += 1
+            d = (qa[k] - qb[k]).abs().amax(dim=(1, 2, 3)) / qa[k].max()
+            if float(d.max()) > TOL:
+                bad += 1
+                print("MISMATCH iteration", it, "stack", k, "maps per slice", ["%.1e" % float(v) for v in d], flush=True)
+else:
+    pipe = StrictPipeline(make, depth=2)
+    for l in pipe.lenses:
+        render_focal_stack_m1(l, img, dbar, fds, grid, 11, spp)
+    for it in range(N):
+        torch.manual_seed(100 + it)
+        want = [render_focal_stack_m1(quiet, img, dbar, fds, grid, 11, spp).clone() for _ in range(n)]
+        torch.manual_seed(100 + it)
+        futs = [pipe.submit(img, dbar, fds, grid, 11, spp) for _ in range(n)]
+        got = [None] * n
+        for k in (1, 0, 2, 5, 4, 3):
+            out, ev = futs[k].result()
+            ev.synchronize()
+            got[k] = out
+        for k in range(n):
+            total += 1
+            d = (got[k] - want[k]).abs().amax(dim=(0, 1, 3, 4)) / want[k].abs().max()
+            if float(d.max()) > (TOL if PARITY == "strict" else 2e-4):      # edge stacks: interior rays on provisional states either way
+                bad += 1
+                print("MISMATCH iteration", it, "stack", k, "image per slice", ["%.1e" % float(v) for v in d], flush=True)
+    pipe.close()
+print(f"concurrency probe, mode {MODE}, parity {PARITY}, native host driver {strict_stack._HostNative.on}: {bad} mismatching stacks of {total}", flush=True)
