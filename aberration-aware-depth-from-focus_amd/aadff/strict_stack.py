@@ -559,9 +559,7 @@ class _Stage:
         # parameter blocks.  levels 1 / 2: [geometry G | job -> batch J | pred J*MS]  (G = S*3 axis points | S*3 sensor corners + M*3 pupil points)
         #                   level 3: [z_sensor B | object points S*N*3 | pred B*2*MS];  its replays: [job -> batch B | pred B*2*MS]
         self.G = [S * 3, S * 3 + M * 3]
-        self.replay_slots = max(1, int(os.environ.get("AADFF_REPLAY_ROTATE", "1")))      # experiment: replays rotate over several parameter regions
-        self.replay_turn = 0
-        sizes = [self.G[0] + J + J * MS, self.G[1] + J + J * MS, B + S * N * 3 + B * 2 * MS, (B + B * 2 * MS) * self.replay_slots]
+        sizes = [self.G[0] + J + J * MS, self.G[1] + J + J * MS, B + S * N * 3 + B * 2 * MS, B + B * 2 * MS]
         self.h_par = [torch.empty(n, dtype=i32, pin_memory=True) for n in sizes]
         self.d_par = [torch.empty(n, dtype=i32, device=dev) for n in sizes]
         # result blocks: levels 1 / 2 [value J*n | ra J*n | bits J*2*MS], level 3 and its replays [bits B*4*MS | any_valid B]
@@ -933,14 +931,6 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                 provisional_pass()
                 prov_done = True
             yield nl["events"][0]
-            if os.environ.get("AADFF_NATIVE_DEBUG_SYNC") == "1":
-                torch.cuda.synchronize()
-            elif os.environ.get("AADFF_NATIVE_DEBUG_SYNC") == "check":
-                snap = st.result(0).copy()
-                q = nl["events"][0].query()
-                torch.cuda.synchronize()
-                if not np.array_equal(snap, st.result(0)):
-                    print("PREMATURE: level-1 results changed after the event had been waited for; query() said", q, "differing words", int((snap != st.result(0)).sum()), flush=True)
             counts.stats["fused"] += 1
             status = lib.aadff_levels_focus_finish(C.byref(lv), C.c_void_p(nl["chosen"].ctypes.data), C.c_void_p(nl["dsens"].ctypes.data), C.c_void_p(nl["scratch"].ctypes.data))
             if status == 0:
@@ -1007,8 +997,6 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                 raise RuntimeError("aadff_levels_fov_submit failed: " + lib.aadff_last_error().decode(errors="replace"))
             mark("level 2 rays")
             yield nl["events"][1]
-            if os.environ.get("AADFF_NATIVE_DEBUG_SYNC") == "1":
-                torch.cuda.synchronize()
             counts.stats["fused"] += 1
             status = lib.aadff_levels_fov_finish(C.byref(lv), C.c_void_p(nl["chosen"].ctypes.data), C.c_void_p(nl["tan"].ctypes.data), C.c_void_p(nl["ra"].ctypes.data))
             if status == 0:
@@ -1195,12 +1183,10 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                 rnd += 1
                 J = len(bad)
                 rows = fix[bad] if rnd == 1 else rows_next
-                base = (st.replay_turn % st.replay_slots) * (B + B * 2 * MS)
-                st.replay_turn += 1
                 hr = st.h_par[3].numpy()
-                hr[base:base + J] = bad
-                hr[base + B:base + B + J * 2 * MS] = rows.reshape(-1)
-                yield st.submit(3, base + B + J * 2 * MS, J * 4 * MS + J, lambda par, res: launch3(J, _ptr_at(par, base), _ptr_at(par, base + B), res, sp12), s12)
+                hr[:J] = bad
+                hr[B:B + J * 2 * MS] = rows.reshape(-1)
+                yield st.submit(3, B + J * 2 * MS, J * 4 * MS + J, lambda par, res: launch3(J, _ptr_at(par, 0), _ptr_at(par, B), res, sp12), s12)
                 r = st.result(3)
                 counts.stats["fused_replays"] += 1
                 jb = r[:J * 4 * MS].view(np.uint32).reshape(J, 2, 2, MS)

@@ -39,14 +39,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// Coherent read of a small PER-LAUNCH parameter (a block the host re-uploads to the SAME device address before every launch: sensor
-// planes, object points, count rows, job lists, lens states).  A plain load of such a word - the compiler makes it a scalar load when
-// the address is wave-uniform, and always for `address_space(4)` pointers - was measured to return the PREVIOUS launch's value about
-// once in 3 000 stacks when kernels of another HIP stream were running (round 6: tools/concurrency_probe.py; never on a quiet GPU):
-// a strict / edge slice then came out 1e-5 ... 2e-4 off, silently.  An agent-scope atomic load goes to the coherence point.
+// Read of a small PER-LAUNCH parameter (a block the host re-uploads to the SAME device address before every launch: sensor planes,
+// object points, count rows, job lists, lens states) as an agent-scope atomic load, i.e. from the coherence point instead of through the
+// scalar cache.  Conservative, not a measured necessity: it was introduced while hunting round 6's run-to-run differences of strict /
+// edge slices beside a busy second stream, whose cause turned out to be an instruction form (tools/check_isa.py); the A/B build with
+// ordinary loads below is just as clean (tools/concurrency_probe.py: 0 of 17 700 stacks either way) and just as fast.
 // fresh_uniform(): the same for a wave-uniform address, result in a scalar register.
 template <typename T>
+#ifdef AADFF_PLAIN_PARAM_LOADS                       // A/B build for tools/concurrency_probe.py: ordinary loads
+__device__ __forceinline__ T fresh(const T* p) { return *p; }
+#else
 __device__ __forceinline__ T fresh(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 __device__ __forceinline__ int fresh_uniform(const int* p) { return __builtin_amdgcn_readfirstlane(fresh(p)); }
 __device__ __forceinline__ unsigned fresh_uniform(const unsigned* p) { return (unsigned)__builtin_amdgcn_readfirstlane((int)fresh(p)); }
 __device__ __forceinline__ float fresh_uniform(const float* p) {

@@ -1,7 +1,7 @@
-// Victim kernels for tools/concurrency_probe.py --classes: each runs ONE class of instruction the strict trace is made of in a long
+// Victim kernels for tools/concurrency_isa_probe.py: each runs ONE class of instruction the strict trace is made of in a long
 // dependent chain on seeded inputs and writes the chain's last value, so that two launches on the same inputs must agree bit for
 // bit.  The probe launches them beside a busy second stream and counts launches whose output differs from a quiet launch.
-// Build: hipcc -O3 --offload-arch=gfx950 -shared -fPIC tools/conc_victims.hip -o tools/conc_victims.so
+// Built by the probe: hipcc -O3 -std=c++17 --offload-arch=gfx950 -shared -fPIC -Iinclude -I<pkg>/csrc tools/conc_victims.hip -o tools/conc_victims.so
 #include <hip/hip_runtime.h>
 #include "strict_math2.h"
 using aadff::strict::div2; using aadff::strict::sqrt2; using aadff::strict::normalize32; using aadff::strict::recip2;
@@ -96,6 +96,45 @@ __global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ i
             f2 z, g;
             sag_dsag2(s0, r2, z, g);
             v = z * 0.1f + g + 1.f;
+        } else if (OP >= 23 && OP <= 27) {                                                         // the first instructions of the polynomial block, exactly
+            // y half as the compiler emits it: cvt_f64 | pk_mov (t = {v.hi, S}) | mul_f64 | pk_mul (t * v.hi); variants take pieces away
+            double dd, qq;
+            f2 t;
+            const float S = 1.0000002f;
+            if (OP == 23) asm volatile("v_cvt_f64_f32 %0, %3\n\tv_pk_mov_b32 %2, %4, %5 op_sel:[1,0]\n\tv_mul_f64 %1, %0, %0\n\tv_pk_mul_f32 %2, %2, %4 op_sel:[0,1]"
+                                       : "=&v"(dd), "=&v"(qq), "=&v"(t) : "v"(v.y), "v"(v), "s"((f2){S, S}));
+            else if (OP == 24) asm volatile("v_cvt_f64_f32 %0, %3\n\tv_pk_mov_b32 %2, %4, %5 op_sel:[1,0]\n\ts_nop 0\n\tv_pk_mul_f32 %2, %2, %4 op_sel:[0,1]\n\tv_mul_f64 %1, %0, %0"
+                                       : "=&v"(dd), "=&v"(qq), "=&v"(t) : "v"(v.y), "v"(v), "s"((f2){S, S}));
+            else if (OP == 25) asm volatile("v_cvt_f64_f32 %0, %3\n\tv_pk_mov_b32 %2, %4, %5 op_sel:[1,0]\n\tv_mul_f64 %1, %0, %0\n\ts_nop 0\n\tv_pk_mul_f32 %2, %2, %4 op_sel:[0,1]"
+                                       : "=&v"(dd), "=&v"(qq), "=&v"(t) : "v"(v.y), "v"(v), "s"((f2){S, S}));
+            else if (OP == 26) asm volatile("v_cvt_f64_f32 %0, %3\n\tv_pk_mov_b32 %2, %4, %5 op_sel:[1,0]\n\tv_mul_f64 %1, %0, %0\n\ts_nop 4\n\tv_pk_mul_f32 %2, %2, %4 op_sel:[0,1]"
+                                       : "=&v"(dd), "=&v"(qq), "=&v"(t) : "v"(v.y), "v"(v), "s"((f2){S, S}));
+            else asm volatile("v_pk_mov_b32 %2, %4, %5 op_sel:[1,0]\n\ts_nop 0\n\tv_pk_mul_f32 %2, %2, %4 op_sel:[0,1]\n\tv_cvt_f64_f32 %0, %3\n\tv_mul_f64 %1, %0, %0"
+                                       : "=&v"(dd), "=&v"(qq), "=&v"(t) : "v"(v.y), "v"(v), "s"((f2){S, S}));
+            v = (f2){t.y * 0.25f + 0.9f, t.x * 0.2f + (float)qq * 0.1f + 0.6f};
+        } else if (OP >= 28 && OP <= 32) {                                                         // ... taken apart further: no float64 at all
+            f2 t;
+            const float S = 1.0000002f;
+            if (OP == 28) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]\n\ts_nop 0\n\tv_pk_mul_f32 %0, %0, %1 op_sel:[0,1]" : "=&v"(t) : "v"(v), "s"((f2){S, S}));
+            else if (OP == 29) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=&v"(t) : "v"(v), "s"((f2){S, S}));          // t = {v.hi, S}
+            else if (OP == 30) { t = v * 1.5f; asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[0,1]" : "+v"(t) : "v"(v)); }          // {t.lo v.hi, t.hi v.hi}
+            else if (OP == 31) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=&v"(t) : "v"(v), "v"((f2){S, S}));          // VGPR second source
+            else { t = v * 1.5f; asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(t) : "v"(v)); }                      // {t.lo v.lo, t.hi v.lo}
+            v = (f2){t.y * 0.25f + 0.9f, t.x * 0.2f + 0.7f};
+        } else if (OP >= 33 && OP <= 42) {                                                         // which packed forms: op_sel on the other source, SGPR sources, fma, add
+            f2 t = v * 1.5f;
+            const f2 S2 = (f2){1.0000002f, 0.9999998f};
+            if (OP == 33) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[1,0]" : "+v"(t) : "v"(v));                                    // {t.hi v.lo, t.hi v.hi}
+            else if (OP == 34) asm volatile("v_pk_mul_f32 %0, %2, %1 op_sel:[1,0]" : "=&v"(t) : "v"(v), "s"(S2));                     // SGPR pair, high half to the low lane
+            else if (OP == 35) asm volatile("v_pk_fma_f32 %0, %0, %1, %1 op_sel:[1,0,0]" : "+v"(t) : "v"(v));
+            else if (OP == 36) asm volatile("v_pk_fma_f32 %0, %2, %1, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=&v"(t) : "v"(v), "s"(S2));   // conv.hip:90 (VALU path)
+            else if (OP == 37) asm volatile("v_pk_fma_f32 %0, %0, %1, %1 op_sel:[0,0,1]" : "+v"(t) : "v"(v));
+            else if (OP == 38) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1]" : "+v"(t) : "v"(v));
+            else if (OP == 39) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(t) : "v"(v));               // swapped halves (csrc/strict.hip)
+            else if (OP == 40) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(t) : "v"(v));
+            else if (OP == 41) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[1,1]" : "+v"(t) : "v"(v));                               // both sources from the high halves
+            else asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[0,0]" : "+v"(t) : "v"(v));                                          // both lanes from the low halves
+            v = (f2){t.y * 0.25f + 0.9f, t.x * 0.2f + 0.7f};
         } else if (OP == 21) {                                                                     // one loose Newton residual
             const R32 o = {v, v * 0.5f, f2s(40.f)}, d = {f2s(0.05f), f2s(-0.03f), f2s(0.998f)};
             f2 ft, dfdt;
@@ -113,7 +152,7 @@ extern "C" int victim_launch(int op, const float* in, float* out, int n, int blo
     hipStream_t s = (hipStream_t)stream;
     switch (op) {
 #define V(K) case K: victim_kernel<K><<<blocks, 256, 0, s>>>(in, out, n, iters, table); break;
-        V(0) V(1) V(2) V(3) V(4) V(5) V(6) V(7) V(8) V(9) V(10) V(11) V(12) V(13) V(14) V(15) V(16) V(17) V(18) V(19) V(20) V(21) V(22)
+        V(0) V(1) V(2) V(3) V(4) V(5) V(6) V(7) V(8) V(9) V(10) V(11) V(12) V(13) V(14) V(15) V(16) V(17) V(18) V(19) V(20) V(21) V(22) V(23) V(24) V(25) V(26) V(27) V(28) V(29) V(30) V(31) V(32) V(33) V(34) V(35) V(36) V(37) V(38) V(39) V(40) V(41) V(42)
 #undef V
         default: return -1;
     }

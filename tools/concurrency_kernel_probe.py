@@ -1,3 +1,12 @@
+#!/usr/bin/env python3
+"""A strict trace kernel on IDENTICAL device inputs, launched again and again beside a load on a second stream: does any ray come out
+different from a quiet launch?  FORMS=fused (aadff_trace_rays_strict_fused, packed float32) , batched (one launch pair per surface,
+scalar); LOADS=none,conv,conv1,agg0..3,matmul (see tools/concurrency_isa_probe.py; conv1 = the lone-slice convolution); LAST=k traces
+surfaces [0, k) only.  Round 6, before the fix (profiles/r06_concurrency_probe_grid.txt): fused beside conv 31/200, conv1 198/200,
+agg0 200/200 - always odd rays (the second ray of a lane), only from the first aspheric surface on; batched 0.  After building the
+strict units with -fno-slp-vectorize: 0 of 200 everywhere.
+
+    python tools/concurrency_kernel_probe.py [launches]"""
 import os, sys, ctypes as C
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "aberration-aware-depth-from-focus_amd"), os.path.join(REPO, "tests")]

@@ -5,11 +5,12 @@ Two experiments, maps compared stack by stack against a quiet sequential render 
 histogram's float atomics):
   load      sequential strict (or edge) stacks while a side stream runs fast 1024^2 stacks back to back
   pipeline  StrictPipeline (2 in flight) against the sequential loop, results fetched out of order
-The cause found with this probe: per-launch parameter blocks (sensor planes, object points, count rows) are re-uploaded to the SAME
-device address before every launch and were read with scalar loads (`address_space(4)` pointers / wave-uniform addresses); with a
-second queue active such a load returned the PREVIOUS launch's value now and then - a slice 1e-5 ... 2e-4 off, silently (a stale
-count row passes the any-bits check when it is one SHORTER than the intended one).  Fixed by agent-scope atomic loads
-(csrc/common.h: fresh / fresh_uniform).  Before: load 7 of 21 000 stacks, pipeline 6-7 of 18 000; after: see profiles/r06_*_concurrency_probe.txt.
+Cause (found with tools/concurrency_kernel_probe.py and tools/concurrency_isa_probe.py): one instruction form of the strict kernels -
+v_pk_mul_f32 / v_pk_add_f32 with op_sel on the second source, which the SLP vectoriser produced for the aspheric terms - returns wrong
+low-lane results while an MFMA kernel (the other stack's convolution) shares the SIMD.  The strict units are built without that
+vectoriser now and tools/check_isa.py refuses the form.  An earlier theory - stale scalar loads of the per-launch parameter blocks - is
+NOT supported: an A/B build with ordinary loads (-DAADFF_PLAIN_PARAM_LOADS) is as clean as the shipped one with agent-scope loads
+(csrc/common.h: fresh), 0 of 17 700 stacks each over the four mode x parity cells (before: load 7 of 21 000, pipeline 6-7 of 18 000).
 Usage: python tools/concurrency_probe.py [iterations] ; MODE=load|pipeline ; PARITY=strict|edge"""
 import os
 import sys
