@@ -43,6 +43,9 @@ AADFF_CONV_BLKW_RB=24 timeout 200 python tools/conv_single_timeline.py --ks 21 -
 PROBE_DEPTHS=3 timeout 300 python tools/strict_pipe_probe.py 30 2>/dev/null | grep -v "^/opt" > gpurun_out/${TAG}_strict_pipe_probe.txt
 PROBE_DEPTHS=2,4 timeout 300 python tools/edge_bench.py 40 2>/dev/null | grep -v "^/opt" > gpurun_out/${TAG}_edge_bench.txt
 AADFF_CALL_ZERO_COPY=0 timeout 300 python tools/dropin_bench.py 20 > gpurun_out/${TAG}_dropin_with_copies.txt 2>/dev/null
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -v "^/opt" > gpurun_out/${TAG}_gputest.txt
+timeout 900 python tools/parity_seeds.py --cases 4 --first 5 > gpurun_out/${TAG}_parity_seeds.json 2> gpurun_out/${TAG}_parity_seeds.err
+for M in load pipeline; do for P in strict edge; do MODE=$M PARITY=$P timeout 300 python tools/concurrency_probe.py 500 2>&1 | tail -1; done; done > gpurun_out/${TAG}_concurrency_probe.txt
 # the raw rocprofv3 directories exceed what gpurun copies back (64 MiB): reduce them HERE (tools/summarise_profiles.py writes the judged
 # summaries into profiles/), ship the summaries in gpurun_out/${TAG}_profiles/ and drop the raw traces
 python3 tools/summarise_profiles.py ${TAG} > gpurun_out/${TAG}_summarise.log 2>&1
