@@ -15,9 +15,9 @@ spec.loader.exec_module(check_isa)
 def test_pattern_matches_the_measured_forms_only():
     bad = ["v_pk_mul_f32 v[66:67], v[66:67], v[42:43] op_sel:[0,1]",
            "v_pk_add_f32 v[12:13], v[12:13], v[12:13] op_sel:[0,1] op_sel_hi:[1,0]",
-           "v_pk_mul_f32 v[28:29], v[28:29], s[66:67] op_sel:[0,1]",
            "v_pk_mul_f32 v[2:3], v[2:3], v[4:5] op_sel:[1,1]"]                      # measured clean, refused all the same: never emitted, one rule
     good = ["v_pk_mul_f32 v[6:7], v[8:9], s[30:31] op_sel_hi:[1,0]",
+            "v_pk_mul_f32 v[28:29], v[28:29], s[66:67] op_sel:[0,1]",               # an odd scalar register broadcast: measured clean
             "v_pk_mul_f32 v[24:25], s[16:17], v[6:7] op_sel:[1,0]",
             "v_pk_fma_f32 v[0:1], s[2:3], v[4:5], v[0:1] op_sel:[1,0,0] op_sel_hi:[1,1,1]",
             "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,1,0]",
@@ -29,7 +29,7 @@ def test_pattern_matches_the_measured_forms_only():
         assert not check_isa.BAD.search(line), line
 
 
-@pytest.mark.parametrize("lib", ["libaadff.so", "libaadff_latestage.so"])
+@pytest.mark.parametrize("lib", ["libaadff.so", "libaadff_latestage.so", "libaadff_literal.so"])
 def test_built_libraries_are_clean(lib):
     path = os.path.join(REPO, "aberration-aware-depth-from-focus_amd", "csrc", lib)
     assert os.path.exists(path), f"{path} is not built (python -c 'import __graft_entry__ as g; g.build()')"

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Build guard: no gfx950 code object of the library may contain a two-operand packed float32 instruction whose LOW lane reads the HIGH
-half of its SECOND source (`v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[x,1]`, with or without op_sel_hi).
+half of its SECOND source when that source is a VGPR pair (`v_pk_mul_f32 / v_pk_add_f32 d, a, v[n:n+1] op_sel:[x,1]`, with or without
+op_sel_hi).
 
 Why: on MI355X that form returns wrong low-lane results now and then while a wave of ANOTHER kernel issues MFMA instructions on the same
 SIMD (our own convolution on a second stream is enough); alone on the chip it is exact.  Measured with tools/concurrency_probe.py
 (profiles/r06_concurrency_probe_grid.txt): v_pk_mul_f32 / v_pk_add_f32 with op_sel:[0,1] (also the swapped form op_sel:[0,1]
 op_sel_hi:[1,0]) differ in every launch beside a bare MFMA chain; op_sel on the first source, op_sel:[1,1], every op_sel_hi-only form,
-every v_pk_fma_f32 form and SGPR sources do not.  The compiler only produces the form when its SLP vectoriser re-packs scalar code that
+every v_pk_fma_f32 form and SGPR sources (also an SGPR pair as the second source with op_sel:[0,1], the compiler's broadcast of an odd
+scalar register) do not.  The compiler only produces the form when its SLP vectoriser re-packs scalar code that
 follows explicit float2 arithmetic (the aspheric polynomial of csrc/strict_math.h after csrc/strict_math2.h's conic part), so the
 strict translation units are built with -fno-slp-vectorize; this check keeps every object honest.
 
@@ -19,7 +21,7 @@ import sys
 import tempfile
 
 LLVM = os.environ.get("AADFF_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
-BAD = re.compile(r"\bv_pk_(mul|add|min|max)_f32\b.*\bop_sel:\[[01],1\]")
+BAD = re.compile(r"\bv_pk_(mul|add|min|max)_f32\s+[^,]+,\s*[^,]+,\s*v\[\d+:\d+\]\s+op_sel:\[[01],1\]")      # second source a VGPR pair
 
 
 def offenders(path):

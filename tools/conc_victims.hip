@@ -121,6 +121,10 @@ __global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ i
             else if (OP == 31) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=&v"(t) : "v"(v), "v"((f2){S, S}));          // VGPR second source
             else { t = v * 1.5f; asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(t) : "v"(v)); }                      // {t.lo v.lo, t.hi v.lo}
             v = (f2){t.y * 0.25f + 0.9f, t.x * 0.2f + 0.7f};
+        } else if (OP == 43) {                                                                     // SGPR pair as the SECOND source, its high half to both lanes
+            f2 t = v * 1.5f;                                                                       // (how the compiler broadcasts an odd scalar register)
+            asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[0,1]" : "+v"(t) : "s"((f2){1.0000002f, 0.9999998f}));
+            v = (f2){t.y * 0.25f + 0.9f, t.x * 0.2f + 0.7f};
         } else if (OP >= 33 && OP <= 42) {                                                         // which packed forms: op_sel on the other source, SGPR sources, fma, add
             f2 t = v * 1.5f;
             const f2 S2 = (f2){1.0000002f, 0.9999998f};
@@ -152,7 +156,7 @@ extern "C" int victim_launch(int op, const float* in, float* out, int n, int blo
     hipStream_t s = (hipStream_t)stream;
     switch (op) {
 #define V(K) case K: victim_kernel<K><<<blocks, 256, 0, s>>>(in, out, n, iters, table); break;
-        V(0) V(1) V(2) V(3) V(4) V(5) V(6) V(7) V(8) V(9) V(10) V(11) V(12) V(13) V(14) V(15) V(16) V(17) V(18) V(19) V(20) V(21) V(22) V(23) V(24) V(25) V(26) V(27) V(28) V(29) V(30) V(31) V(32) V(33) V(34) V(35) V(36) V(37) V(38) V(39) V(40) V(41) V(42)
+        V(0) V(1) V(2) V(3) V(4) V(5) V(6) V(7) V(8) V(9) V(10) V(11) V(12) V(13) V(14) V(15) V(16) V(17) V(18) V(19) V(20) V(21) V(22) V(23) V(24) V(25) V(26) V(27) V(28) V(29) V(30) V(31) V(32) V(33) V(34) V(35) V(36) V(37) V(38) V(39) V(40) V(41) V(42) V(43)
 #undef V
         default: return -1;
     }

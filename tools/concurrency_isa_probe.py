@@ -39,8 +39,8 @@ psf = torch.rand(10, 3, 121, 121, device=dev); psf /= psf.sum()
 out_big = torch.empty(1, 3, 10, 1024, 1024, device=dev)
 agg_out = torch.empty(8192 * 256, device=dev)
 side = torch.cuda.Stream()
-NAMES = ["pk_fma", "pk_mul_add", "fma", "rcp", "sqrt", "ieee_div", "div_fixup", "lds", "s_load", "fresh_load", "f64_pow", "asph_terms", "div2", "sqrt2", "normalize32", "rcp_pair_pk", "rcp_pair_nop_pk", "sag_poly", "dsag_poly", "dsag", "sag_dsag2", "residual2", "sag_dsag2_nopoly", "asm_cvt_pkmov_mulf64_pkmul", "asm_pkmov_nop_pkmul_then_f64", "asm_pkmov_mulf64_nop0_pkmul", "asm_pkmov_mulf64_nop4_pkmul", "asm_pk_first_then_f64", "asm_pkmov_pkmul_nof64", "asm_pkmov_sgpr_only", "asm_pkmul_opsel01_only", "asm_pkmov_vgpr_only", "asm_pkmul_opselhi10_only", "pkmul_opsel10", "pkmul_sgpr_opsel10", "pkfma_opsel100", "pkfma_sgpr_opsel100", "pkfma_opsel001", "pkadd_opsel01", "pkadd_swap", "pkmul_swap", "pkmul_opsel11", "pkmul_opselhi00"]
-ITERS = [4000, 3000, 4000, 1500, 1500, 300, 1500, 1500, 1500, 600, 400, 200, 400, 400, 150, 1500, 1500, 150, 150, 100, 100, 100, 100, 1500, 1500, 1500, 1500, 1500, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000]
+NAMES = ["pk_fma", "pk_mul_add", "fma", "rcp", "sqrt", "ieee_div", "div_fixup", "lds", "s_load", "fresh_load", "f64_pow", "asph_terms", "div2", "sqrt2", "normalize32", "rcp_pair_pk", "rcp_pair_nop_pk", "sag_poly", "dsag_poly", "dsag", "sag_dsag2", "residual2", "sag_dsag2_nopoly", "asm_cvt_pkmov_mulf64_pkmul", "asm_pkmov_nop_pkmul_then_f64", "asm_pkmov_mulf64_nop0_pkmul", "asm_pkmov_mulf64_nop4_pkmul", "asm_pk_first_then_f64", "asm_pkmov_pkmul_nof64", "asm_pkmov_sgpr_only", "asm_pkmul_opsel01_only", "asm_pkmov_vgpr_only", "asm_pkmul_opselhi10_only", "pkmul_opsel10", "pkmul_sgpr_opsel10", "pkfma_opsel100", "pkfma_sgpr_opsel100", "pkfma_opsel001", "pkadd_opsel01", "pkadd_swap", "pkmul_swap", "pkmul_opsel11", "pkmul_opselhi00", "pkmul_sgpr_src1_opsel01"]
+ITERS = [4000, 3000, 4000, 1500, 1500, 300, 1500, 1500, 1500, 600, 400, 200, 400, 400, 150, 1500, 1500, 150, 150, 100, 100, 100, 100, 1500, 1500, 1500, 1500, 1500, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000, 2000]
 NIT = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 def victim(op):
     out = torch.empty(2 * BL * 256, device=dev)
