@@ -25,6 +25,11 @@ for p in (REPO, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# numpy's OpenBLAS comes with a pool of up to 64 pthreads that busy-wait for ~10 ms after every BLAS call (np.linalg.norm of a stack in
+# the parity legs): on a GPU box with a 16-CPU quota that burst, a few ms before a host-bound timed loop, used up the cgroup's 100 ms
+# period and froze the process for 55-85 ms somewhere in the loop (one step of an edge-mode leg at 80 ms instead of 1; found with
+# `host_cpu_quota` / AADFF_BENCH_THREADS=1 below).  One BLAS thread: the norms take 1 s longer in total, nothing spins.
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 import numpy as np
 import torch
 
@@ -32,6 +37,35 @@ H = W = 1024
 S, GRID, KS, SPP = 10, 11, 11, 2048
 HBM_PEAK = 8.0e12                       # B/s, MI355X_MICROARCH.md
 ALG_BYTES_PER_SLICE = 2 * 3 * H * W * 4  # read image once + write output once
+
+
+_THREAD_MARKS = []
+
+
+def _threads_cpu():
+    """{tid: user + system clock ticks} of this process's threads"""
+    out = {}
+    for t in os.listdir("/proc/self/task"):
+        try:
+            f = open(f"/proc/self/task/{t}/stat").read()
+            rest = f[f.rindex(")") + 2:].split()
+            out[int(t)] = int(rest[11]) + int(rest[12])
+        except (OSError, ValueError):
+            pass
+    return out
+
+
+def _thread_mark(label):
+    if os.environ.get("AADFF_BENCH_THREADS") == "1":
+        _THREAD_MARKS.append((label, set(_threads_cpu())))
+
+
+def _cgroup_cpu():
+    """cpu.stat of this process's cgroup (v2), or None"""
+    try:
+        return {k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/cpu.stat"))}
+    except (OSError, ValueError):
+        return None
 
 
 def usable_cpus():
@@ -117,6 +151,7 @@ def main():
                          "m1l: M1-layered (SURVEY.md 8(d)): the depth MAP in 4 layers, one ray-traced PSF map per (slice, layer), per-pixel selection "
                          "fused into the stack convolution")
     args = ap.parse_args()
+    _thread_mark("after the imports")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Self-launch: one child per rank, started BEFORE this process has made any GPU call (it never makes one).
@@ -484,7 +519,9 @@ def main():
             except Exception as e:
                 res["dropin_api"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
+            _thread_mark("before cpu_baseline")
             res["cpu_baseline"], want = cpu_baseline(lens_path, img_h, dbar, fds)
+            _thread_mark("after cpu_baseline")
             n = len(want)
             a = got[:, :n].astype(np.float64)
             b = np.stack([w[0].numpy() for w in want], 1).astype(np.float64)
@@ -550,6 +587,9 @@ def main():
                 stats0 = dict(_ss.StrictCounts.of(ls).stats)
                 gc.collect()
                 gc.freeze()                                      # the bench's long-lived objects out of the collector's way: a full collection
+                cg0 = _cgroup_cpu()
+                _thread_mark(f"before the {parity_name} timed loop")
+                th0 = _threads_cpu() if os.environ.get("AADFF_BENCH_THREADS") == "1" else None
                 t_s = time.perf_counter()                        # over them cost 50-90 ms every ~10 steps of this leg
                 marks_s = []
                 _pr = None
@@ -569,6 +609,17 @@ def main():
                     _pr.disable()
                     pstats.Stats(_pr, stream=sys.stderr).sort_stats("tottime").print_stats(18)
                 t_s = (time.perf_counter() - t_s) / n_strict
+                cg1 = _cgroup_cpu()
+                if th0 is not None:                              # debug: which threads used the CPU during the loop, and since when they exist
+                    th1 = _threads_cpu()
+                    top = sorted(((th1[t] - th0.get(t, 0), t) for t in th1), reverse=True)
+                    born = lambda t: next((lab for lab, tids in _THREAD_MARKS if t in tids), "later")
+                    groups = {}
+                    for dt, t in top:
+                        if dt > 0:
+                            groups.setdefault(born(t), []).append(dt)
+                    print(f"bench threads [{parity_name}]: {len(th1)} threads; CPU ticks (10 ms) during the loop by first sighting:",
+                          {k: (len(v), sum(v), max(v)) for k, v in groups.items()}, file=sys.stderr, flush=True)
                 stats1 = _ss.StrictCounts.of(ls).stats
                 rec = {"rel_l2": float(f"{np.linalg.norm(a2 - b) / np.linalg.norm(b):.3e}"),
                        "rel_l2_per_slice": [float(f"{v:.3e}") for v in per2], "worst_slice": float(f"{max(per2):.3e}"),
@@ -585,7 +636,13 @@ def main():
                                  "ms_per_step_max_at": int(np.argmax(marks_s)), "ms_per_step_second_max": round(float(np.sort(marks_s)[-2]) * 1e3, 3),
                                  "unit": "MP/s", "what": f"render_focal_stack_m1 through the {parity_name} lens, one stack at a time "
                                  "(host call to device idle), fresh draws every step",
-                                 "speculation": {k: stats1[k] - stats0.get(k, 0) for k in stats1}},
+                                 "speculation": {k: stats1[k] - stats0.get(k, 0) for k in stats1},
+                                 "host_cpu_quota": None if cg0 is None or cg1 is None else {
+                                     "throttled_ms": round((cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e3, 1),
+                                     "nr_throttled": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0),
+                                     "cpu_ms_used": round((cg1.get("usage_usec", 0) - cg0.get("usage_usec", 0)) / 1e3, 1),
+                                     "what": "this process group's cgroup cpu.stat over the timed loop: a step that ran into the box's CPU quota "
+                                             "shows up here and in ms_per_step_max, not in the p50"}},
                        "seconds_per_stack": round(t_s, 4), "what": what}
                 _ss.release_buffers(ls)
                 # the same mode with FOUR stacks in flight (StrictPipeline: four lenses / streams software-pipelined on this thread; draws at submission)
