@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AADFF_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libaadff.so")   # AADFF_LIB: A/B builds (tools/)
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_GRID, MAX_KS, MAX_SURF, MAX_AI = 64, 51, 32, 8
 SURF_STOP, SURF_SPHERIC, SURF_ASPHERIC = 0, 1, 2
 
@@ -99,6 +99,7 @@ PROTOTYPES = {
     "aadff_trace_rays_strict_batched": [_P, _P, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "aadff_trace_rays_strict_fused": [_P, _P, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "aadff_strict_psf_points": [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _F, _I, _I, _P, _P, _P, _P, _P],
+    "aadff_strict_psf_points_alt": [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "aadff_selftest_strict_ops": [_P, _P, _I, _I, _P, _P],
     "aadff_strict_centroid": [_P, _P, _I, _I, _I, _P, _P, _P],
     "aadff_trace_points": [_P, _I, _P, _P, _I, _F, _F, _P, _I, _P, _P, _P, _P, _P],

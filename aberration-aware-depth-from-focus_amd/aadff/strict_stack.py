@@ -245,6 +245,26 @@ class StrictCounts:
         return t
 
 
+ALT_JOBS = os.environ.get("AADFF_STRICT_ALT", "1") != "0"       # two-variant psf_map jobs (aadff_strict_psf_points_alt) instead of re-launches
+
+
+def _two_variant_words(seen_chief, curved):
+    """[B, MS] uint16 masks of the chief counts on record (bit n = count n has been the truth) -> [B] int32: surface | n << 8 where
+    exactly ONE curved surface of the batch's chief row has more than one count on record and these are two neighbours n, n + 1;
+    -1 otherwise."""
+    s = np.asarray(seen_chief).astype(np.uint32) * np.asarray(curved, dtype=np.uint32)[None, :]
+    multi = (s & (s - 1)) != 0
+    one = multi.sum(-1) == 1
+    idx = multi.argmax(-1)
+    v = s[np.arange(len(s)), idx]
+    low = v & (~v + np.uint32(1))
+    pair = one & (v == (low | (low << np.uint32(1))))
+    n_lo = np.zeros(len(s), dtype=np.int64)
+    n_lo[pair] = np.log2(low[pair].astype(np.float64)).astype(np.int64)
+    out = np.where(pair & (n_lo >= 1) & (n_lo + 1 <= MAX_ITER), idx | (n_lo << 8), -1).astype(np.int32)
+    return out
+
+
 def _curved(lens):
     c = lens._table_cache.get("strict-curved")
     if c is None:
@@ -557,13 +577,14 @@ class _Stage:
         self.h_pupil = torch.empty(self.n_pf + self.n_pm + self.n_pc, dtype=f32, pin_memory=True)
         self.d_pupil = torch.empty(self.n_pf + self.n_pm + self.n_pc, dtype=f32, device=dev)
         # parameter blocks.  levels 1 / 2: [geometry G | job -> batch J | pred J*MS]  (G = S*3 axis points | S*3 sensor corners + M*3 pupil points)
-        #                   level 3: [z_sensor B | object points S*N*3 | pred B*2*MS];  its replays: [job -> batch B | pred B*2*MS]
+        #                   level 3: [z_sensor B | object points S*N*3 | pred B*2*MS | two-variant word B];  its replays: [job -> batch B | pred B*2*MS]
         self.G = [S * 3, S * 3 + M * 3]
-        sizes = [self.G[0] + J + J * MS, self.G[1] + J + J * MS, B + S * N * 3 + B * 2 * MS, B + B * 2 * MS]
+        sizes = [self.G[0] + J + J * MS, self.G[1] + J + J * MS, B + S * N * 3 + B * 2 * MS + B, B + B * 2 * MS]
         self.h_par = [torch.empty(n, dtype=i32, pin_memory=True) for n in sizes]
         self.d_par = [torch.empty(n, dtype=i32, device=dev) for n in sizes]
-        # result blocks: levels 1 / 2 [value J*n | ra J*n | bits J*2*MS], level 3 and its replays [bits B*4*MS | any_valid B]
-        rs = [2 * J * GEO_SPP + J * 2 * MS, 2 * J * M + J * 2 * MS, B * 4 * MS + B, B * 4 * MS + B]
+        # result blocks: levels 1 / 2 [value J*n | ra J*n | bits J*2*MS], level 3 [bits B*4*MS | any_valid B | second variant: chief bits B*2*MS |
+        # any_valid B], its replays [bits B*4*MS | any_valid B]
+        rs = [2 * J * GEO_SPP + J * 2 * MS, 2 * J * M + J * 2 * MS, B * 4 * MS + B + B * 2 * MS + B, B * 4 * MS + B]
         self.h_res = [torch.empty(n, dtype=i32, pin_memory=True) for n in rs]
         self.d_res = [torch.empty(n, dtype=i32, device=dev) for n in rs]
         self.pset = torch.arange(S, dtype=i32).repeat_interleave(L).to(dev)
@@ -1055,7 +1076,7 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
             h = st.h_par[2]
             hn = h.numpy()
             if eb.get("pred_ref") is not pred3:                 # the table's rows are replaced, never edited: same object = same counts
-                hn[B + S * N * 3:].reshape(B, 2, MS)[:] = pred3
+                hn[B + S * N * 3:B + S * N * 3 + B * 2 * MS].reshape(B, 2, MS)[:] = pred3
                 eb["pred_ref"] = pred3
             par = st.d_par[2]
             if edge_native:
@@ -1140,19 +1161,47 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
             pred3 = counts.rows[keys[2]]
             maps = torch.empty((S, L, grid * ks, grid * ks), dtype=f32, device=dev)
             centre = torch.empty((B, N, 2), dtype=f32, device=dev)
+            # two-variant jobs (aadff_strict_psf_points_alt): a batch whose CHIEF count at exactly one surface has been seen at two
+            # neighbouring values n, n + 1 (and nothing else undecided in its chief row) is rendered under both in this launch
+            # (not inside a StrictPipeline: there the re-launch runs beside the next stack's psf_map launch for free, while the second
+            # variant makes every launch 4.6 % longer - measured 3.63 against 3.97 ms per stack at depth 3)
+            alt = _two_variant_words(counts.seen[keys[2]][:, 0], curved) if ALT_JOBS and getattr(lens, "_strict_l3_chain", None) is None else None
+            if alt is not None and (alt >= 0).any():
+                pred3 = pred3.copy()
+                ab = np.nonzero(alt >= 0)[0]
+                pred3[ab, 0, alt[ab] & 0xff] = (alt[ab] >> 8) + 1
+                ak = ("alt", grid, ks)
+                if not hasattr(st, "_alt_out"):
+                    st._alt_out = {}
+                if ak not in st._alt_out:
+                    st._alt_out[ak] = (torch.empty((B, grid * ks, grid * ks), dtype=f32, device=dev), torch.empty((B, N, 2), dtype=f32, device=dev))
+                maps_alt, centre_alt = st._alt_out[ak]
+                counts.stats["alt_jobs"] = counts.stats.get("alt_jobs", 0) + len(ab)
+            else:
+                alt = None
             h = st.h_par[2]
             h[:B].view(f32).copy_(torch.tensor(d_sensor, dtype=f32).repeat_interleave(L))
             h[B:B + S * N * 3].view(f32).view(S, N, 3).copy_(pobj)
-            h[B + S * N * 3:].view(B, 2, MS).copy_(torch.from_numpy(pred3))
+            h[B + S * N * 3:B + S * N * 3 + B * 2 * MS].view(B, 2, MS).copy_(torch.from_numpy(pred3))
+            if alt is not None:
+                h[B + S * N * 3 + B * 2 * MS:].copy_(torch.from_numpy(alt))
+            n_up3 = h.numel() if alt is not None else h.numel() - B
 
-            def launch3(J, jobs_ptr, pred_ptr, res, on=None):
+            def launch3(J, jobs_ptr, pred_ptr, res, on=None, alt_ptr=None):
                 # re-launches go to the short levels' stream: behind a pipeline's NEXT psf_map launch they would wait 3 ms (the host
                 # has seen the first launch finish, and waits for the re-launch before the convolution is queued: ordered either way)
                 par = st.d_par[2]
-                _abi.call("aadff_strict_psf_points", _ptr_at(par, B), N, J, jobs_ptr, _abi.ptr(st.pset), _abi.ptr(tab_dev), len(wv), n_surf,
-                          _abi.ptr(st.bt_main), _abi.ptr(st.bt_green), _ptr_at(par, 0), _ptr_at(st.d_pupil, st.n_pf), spp,
-                          _ptr_at(st.d_pupil, st.n_pf + st.n_pm), GEO_SPP, pred_ptr, float(lens.pixel_size), ks, grid, _abi.ptr(maps), _abi.ptr(centre),
-                          _ptr_at(res, 0), _ptr_at(res, J * 4 * MS), sp if on is None else on)
+                if alt_ptr is None:
+                    _abi.call("aadff_strict_psf_points", _ptr_at(par, B), N, J, jobs_ptr, _abi.ptr(st.pset), _abi.ptr(tab_dev), len(wv), n_surf,
+                              _abi.ptr(st.bt_main), _abi.ptr(st.bt_green), _ptr_at(par, 0), _ptr_at(st.d_pupil, st.n_pf), spp,
+                              _ptr_at(st.d_pupil, st.n_pf + st.n_pm), GEO_SPP, pred_ptr, float(lens.pixel_size), ks, grid, _abi.ptr(maps), _abi.ptr(centre),
+                              _ptr_at(res, 0), _ptr_at(res, J * 4 * MS), sp if on is None else on)
+                else:
+                    _abi.call("aadff_strict_psf_points_alt", _ptr_at(par, B), N, J, jobs_ptr, _abi.ptr(st.pset), _abi.ptr(tab_dev), len(wv), n_surf,
+                              _abi.ptr(st.bt_main), _abi.ptr(st.bt_green), _ptr_at(par, 0), _ptr_at(st.d_pupil, st.n_pf), spp,
+                              _ptr_at(st.d_pupil, st.n_pf + st.n_pm), GEO_SPP, pred_ptr, float(lens.pixel_size), ks, grid, _abi.ptr(maps), _abi.ptr(centre),
+                              _ptr_at(res, 0), _ptr_at(res, J * 4 * MS), alt_ptr, _abi.ptr(maps_alt), _abi.ptr(centre_alt),
+                              _ptr_at(res, J * 4 * MS + J), _ptr_at(res, J * 4 * MS + J + J * 2 * MS), sp if on is None else on)
 
             pupils_ready.result()
             st.d_pupil[st.n_pf:].copy_(hp[st.n_pf:], non_blocking=True)
@@ -1162,7 +1211,9 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
                 # StrictPipeline: behind the psf_map launch of the stack in front, not beside it - two such launches sharing the chip
                 # finish together, and the host would learn the first one's counts 3 ms later
                 stream.wait_event(chain[0])
-            ev3 = st.submit(2, h.numel(), B * 4 * MS + B, lambda par, res: launch3(B, None, _ptr_at(par, B + S * N * 3), res), stream)
+            n_dn3 = B * 4 * MS + B + (B * 2 * MS + B if alt is not None else 0)
+            ev3 = st.submit(2, n_up3, n_dn3, lambda par, res: launch3(B, None, _ptr_at(par, B + S * N * 3), res,
+                                                                          alt_ptr=None if alt is None else _ptr_at(par, B + S * N * 3 + B * 2 * MS)), stream)
             if chain is not None:
                 chain[0] = ev3
             yield ev3
@@ -1173,6 +1224,35 @@ def _strict_psf_maps_steps(lens, depth_plane_mm, focus, grid, ks, spp, fused=Non
             any_valid = torch.from_numpy(r[B * 4 * MS:B * 4 * MS + B].copy())
             ok2, fix = check_counts(hb[:, :, 0], pred3, curved, fwd_order)                        # [B,2]: chief and main of the batch
             ok = ok2.all(-1)
+            if alt is not None:
+                # a two-variant batch whose run under n + 1 shows that the loop stops at n: the variant under n is the truth if ITS bits
+                # (bits_alt: the unchanged ones in front of the undecided surface, its own behind) confirm the rest of its row
+                o2 = B * 4 * MS + B
+                hb_alt = r[o2:o2 + B * 2 * MS].view(np.uint32).reshape(B, 2, MS)
+                av_alt = r[o2 + B * 2 * MS:o2 + B * 2 * MS + B]
+                counts.stats["alt_retraced_max"] = max(counts.stats.get("alt_retraced_max", 0), int(hb_alt[ab, 0, MS - 1].max()))
+                sa, nl_ = alt[ab] & 0xff, alt[ab] >> 8
+                cand = ~ok2[ab, 0] & ok2[ab, 1] & (fix[ab, 0, sa] == nl_) & (av_alt[ab] >= 0)
+                if cand.any():
+                    cb = ab[cand]
+                    rows_lo = pred3[cb, 0].copy()
+                    rows_lo[np.arange(len(cb)), alt[cb] & 0xff] = alt[cb] >> 8
+                    ok_lo, _ = check_counts(hb_alt[cb, 0], rows_lo, curved, fwd_order)
+                    take = cb[ok_lo]
+                    if len(take):
+                        if _nan_in_run(hb_alt[take, 1][:, None], rows_lo[ok_lo][:, None], curved):
+                            raise FloatingPointError("found nan in ft in non-diff newton method.")
+                        with torch.cuda.stream(stream):
+                            for b_ in take:                  # (a few 70 KB device copies in front of the convolution; the centres stay behind:
+                                maps.view(B, grid * ks, grid * ks)[int(b_)].copy_(maps_alt[int(b_)], non_blocking=True)   # nothing reads them)
+                        pred3[take, 0] = rows_lo[ok_lo]
+                        hb = hb.copy()
+                        hb[take, 0, 0] = hb_alt[take, 0]
+                        hb[take, 0, 1] = hb_alt[take, 1]
+                        any_valid[torch.from_numpy(take)] = torch.from_numpy((av_alt[take] > 0).astype(np.int32))
+                        ok = ok.copy()
+                        ok[take] = True
+                        counts.stats["alt_taken"] = counts.stats.get("alt_taken", 0) + len(take)
             if _nan_in_run(hb[ok][:, :, 1], pred3[ok], curved):
                 raise FloatingPointError("found nan in ft in non-diff newton method.")
             truth = pred3.copy()

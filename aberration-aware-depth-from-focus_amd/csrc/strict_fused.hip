@@ -18,6 +18,8 @@
 #include <atomic>
 #include "strict_math2.h"
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 namespace aadff {
@@ -30,8 +32,11 @@ __device__ __forceinline__ Surf load_surf(csurf_t h, int forward) { return make_
 
 // Two rays (the halves of a lane's float2 values, csrc/strict_math2.h) through surfaces [first, last) in travel order with the
 // predicted counts pred[surface] (1..10); any-bits / NaN-bits of curved surface i are ORed into sink(i, bits) as (nan << 16 | any).
-template <typename Sink>
-__device__ __forceinline__ void trace_ray_fused2(csurf_t tab, int first, int last, int forward, const int* pred, R32& o, R32& d, f2& ra, Sink sink) {
+// ALT (the two-variant chief pass of fused_psf_kernel): at surface s_alt the loop also reports t one iteration earlier; *differs is
+// set when that iterate is another float for a live ray of the pair - under a count one lower THIS pair would go on differently.
+template <typename Sink, bool ALT = false>
+__device__ __forceinline__ void trace_ray_fused2(csurf_t tab, int first, int last, int forward, const int* pred, R32& o, R32& d, f2& ra, Sink sink,
+                                                 int s_alt = -1, bool* differs = nullptr) {
     const int nsteps = last - first;
     for (int k = 0; k < nsteps; ++k) {
         const int i = forward ? first + k : last - 1 - k;
@@ -44,12 +49,20 @@ __device__ __forceinline__ void trace_ray_fused2(csurf_t tab, int first, int las
             n = n < 1 ? 1 : (n > kMaxIter ? kMaxIter : n);
             unsigned mine = 0, nans = 0;
             const f2 alive = sel(ra > 0.f, f2s(1.f), f2s(0.f));
-            if (s.k_gt_m1) {                             // uniform: the usual case (k > -1) and the rest as two instances of the loop
-                const f2 t = loose_cycle2<true>(s, o, d, alive, n, t0, mine, nans);
+            f2 t;
+            if (ALT && i == s_alt) {                     // uniform
+                f2 tp;
+                t = s.k_gt_m1 ? loose_cycle2<true, true>(s, o, d, alive, n, t0, mine, nans, &tp) : loose_cycle2<false, true>(s, o, d, alive, n, t0, mine, nans, &tp);
+                *differs = (alive.x > 0.f && fbits(tp.x) != fbits(t.x)) || (alive.y > 0.f && fbits(tp.y) != fbits(t.y));
+                sink(i, mine | (nans << 16));
+                if (s.k_gt_m1) react_ray2<true>(s, o, d, ra, forward, t0, t);
+                else react_ray2<false>(s, o, d, ra, forward, t0, t);
+            } else if (s.k_gt_m1) {                      // uniform: the usual case (k > -1) and the rest as two instances of the loop
+                t = loose_cycle2<true>(s, o, d, alive, n, t0, mine, nans);
                 sink(i, mine | (nans << 16));
                 react_ray2<true>(s, o, d, ra, forward, t0, t);
             } else {
-                const f2 t = loose_cycle2<false>(s, o, d, alive, n, t0, mine, nans);
+                t = loose_cycle2<false>(s, o, d, alive, n, t0, mine, nans);
                 sink(i, mine | (nans << 16));
                 react_ray2<false>(s, o, d, ra, forward, t0, t);
             }
@@ -65,6 +78,26 @@ struct LdsSink {
         if (v & ~w[i]) atomicOr(&w[i], v);
     }
 };
+
+// the two-variant chief pass: bits of surfaces BEHIND s_alt go to `wm` for a pair that goes on differently under the lower count
+struct AltSink {
+    unsigned* wc;                   // wm = wc + skip (one LDS array: an offset, not a second pointer the compiler would park in scratch)
+    int skip;
+    const bool* differs;
+    int s_alt;
+    __device__ __forceinline__ void operator()(int i, unsigned v) const {
+        unsigned* w = wc + ((i > s_alt && *differs) ? skip : 0);
+        if (v & ~w[i]) atomicOr(&w[i], v);
+    }
+};
+
+__device__ __forceinline__ void flush_bits2(const unsigned* w0, const unsigned* w1, unsigned* g_any, unsigned* g_nan) {     // the OR of two collections
+    for (int i = threadIdx.x; i < AADFF_MAX_SURF; i += blockDim.x) {
+        const unsigned v = w0[i] | w1[i];
+        if (v & 0xffffu) atomicOr(g_any + i, v & 0xffffu);
+        if (v >> 16) atomicOr(g_nan + i, v >> 16);
+    }
+}
 
 __device__ __forceinline__ void flush_bits(const unsigned* lds_w, unsigned* g_any, unsigned* g_nan) {
     for (int i = threadIdx.x; i < AADFF_MAX_SURF; i += blockDim.x) {
@@ -179,32 +212,59 @@ struct PsfArgs {
     float* centre;                  // [B][N][2]
     unsigned* bits;                 // [J][2 phases][2: any, nan][AADFF_MAX_SURF]
     int* any_valid;                 // [J]
+    // two-variant jobs (aadff_strict_psf_points_alt): alt[j] = surface | n_lo << 8 of the chief row's one undecided count (the row holds
+    // n_lo + 1 there), or -1; the second variant's results are indexed by the JOB
+    const int* alt;                 // [J] or NULL
+    float* psf_alt;                 // [J] x the per-batch layout of psf
+    float* centre_alt;              // [J][N][2]
+    unsigned* bits_alt;             // [J][2: any, nan][AADFF_MAX_SURF] chief bits of the lower-count variant
+    int* any_valid_alt;             // [J]: 1 / 0 as any_valid for that variant, -1: its list overflowed (variant not available)
     int N, n_surf, spp, spp_c, ks, map_grid;
     float lo, hi, lim, den_row, den_col;   // histogram geometry (float64 -> fp32 once, host)
 };
 
+
 // kPsfThreads = 256: 6 workgroups per CU, what a whole level needs; 1024: a replay of a few batches is a few hundred workgroups on
 // 256 CUs - one per CU, each a serial chain of 16 rays per thread - so they get four times the threads instead.
+//
+// Two-variant jobs.  The batch-wide count of the chief rays at ONE aspheric surface flips between n and n + 1 from draw to draw for a
+// few batches (whether the slowest of 250 k rays is above 5e-5 after n iterations); mispredicting it cost a re-launch and a host round
+// trip on every stack.  Such a job traces the chief rays under n + 1 - the any-bits of that run tell the host which count was the true
+// one - and notes the pairs whose iterate after n iterations is another float (rays walking a 2- or 3-cycle, or still converging - up to
+// a third of an off-axis point's rays at the 4 / 5 flip of rf50mm: the rest sit on their fixed point and go on identically either way).
+// Those are re-traced under n, their rows
+// patched, the centre summed again: centre_alt; the main rays - traced once - are binned against both centres: psf_alt.  The host
+// takes the variant the bits confirm.  Any-bits behind the undecided surface are kept apart for the noted pairs, so that each variant
+// reports exactly the bits a launch under its row would have reported.
 template <int kPsfThreads>
 __global__ __launch_bounds__(kPsfThreads) void fused_psf_kernel(PsfArgs a) {
-    extern __shared__ float lds[];                       // rows [3][spp_c] | block sums [2][stride] | hist [ks*ks]
-    __shared__ unsigned w[2][AADFF_MAX_SURF];
-    __shared__ int s_pred[2][AADFF_MAX_SURF];
-    __shared__ float red[kPsfThreads / 64], cxy[2];
-    __shared__ int s_valid;
+    extern __shared__ float lds[];                       // rows [3][spp_c] | block sums [2][stride] | hist [ks*ks] | hist of the second variant [ks*ks] | noted samples [spp_c] u16
+    __shared__ unsigned w[4][AADFF_MAX_SURF];            // chief (all / common), main, chief: noted pairs under n + 1, noted pairs under n
+    __shared__ int s_pred[3][AADFF_MAX_SURF];            // chief, main, chief with the lower count
+    __shared__ float red[kPsfThreads / 64], cxy[2], cxy_lo[2];
+    __shared__ int s_valid;                              // bit 0: a valid chief ray (n + 1 variant), 1: one among the pairs not noted, 2: one among the re-traced
+    __shared__ unsigned alt_cnt;
     const int pt = blockIdx.x, job = blockIdx.y, b = a.job_batch ? fresh_uniform(a.job_batch + job) : job, tid = threadIdx.x;
     const int spp_c = a.spp_c, N = a.N, ks = a.ks, kk = ks * ks;
+    const int altw = a.alt ? fresh_uniform(a.alt + job) : -1;
+    const bool two = altw >= 0;                          // uniform
+    const int s_alt = two ? (altw & 0xff) : -1, n_lo = two ? (altw >> 8) : 0;
     float* rows = lds;
     // block-sum scratch of the cascade: at most 4 * (spp_c / 4 / 16 + 1) <= spp_c / 16 + 4 words per component
     const int bs_stride = spp_c / 16 + 8;
     float* bsum = rows + 3 * (size_t)spp_c;
     float* hist = bsum + 2 * bs_stride;
+    float* hist2 = hist + kk;
+    unsigned short* alt_list = reinterpret_cast<unsigned short*>(hist2 + kk);      // every chief sample fits: no overflow (spp_c <= 65535 checked by the entry)
+    const unsigned kAltCap = (unsigned)spp_c;
     for (int k = tid; k < 2 * AADFF_MAX_SURF; k += kPsfThreads) {
-        (&w[0][0])[k] = 0u;
-        (&s_pred[0][0])[k] = fresh(a.pred + (size_t)job * 2 * AADFF_MAX_SURF + k);
+        const int v = fresh(a.pred + (size_t)job * 2 * AADFF_MAX_SURF + k);
+        (&s_pred[0][0])[k] = v;
+        if (k < AADFF_MAX_SURF) s_pred[2][k] = k == s_alt ? n_lo : v;
     }
-    for (int e = tid; e < kk; e += kPsfThreads) hist[e] = 0.f;
-    if (tid == 0) s_valid = 0;
+    for (int k = tid; k < 4 * AADFF_MAX_SURF; k += kPsfThreads) (&w[0][0])[k] = 0u;
+    for (int e = tid; e < 2 * kk; e += kPsfThreads) hist[e] = 0.f;
+    if (tid == 0) { s_valid = 0; alt_cnt = 0u; }
     __syncthreads();
 
     // per-launch parameters through coherent loads (common.h: fresh): the batch of this job, its object point and sensor plane, and both
@@ -212,52 +272,73 @@ __global__ __launch_bounds__(kPsfThreads) void fused_psf_kernel(PsfArgs a) {
     const float* pp0 = a.points + ((size_t)fresh_uniform(a.point_set + b) * N + pt) * 3;
     const struct { float x, y, z; } po = {fresh_uniform(pp0), fresh_uniform(pp0 + 1), fresh_uniform(pp0 + 2)};
     const float zs = fresh_uniform(a.z_sensor + b);
+    const csurf_t tab_c = (csurf_t)(a.tables + (size_t)fresh_uniform(a.table_chief + b) * a.n_surf);
+
+    // one pair of chief rays (samples smp, smp2) to its weighted sensor hits
+    auto chief_pair = [&](int smp, int smp2, auto sink, auto alt_tag, const int* pred, bool* differs, f2& wx, f2& wy, f2& ra) {
+        const f3p pa = fresh3(a.pupil_chief + ((size_t)b * spp_c + smp) * 3);
+        const f3p pb = fresh3(a.pupil_chief + ((size_t)b * spp_c + smp2) * 3);
+        R32 o = {f2s(po.x), f2s(po.y), f2s(po.z)};
+        R32 d = {(f2){pa.x, pb.x} - o.x, (f2){pa.y, pb.y} - o.y, (f2){pa.z, pb.z} - o.z};
+        normalize32(d.x, d.y, d.z);
+        ra = f2s(1.f);
+        trace_ray_fused2<decltype(sink), decltype(alt_tag)::value>(tab_c, 0, a.n_surf, 1, pred, o, d, ra, sink, s_alt, differs);
+        const f2 t = div2(zs - o.z, d.z);
+        o.x = o.x + d.x * t; o.y = o.y + d.y * t;
+        wx = o.x * ra; wy = o.y * ra;
+    };
+    using No = std::false_type;
+    using Yes = std::true_type;
 
     // ---- phase 1: chief rays
     {
-        const csurf_t tab = (csurf_t)(a.tables + (size_t)fresh_uniform(a.table_chief + b) * a.n_surf);
-        const int* pred = s_pred[0];
-        bool valid = false;
+        bool valid = false, valid_c = false;
         // two rays per lane: samples smp and smp + kPsfThreads (a lone last sample is traced twice: same bits, stored once)
         for (int smp = tid; smp < spp_c; smp += 2 * kPsfThreads) {
             const int smp2 = smp + kPsfThreads < spp_c ? smp + kPsfThreads : smp;
-            const f3p pa = fresh3(a.pupil_chief + ((size_t)b * spp_c + smp) * 3);
-            const f3p pb = fresh3(a.pupil_chief + ((size_t)b * spp_c + smp2) * 3);
-            R32 o = {f2s(po.x), f2s(po.y), f2s(po.z)};
-            R32 d = {(f2){pa.x, pb.x} - o.x, (f2){pa.y, pb.y} - o.y, (f2){pa.z, pb.z} - o.z};
-            normalize32(d.x, d.y, d.z);
-            f2 ra = f2s(1.f);
-            trace_ray_fused2(tab, 0, a.n_surf, 1, pred, o, d, ra, LdsSink{w[0]});
-            const f2 t = div2(zs - o.z, d.z);
-            o.x = o.x + d.x * t; o.y = o.y + d.y * t;
-            const f2 wx = o.x * ra, wy = o.y * ra;
+            f2 wx, wy, ra;
+            bool differs = false;
+            if (two) chief_pair(smp, smp2, AltSink{w[0], 2 * AADFF_MAX_SURF, &differs, s_alt}, Yes{}, s_pred[0], &differs, wx, wy, ra);
+            else chief_pair(smp, smp2, LdsSink{w[0]}, No{}, s_pred[0], nullptr, wx, wy, ra);
             rows[smp] = wx.x; rows[spp_c + smp] = wy.x; rows[2 * spp_c + smp] = ra.x;
             if (smp2 != smp) { rows[smp2] = wx.y; rows[spp_c + smp2] = wy.y; rows[2 * spp_c + smp2] = ra.y; }
-            valid |= ra.x == 1.f || ra.y == 1.f;
+            const bool v = ra.x == 1.f || ra.y == 1.f;
+            valid |= v;
+            if (differs) {                               // both samples of the pair are noted (its bits were collected as one word)
+                const unsigned at = atomicAdd(&alt_cnt, smp2 != smp ? 2u : 1u);
+                if (at < kAltCap) alt_list[at] = (unsigned short)smp;
+                if (smp2 != smp && at + 1 < kAltCap) alt_list[at + 1] = (unsigned short)smp2;
+            } else {
+                valid_c |= v;
+            }
         }
         if (__any(valid) && (tid & 63) == 0) atomicOr(&s_valid, 1);
+        if (two && __any(valid_c) && (tid & 63) == 0) atomicOr(&s_valid, 2);
     }
     __syncthreads();
-    // ---- centre in ATen's summation order (the program of centroid_kernel, csrc/strict.hip, on the rows in LDS)
-    {
+    // ---- centre in ATen's summation order (the program of centroid_kernel, csrc/strict.hip, on the rows in LDS); holds barriers
+    auto centroid = [&](float* c_lds, float* c_out) {
         const int vec_cols = (N * 3 / 32) * 32;
-        int nsub[2], nb[2], rem[2], step[2], lp[2];
+        // the cascade's geometry of component k (x or y column of this point): scalars, not arrays - k is the thread index further down
+        auto geom = [&](int k, int& nsub, int& nb, int& rem, int& step, int& lp) {
+            nsub = pt * 3 + k >= vec_cols ? 4 : 1;
+            const int sub = spp_c / nsub;
+            lp = max(4, ceil_log2(sub) / 4);
+            step = 1 << lp;
+            nb = sub / step;
+            rem = sub - nb * step;
+        };
+#pragma unroll
         for (int k = 0; k < 2; ++k) {
-            nsub[k] = pt * 3 + k >= vec_cols ? 4 : 1;
-            const int sub = spp_c / nsub[k];
-            lp[k] = max(4, ceil_log2(sub) / 4);
-            step[k] = 1 << lp[k];
-            nb[k] = sub / step[k];
-            rem[k] = sub - nb[k] * step[k];
-        }
-        for (int k = 0; k < 2; ++k) {
+            int nsub, nb, rem, step, lp;
+            geom(k, nsub, nb, rem, step, lp);
             const float* v = rows + (size_t)k * spp_c;
-            const int total = nsub[k] * (nb[k] + 1);
+            const int total = nsub * (nb + 1);
             for (int id = tid; id < total; id += kPsfThreads) {
-                const int q = id / (nb[k] + 1), kb = id - q * (nb[k] + 1);
-                const int first = q + nsub[k] * kb * step[k], count = kb < nb[k] ? step[k] : rem[k];
+                const int q = id / (nb + 1), kb = id - q * (nb + 1);
+                const int first = q + nsub * kb * step, count = kb < nb ? step : rem;
                 float acc = 0.f;
-                for (int j = 0; j < count; ++j) acc = acc + v[first + nsub[k] * j];
+                for (int j = 0; j < count; ++j) acc = acc + v[first + nsub * j];
                 bsum[k * bs_stride + id] = acc;
             }
         }
@@ -268,47 +349,75 @@ __global__ __launch_bounds__(kPsfThreads) void fused_psf_kernel(PsfArgs a) {
         __syncthreads();
         if (tid < 2) {
             const int k = tid;
+            int nsub, nb, rem, step, lp;
+            geom(k, nsub, nb, rem, step, lp);
             const float* v = rows + (size_t)k * spp_c;
             float wt = 0.f;
             for (int i = 0; i < kPsfThreads / 64; ++i) wt += red[i];
-            float p[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int q = 0; q < nsub[k]; ++q) {
-                const float* bs = bsum + k * bs_stride + q * (nb[k] + 1);
-                float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                const int lmask = step[k] - 1;
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+            for (int q = 0; q < nsub; ++q) {
+                const float* bs = bsum + k * bs_stride + q * (nb + 1);
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;     // the four levels of ATen's cascade
+                const int lmask = step - 1;
                 int i = 0;
-                for (int kb = 0; kb < nb[k]; ++kb) {
-                    acc[0] = acc[0] + bs[kb];
-                    i += step[k];
-                    for (int j = 1; j < 4; ++j) {
-                        acc[j] = acc[j] + acc[j - 1];
-                        acc[j - 1] = 0.f;
-                        if ((i & (lmask << (j * lp[k]))) != 0) break;
+                for (int kb = 0; kb < nb; ++kb) {
+                    a0 = a0 + bs[kb];
+                    i += step;
+                    a1 = a1 + a0; a0 = 0.f;
+                    if ((i & (lmask << lp)) == 0) {
+                        a2 = a2 + a1; a1 = 0.f;
+                        if ((i & (lmask << (2 * lp))) == 0) { a3 = a3 + a2; a2 = 0.f; }
                     }
                 }
-                if (rem[k]) acc[0] = acc[0] + bs[nb[k]];
-                for (int j = 1; j < 4; ++j) acc[0] = acc[0] + acc[j];
-                p[q] = acc[0];
+                if (rem) a0 = a0 + bs[nb];
+                a0 = a0 + a1; a0 = a0 + a2; a0 = a0 + a3;
+                if (q == 0) p0 = a0; else if (q == 1) p1 = a0; else if (q == 2) p2 = a0; else p3 = a0;
             }
-            float total = p[0];
-            if (nsub[k] == 4) {
-                for (int i = 4 * (spp_c / 4); i < spp_c; ++i) p[0] = p[0] + v[i];
-                total = ((p[0] + p[1]) + p[2]) + p[3];
+            float total = p0;
+            if (nsub == 4) {
+                for (int i = 4 * (spp_c / 4); i < spp_c; ++i) p0 = p0 + v[i];
+                total = ((p0 + p1) + p2) + p3;
             }
             const float c = -(total / (wt + kEps));
-            cxy[k] = c;
-            a.centre[((size_t)b * N + pt) * 2 + k] = c;
+            c_lds[k] = c;
+            c_out[k] = c;
         }
-        if (tid == 0 && s_valid) atomicOr(a.any_valid + job, 1);
+        __syncthreads();
+    };
+    centroid(cxy, a.centre + ((size_t)b * N + pt) * 2);
+    if (tid == 0 && (s_valid & 1)) atomicOr(a.any_valid + job, 1);
+    // ---- the second variant: the noted pairs again under the lower count, rows patched, centre summed again
+    bool lo_ok = false;                                      // uniform
+    if (two) {
+        const unsigned have = alt_cnt;
+        lo_ok = have <= kAltCap;
+        if (lo_ok) {
+            bool valid_l = false;
+            for (int k2 = 2 * tid; k2 < (int)have; k2 += 2 * kPsfThreads) {
+                const int smp = alt_list[k2], smp2 = k2 + 1 < (int)have ? alt_list[k2 + 1] : smp;
+                f2 wx, wy, ra;
+                chief_pair(smp, smp2, LdsSink{w[3]}, No{}, s_pred[2], nullptr, wx, wy, ra);
+                rows[smp] = wx.x; rows[spp_c + smp] = wy.x; rows[2 * spp_c + smp] = ra.x;
+                if (smp2 != smp) { rows[smp2] = wx.y; rows[spp_c + smp2] = wy.y; rows[2 * spp_c + smp2] = ra.y; }
+                valid_l |= ra.x == 1.f || ra.y == 1.f;
+            }
+            if (__any(valid_l) && (tid & 63) == 0) atomicOr(&s_valid, 4);
+            __syncthreads();
+            centroid(cxy_lo, a.centre_alt + ((size_t)job * N + pt) * 2);
+        }
+        if (tid == 0) {                                      // every workgroup of the job adds its share: the sign bit (overflow) wins on the host
+            if (!lo_ok) atomicOr(a.any_valid_alt + job, (int)0x80000000);
+            else if (s_valid & 6) atomicOr(a.any_valid_alt + job, 1);
+            // telemetry in the last (never a surface's) any-word: the longest list among the job's workgroups
+            if (a.n_surf < AADFF_MAX_SURF) atomicMax(a.bits_alt + (size_t)job * 2 * AADFF_MAX_SURF + AADFF_MAX_SURF - 1, have);
+        }
     }
-    __syncthreads();
-    // ---- phase 2: main rays -> histogram
+    // ---- phase 2: main rays -> histogram(s)
     {
         const csurf_t tab = (csurf_t)(a.tables + (size_t)fresh_uniform(a.table_main + b) * a.n_surf);
         const int* pred = s_pred[1];
-        const float cx = cxy[0], cy = cxy[1];
         const float km1 = (float)(ks - 1);
-        auto splat = [&](float ox, float oy, float ra) {
+        auto splat = [&](float* h, float cx, float cy, float ox, float oy, float ra) {
             // forward_integral: flip, centre, window test (monte_carlo.py:24-38); a ray outside deposits zero weights: skipped
             const float X = -ox - cx, Y = -oy - cy;
             if ((fabsf(X) < a.lim) && (fabsf(Y) < a.lim) && (ra > 0.f)) {
@@ -317,12 +426,13 @@ __global__ __launch_bounds__(kPsfThreads) void fused_psf_kernel(PsfArgs a) {
                 const float wb = rowf - fr, wr = colf - fc;
                 const int r0 = (int)fr, c0 = (int)fc;
                 const int r1 = (int)floorf(rowf + 1.f), c1 = (int)floorf(colf + 1.f);
-                atomicAdd(&hist[r0 * ks + c0], ((1.f - wb) * (1.f - wr)) * ra);
-                atomicAdd(&hist[r0 * ks + c1], ((1.f - wb) * wr) * ra);
-                atomicAdd(&hist[r1 * ks + c0], (wb * (1.f - wr)) * ra);
-                atomicAdd(&hist[(r0 + 1) * ks + (c0 + 1)], (wb * wr) * ra);
+                atomicAdd(&h[r0 * ks + c0], ((1.f - wb) * (1.f - wr)) * ra);
+                atomicAdd(&h[r0 * ks + c1], ((1.f - wb) * wr) * ra);
+                atomicAdd(&h[r1 * ks + c0], (wb * (1.f - wr)) * ra);
+                atomicAdd(&h[(r0 + 1) * ks + (c0 + 1)], (wb * wr) * ra);
             }
         };
+        const float cx = cxy[0], cy = cxy[1], cx2 = lo_ok ? cxy_lo[0] : 0.f, cy2 = lo_ok ? cxy_lo[1] : 0.f;
         for (int smp = tid; smp < a.spp; smp += 2 * kPsfThreads) {
             const int smp2 = smp + kPsfThreads < a.spp ? smp + kPsfThreads : smp;
             const f3p pa = fresh3(a.pupil_main + ((size_t)b * a.spp + smp) * 3);
@@ -334,33 +444,44 @@ __global__ __launch_bounds__(kPsfThreads) void fused_psf_kernel(PsfArgs a) {
             trace_ray_fused2(tab, 0, a.n_surf, 1, pred, o, d, ra, LdsSink{w[1]});
             const f2 t = div2(zs - o.z, d.z);
             o.x = o.x + d.x * t; o.y = o.y + d.y * t;
-            splat(o.x.x, o.y.x, ra.x);
-            if (smp2 != smp) splat(o.x.y, o.y.y, ra.y);
+            splat(hist, cx, cy, o.x.x, o.y.x, ra.x);
+            if (smp2 != smp) splat(hist, cx, cy, o.x.y, o.y.y, ra.y);
+            if (lo_ok) {
+                splat(hist2, cx2, cy2, o.x.x, o.y.x, ra.x);
+                if (smp2 != smp) splat(hist2, cx2, cy2, o.x.y, o.y.y, ra.y);
+            }
         }
     }
     __syncthreads();
     // ---- normalise (optics.py:978; 0/0 -> NaN like the reference) and write
-    float part = 0.f;
-    for (int e = tid; e < kk; e += kPsfThreads) part += hist[e];
-    part = wave_sum(part);
-    if ((tid & 63) == 0) red[tid >> 6] = part;
-    __syncthreads();
-    float total = 0.f;
-    for (int i = 0; i < kPsfThreads / 64; ++i) total += red[i];
-    if (a.map_grid > 0) {
-        const int g = a.map_grid, gy = pt / g, gx = pt - gy * g;
-        float* dst = a.psf + (size_t)b * g * ks * g * ks + (size_t)gy * ks * g * ks + (size_t)gx * ks;
-        for (int e = tid; e < kk; e += kPsfThreads) {
-            const int r = e / ks, c = e - r * ks;
-            dst[(size_t)r * g * ks + c] = hist[e] / total;
+    auto write_psf = [&](const float* h, float* base) {      // holds a barrier
+        float part = 0.f;
+        for (int e = tid; e < kk; e += kPsfThreads) part += h[e];
+        part = wave_sum(part);
+        __syncthreads();                                     // (red is free again)
+        if ((tid & 63) == 0) red[tid >> 6] = part;
+        __syncthreads();
+        float total = 0.f;
+        for (int i = 0; i < kPsfThreads / 64; ++i) total += red[i];
+        if (a.map_grid > 0) {
+            const int g = a.map_grid, gy = pt / g, gx = pt - gy * g;
+            float* dst = base + (size_t)gy * ks * g * ks + (size_t)gx * ks;
+            for (int e = tid; e < kk; e += kPsfThreads) {
+                const int r = e / ks, c = e - r * ks;
+                dst[(size_t)r * g * ks + c] = h[e] / total;
+            }
+        } else {
+            float* dst = base + (size_t)pt * kk;
+            for (int e = tid; e < kk; e += kPsfThreads) dst[e] = h[e] / total;
         }
-    } else {
-        float* dst = a.psf + ((size_t)b * N + pt) * kk;
-        for (int e = tid; e < kk; e += kPsfThreads) dst[e] = hist[e] / total;
-    }
+    };
+    const size_t per_batch = a.map_grid > 0 ? (size_t)a.map_grid * ks * a.map_grid * ks : (size_t)N * kk;
+    write_psf(hist, a.psf + (size_t)b * per_batch);
+    if (lo_ok) write_psf(hist2, a.psf_alt + (size_t)job * per_batch);
     unsigned* gb = a.bits + (size_t)job * 4 * AADFF_MAX_SURF;
-    flush_bits(w[0], gb, gb + AADFF_MAX_SURF);
+    flush_bits2(w[0], w[2], gb, gb + AADFF_MAX_SURF);
     flush_bits(w[1], gb + 2 * AADFF_MAX_SURF, gb + 3 * AADFF_MAX_SURF);
+    if (two) flush_bits2(w[0], w[3], a.bits_alt + (size_t)job * 2 * AADFF_MAX_SURF, a.bits_alt + ((size_t)job * 2 + 1) * AADFF_MAX_SURF);
 }
 
 // ---- edge-exact PSF grid: the deferred border rays of aadff_psf_points_edge in the reference's arithmetic ---------------------------
@@ -529,28 +650,36 @@ extern "C" int aadff_strict_replay_threads(int threads) {
     return 0;
 }
 
-extern "C" int aadff_strict_psf_points(const float* points, int N, int B, const int* job_batch_or_null, const int* point_set, const aadff_surface_t* tables_dev, int n_tables,
-                                       int n_surf, const int* table_main, const int* table_chief, const float* z_sensor, const float* pupil_main,
-                                       int spp, const float* pupil_chief, int spp_chief, const int* pred, float pixel_size, int ks,
-                                       int map_grid, float* psf, float* centre, unsigned* bits, int* any_valid, aadff_stream_t stream) {
+extern "C" int aadff_strict_psf_points_alt(const float* points, int N, int B, const int* job_batch_or_null, const int* point_set, const aadff_surface_t* tables_dev,
+                                           int n_tables, int n_surf, const int* table_main, const int* table_chief, const float* z_sensor,
+                                           const float* pupil_main, int spp, const float* pupil_chief, int spp_chief, const int* pred, float pixel_size,
+                                           int ks, int map_grid, float* psf, float* centre, unsigned* bits, int* any_valid, const int* alt_or_null,
+                                           float* psf_alt, float* centre_alt, unsigned* bits_alt, int* any_valid_alt, aadff_stream_t stream) {
     AADFF_CHECK_ARG(points && point_set && tables_dev && table_main && table_chief && z_sensor && pupil_main && pupil_chief && pred && psf && centre &&
                     bits && any_valid, "strict_psf_points: NULL pointer");
+    AADFF_CHECK_ARG(!alt_or_null || (psf_alt && centre_alt && bits_alt && any_valid_alt), "strict_psf_points_alt: two-variant jobs need the second set of outputs");
     AADFF_CHECK_ARG(N >= 1 && B >= 1 && B <= 65535 && spp >= 1 && spp_chief >= 1 && spp_chief <= 65536, "strict_psf_points: N=%d B=%d spp=%d spp_chief=%d", N, B,
                     spp, spp_chief);
     AADFF_CHECK_ARG(n_tables >= 1 && n_surf >= 1 && n_surf <= AADFF_MAX_SURF, "strict_psf_points: n_tables=%d n_surf=%d", n_tables, n_surf);
     AADFF_CHECK_ARG(ks >= 1 && ks <= AADFF_MAX_KS && (ks & 1), "strict_psf_points: ks=%d", ks);
     AADFF_CHECK_ARG(map_grid == 0 || map_grid * map_grid == N, "strict_psf_points: map layout needs N = grid^2 (N=%d grid=%d)", N, map_grid);
-    const size_t lds = ((size_t)3 * spp_chief + 2 * (spp_chief / 16 + 8) + (size_t)ks * ks) * sizeof(float);
-    if (lds > 64 * 1024 - 1024) {
+    AADFF_CHECK_ARG(!alt_or_null || spp_chief <= 65535, "strict_psf_points_alt: two-variant jobs index chief samples with 16 bits (spp_chief=%d)", spp_chief);
+    const size_t lds = ((size_t)3 * spp_chief + 2 * (spp_chief / 16 + 8) + 2 * (size_t)ks * ks) * sizeof(float) + (((size_t)spp_chief * 2 + 3) & ~(size_t)3);
+    if (lds > 64 * 1024 - 4096) {
         set_error("strict_psf_points: spp_chief=%d with ks=%d needs %zu bytes of LDS", spp_chief, ks, lds);
         return AADFF_EUNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
     AADFF_CHECK_HIP(hipMemsetAsync(bits, 0, (size_t)B * 4 * AADFF_MAX_SURF * sizeof(unsigned), st));
     AADFF_CHECK_HIP(hipMemsetAsync(any_valid, 0, (size_t)B * sizeof(int), st));
+    if (alt_or_null) {
+        AADFF_CHECK_HIP(hipMemsetAsync(bits_alt, 0, (size_t)B * 2 * AADFF_MAX_SURF * sizeof(unsigned), st));
+        AADFF_CHECK_HIP(hipMemsetAsync(any_valid_alt, 0, (size_t)B * sizeof(int), st));
+    }
     strict::PsfArgs a{};
     a.points = points; a.job_batch = job_batch_or_null; a.point_set = point_set; a.tables = tables_dev; a.table_main = table_main; a.table_chief = table_chief; a.z_sensor = z_sensor;
     a.pupil_main = pupil_main; a.pupil_chief = pupil_chief; a.pred = pred; a.psf = psf; a.centre = centre; a.bits = bits; a.any_valid = any_valid;
+    a.alt = alt_or_null; a.psf_alt = psf_alt; a.centre_alt = centre_alt; a.bits_alt = bits_alt; a.any_valid_alt = any_valid_alt;
     a.N = N; a.n_surf = n_surf; a.spp = spp; a.spp_c = spp_chief; a.ks = ks; a.map_grid = map_grid;
     const double ps = (double)pixel_size;                                        // monte_carlo.py:24: Python floats, rounded once
     const double lo = (-ks / 2.0 + 0.5) * ps, hi = (ks / 2.0 - 0.5) * ps;
@@ -559,6 +688,15 @@ extern "C" int aadff_strict_psf_points(const float* points, int N, int B, const 
     else hipLaunchKernelGGL(strict::fused_psf_kernel<1024>, dim3(N, B), dim3(1024), lds, st, a);
     AADFF_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int aadff_strict_psf_points(const float* points, int N, int B, const int* job_batch_or_null, const int* point_set, const aadff_surface_t* tables_dev, int n_tables,
+                                       int n_surf, const int* table_main, const int* table_chief, const float* z_sensor, const float* pupil_main,
+                                       int spp, const float* pupil_chief, int spp_chief, const int* pred, float pixel_size, int ks,
+                                       int map_grid, float* psf, float* centre, unsigned* bits, int* any_valid, aadff_stream_t stream) {
+    return aadff_strict_psf_points_alt(points, N, B, job_batch_or_null, point_set, tables_dev, n_tables, n_surf, table_main, table_chief, z_sensor, pupil_main, spp,
+                                       pupil_chief, spp_chief, pred, pixel_size, ks, map_grid, psf, centre, bits, any_valid, nullptr, nullptr, nullptr, nullptr,
+                                       nullptr, stream);
 }
 
 extern "C" int aadff_strict_edge_retrace(const float* points, int N, int B, const int* point_set, const aadff_surface_t* tables_dev, int n_tables, int n_surf,

@@ -143,8 +143,10 @@ __device__ __forceinline__ float cycle_finish(int p, int j, int n, unsigned& bm,
     return r == 0 ? tj : (p - r == 1 ? tj1 : tj2);
 }
 
-template <bool KGT>
-__device__ __forceinline__ f2 loose_cycle2(const Surf& s, const R32& o, const R32& d, f2 alive, int n, f2 t0, unsigned& mine, unsigned& nans) {
+// t_prev (optional): t after n - 1 iterations as well - what the loop would have returned under a count one lower (the two-variant
+// chief pass of fused_psf_kernel, csrc/strict_fused.hip).
+template <bool KGT, bool WITH_PREV = false>
+__device__ __forceinline__ f2 loose_cycle2(const Surf& s, const R32& o, const R32& d, f2 alive, int n, f2 t0, unsigned& mine, unsigned& nans, f2* t_prev = nullptr) {
     f2 t = t0, h2 = t0, h3 = t0, tn = t0;
     unsigned bmx = 0, bmy = 0, bnx = 0, bny = 0;
     int j = 0, px = 0, py = 0;
@@ -165,6 +167,14 @@ __device__ __forceinline__ f2 loose_cycle2(const Surf& s, const R32& o, const R3
         h3 = h2; h2 = t; t = tn;
     }
     f2 tfin = tn;
+    if (WITH_PREV) {
+        *t_prev = t;                                     // the loop ran all n iterations: t entered the last one
+        if (j < n) {                                     // periodic from iteration j <= n - 1 on: read t_{n-1} off the cycle (bits untouched)
+            unsigned b0 = bmx, b1 = bnx, b2 = bmy, b3 = bny;
+            t_prev->x = cycle_finish(px, j, n - 1, b0, b1, tn.x, t.x, h2.x);
+            t_prev->y = cycle_finish(py, j, n - 1, b2, b3, tn.y, t.y, h2.y);
+        }
+    }
     if (j < n) {                                         // both periodic at iteration j (periods px, py)
         tfin.x = cycle_finish(px, j, n, bmx, bnx, tn.x, t.x, h2.x);
         tfin.y = cycle_finish(py, j, n, bmy, bny, tn.y, t.y, h2.y);

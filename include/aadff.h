@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AADFF_ABI_VERSION 8
+#define AADFF_ABI_VERSION 9
 
 #define AADFF_EINVAL      (-1)   /* bad shape / size / NULL pointer                  */
 #define AADFF_EUNSUPPORTED (-2)  /* parameter outside what the kernels were built for */
@@ -260,6 +260,24 @@ int aadff_strict_psf_points(const float* points, int N, int B, const int* job_ba
                             int n_surf, const int* table_main, const int* table_chief, const float* z_sensor, const float* pupil_main,
                             int spp, const float* pupil_chief, int spp_chief, const int* pred, float pixel_size, int ks, int map_grid,
                             float* psf, float* centre, unsigned* bits, int* any_valid, aadff_stream_t stream);
+
+/* aadff_strict_psf_points with TWO-VARIANT jobs (ABI v9): a batch whose chief-ray count at ONE surface is known to flip between n and
+ * n + 1 from draw to draw (whether the slowest ray of the batch is still above 5e-5 after n iterations, deeplens/surfaces.py:547) is
+ * rendered under both counts in the same launch instead of being re-launched when the guess was wrong.
+ *   alt_or_null [B] int32 (device): per job, surface | n << 8 with pred[j][0][surface] = n + 1, or -1 (an ordinary job).
+ *   The job's ordinary outputs (psf, centre, bits, any_valid) are those of the row as given (count n + 1); the bits of that run show
+ *   which count the reference's loop would have stopped at.  The variant under n: psf_alt [B] x the per-batch layout of psf and
+ *   centre_alt [B][N][2], indexed by the JOB; bits_alt [B][2][AADFF_MAX_SURF] (any | nan) the chief bits a launch under that row
+ *   would have reported (its last any-word, never a surface's: the largest number of re-traced chief rays among the job's object
+ *   points); any_valid_alt [B]: > 0 a chief ray of that variant is valid, 0 none, < 0 the variant is not available.  All zeroed by
+ *   the call.  Only the chief rays whose iterate after n iterations differs from the one after n + 1 are traced twice (rf50mm at its
+ *   4 / 5 flip: up to a third of an off-axis point's 2048); the main rays are traced once and binned against both centres.
+ * alt_or_null = NULL is aadff_strict_psf_points. */
+int aadff_strict_psf_points_alt(const float* points, int N, int B, const int* job_batch_or_null, const int* point_set, const aadff_surface_t* tables_dev,
+                                int n_tables, int n_surf, const int* table_main, const int* table_chief, const float* z_sensor,
+                                const float* pupil_main, int spp, const float* pupil_chief, int spp_chief, const int* pred, float pixel_size,
+                                int ks, int map_grid, float* psf, float* centre, unsigned* bits, int* any_valid, const int* alt_or_null,
+                                float* psf_alt, float* centre_alt, unsigned* bits_alt, int* any_valid_alt, aadff_stream_t stream);
 
 /* Self test (no reference counterpart) of the packed float32 primitives the two-rays-per-lane strict kernels use (csrc/strict_math2.h)
  * against the compiler's IEEE forms, bit for bit: op 0: num[i] / den[i] (reciprocal refinement with packed FMAs + v_div_fixup_f32,

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(header):
 
 def test_abi_version_and_error_string():
     lib = _abi.load_library()
-    assert lib.aadff_abi_version() == _abi.ABI_VERSION == 8
+    assert lib.aadff_abi_version() == _abi.ABI_VERSION == 9
     assert isinstance(lib.aadff_last_error(), bytes)
 
 

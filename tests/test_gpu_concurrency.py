@@ -62,3 +62,94 @@ def test_strict_trace_is_bit_stable_beside_the_convolution(repo_root):
             torch.cuda.synchronize()
             differing += int(not torch.equal(got, ref))
         assert differing == 0, f"{name} strict trace: {differing} of {launches} launches beside the convolution differ from a quiet launch"
+
+
+def test_two_variant_jobs_equal_the_single_variant_launches(repo_root, margin):
+    """`aadff_strict_psf_points_alt` (round 6): a batch whose chief count at one aspheric surface flips between n and n + 1 is rendered
+    under both counts in ONE launch.  Checked against two ordinary launches of `aadff_strict_psf_points` (row with n + 1, row with n):
+    centres bit-identical, PSF maps equal to the histogram's float atomics, the chief any-bits of both variants identical to what the
+    ordinary launches report - for a real level (counts of a seed run) with EVERY batch made a two-variant job at surface 9."""
+    dev = torch.device(DEV)
+    lens = Lensgroup(lp(repo_root), sensor_res=(512, 512), device=DEV, parity="strict")
+    S, grid, spp, ks = 2, 5, 512, 11
+    from deeplens.basics import GEO_SPP
+    a = _psf_level_inputs(lens, S, grid, spp, seed=5)
+    N, B, n_surf, MS = a["N"], a["B"], len(lens.surfaces), _abi.MAX_SURF
+    curved = ss._curved(lens)
+    _, cnt, _ = ss._level3_batched(lens, None, a["points"], a["pset"], a["pc"], a["pm"], a["zs"], a["bt_chief"], a["bt_main"], a["tabs"], len(a["wv"]), n_surf, N, spp, ks, dev)
+    cnt = np.ascontiguousarray(cnt, dtype=np.int32)                              # [B, 2, MS] true counts
+    s_alt = 9
+    assert curved[s_alt] and (cnt[:, 0, s_alt] >= 2).all() and (cnt[:, 0, s_alt] < 10).all()
+
+    def run(rows, alt=None):
+        maps = torch.empty((B, grid * ks, grid * ks), device=dev)
+        centre = torch.empty((B, N, 2), device=dev)
+        bits = torch.empty((B, 2, 2, MS), dtype=torch.int32, device=dev)
+        av = torch.empty(B, dtype=torch.int32, device=dev)
+        pred = torch.from_numpy(rows).to(dev)
+        args = [_abi.ptr(a["points"]), N, B, None, _abi.ptr(a["pset"]), _abi.ptr(a["tab_dev"]), len(a["wv"]), n_surf, _abi.ptr(a["bt_main"]), _abi.ptr(a["bt_chief"]),
+                _abi.ptr(a["zs"]), _abi.ptr(a["pm"]), spp, _abi.ptr(a["pc"]), GEO_SPP, _abi.ptr(pred), float(lens.pixel_size), ks, grid, _abi.ptr(maps),
+                _abi.ptr(centre), _abi.ptr(bits), _abi.ptr(av)]
+        if alt is None:
+            _abi.call("aadff_strict_psf_points", *args, _abi.stream_ptr(dev))
+            return maps, centre, bits.cpu().numpy(), av.cpu().numpy()
+        m2, c2 = torch.empty_like(maps), torch.empty_like(centre)
+        b2 = torch.empty((B, 2, MS), dtype=torch.int32, device=dev)
+        av2 = torch.empty(B, dtype=torch.int32, device=dev)
+        _abi.call("aadff_strict_psf_points_alt", *args, _abi.ptr(torch.from_numpy(alt).to(dev)), _abi.ptr(m2), _abi.ptr(c2), _abi.ptr(b2), _abi.ptr(av2), _abi.stream_ptr(dev))
+        return maps, centre, bits.cpu().numpy(), av.cpu().numpy(), m2, c2, b2.cpu().numpy(), av2.cpu().numpy()
+
+    # true count n* at the surface: the pair (n* - 1, n*) - the usual case, truth is the higher - and (n*, n* + 1) - truth is the lower
+    for shift in (0, 1):
+        n_lo = cnt[:, 0, s_alt] - 1 + shift
+        hi_rows, lo_rows = cnt.copy(), cnt.copy()
+        hi_rows[:, 0, s_alt] = n_lo + 1
+        lo_rows[:, 0, s_alt] = n_lo
+        alt = (s_alt | (n_lo << 8)).astype(np.int32)
+        m_hi, c_hi, b_hi, v_hi = run(hi_rows)
+        m_lo, c_lo, b_lo, v_lo = run(lo_rows)
+        m, c, b, v, m2, c2, b2, v2 = run(hi_rows, alt)
+        print(f"two-variant jobs, shift {shift}: counts at the surface {cnt[:, 0, s_alt].tolist()}, longest list of noted rays per job {b2[:, 0, MS - 1].tolist()} of {GEO_SPP}")
+        assert (v2 >= 0).all(), "a two-variant job ran out of list space"
+        assert torch.equal(c.view(torch.int32), c_hi.view(torch.int32)) and torch.equal(c2.view(torch.int32), c_lo.view(torch.int32))
+        assert np.array_equal(b, b_hi) and np.array_equal(v, v_hi) and np.array_equal(v2 > 0, v_lo > 0)
+        assert np.array_equal(b2[:, 0, :n_surf], b_lo[:, 0, 0, :n_surf]) and np.array_equal(b2[:, 1], b_lo[:, 0, 1])      # chief any / nan bits of the lower-count variant
+        margin(f"two-variant psf_map jobs (pair n*{'' if shift else ' - 1'}..): PSF maps of the n + 1 variant vs an ordinary launch, max |d| / max",
+               float((m - m_hi).abs().max() / m_hi.max()), 2e-6)
+        margin(f"two-variant psf_map jobs (pair n*{'' if shift else ' - 1'}..): PSF maps of the n variant vs an ordinary launch, max |d| / max",
+               float((m2 - m_lo).abs().max() / m_lo.max()), 2e-6)
+        differ = int((c_hi.view(torch.int32) != c_lo.view(torch.int32)).any(-1).sum())
+        print(f"two-variant jobs, shift {shift}: centres that differ between the two counts: {differ} of {B * N}")
+
+
+def test_strict_stacks_without_relaunches(repo_root, margin):
+    """With the two-variant jobs a strict stack needs no level-3 re-launch once the count table knows both values (VERDICT r5 #2:
+    at most 2 per 20 stacks), and its maps equal those of the re-launching form (AADFF_STRICT_ALT=0) on the same draws."""
+    H = W = 512
+    S, grid, spp = 10, 11, 2048
+    from aadff.synth import synth_depth_mm
+    depth = synth_depth_mm(1024, 1024, seed=5678)
+    dbar, fds = -float(depth.mean()), [float(f) for f in -np.linspace(depth.min(), depth.max(), S)]
+    out = {}
+    for alt_on in (True, False):
+        ss.ALT_JOBS = alt_on
+        try:
+            lens = Lensgroup(lp(repo_root), sensor_res=(H, W), device=DEV, parity="strict")
+            torch.manual_seed(21)
+            for _ in range(40):                                                      # seeds the table and lets it see both counts of the batches that flip
+                ss.strict_psf_maps(lens, dbar, fds, grid, 11, spp)
+            stats0 = dict(ss.StrictCounts.of(lens).stats)
+            torch.manual_seed(22)
+            maps = [ss.strict_psf_maps(lens, dbar, fds, grid, 11, spp).clone() for _ in range(20)]
+            torch.cuda.synchronize()
+            st = ss.StrictCounts.of(lens).stats
+            out[alt_on] = (maps, {k: st[k] - stats0.get(k, 0) for k in st})
+        finally:
+            ss.ALT_JOBS = True
+    print("strict stacks, two-variant jobs on :", out[True][1])
+    print("strict stacks, two-variant jobs off:", out[False][1])
+    worst = max(float((x - y).abs().max() / y.max()) for x, y in zip(out[True][0], out[False][0]))
+    margin("strict stacks: two-variant jobs vs re-launches, PSF maps max |d| / max over 20 stacks", worst, 2e-6)
+    # (replayed_batches counts psf_map batches only; a batch that shows its second count for the first time still costs one re-launch)
+    assert out[True][1]["replayed_batches"] <= 2, out[True][1]
+    assert out[True][1].get("alt_taken", 0) > 0 and out[False][1]["replayed_batches"] >= 20, (out[True][1], out[False][1])
