@@ -430,6 +430,9 @@ def main():
             # who took part (the driver's first 8-rank run will want this): group size and backend as torch.distributed reports them,
             # every rank's own ms per step and host-side queueing time before the max over ranks
             "ranks_seen": ranks_seen,
+            # the GPU boxes are shared hosts (256 logical CPUs, a 16-CPU quota per job, load averages of 15-30 from other jobs): the
+            # host-bound legs (strict / edge pipelines at depth 4) read up to 2-4 x slower on a busy host - profiles/r06_zz_bench_busy_host.json
+            "host": {"loadavg_1_5_15": [round(v, 1) for v in os.getloadavg()], "usable_cpus": usable_cpus()},
             "soak": {"ms_per_step": round(soak_ms, 4), "steps": n_soak, "seconds": round(soak_ms * n_soak / 1e3, 2),
                      "what": "the same pipelined step queued for >= 1 s after the timed region (untimed leg; synchronised every 64 steps)"},
             "one_stream": {"ms_per_step": round(one_stream_ms, 4), "value": round(S * H * W / 1e6 / (one_stream_ms * 1e-3), 2), "steps": n_one,
