@@ -36,7 +36,9 @@ dbar, fds = -float(depth.mean()), [float(f) for f in -np.linspace(depth.min(), d
 img = torch.from_numpy(synth_rgb(H, W, seed=3))[None].to(DEV)
 LP = os.path.join(REPO, "lenses", "rf50mm", "lens.json")
 make = lambda: Lensgroup(LP, sensor_res=(H, W), device=DEV, parity=PARITY)
-TOL = 2e-6 if PARITY == "strict" else 2e-6
+# float atomics: strict PSFs are one LDS histogram (2e-6 of the peak has never been exceeded); edge PSFs add the re-trace's global atomics in
+# list order (2.2e-6 seen once in 36 000 stacks; the instruction-form errors this probe hunted were 1e-5 ... 2e-4)
+TOL = 2e-6 if PARITY == "strict" else 5e-6
 bad = total = 0
 quiet = make()
 render_focal_stack_m1(quiet, img, dbar, fds, grid, 11, spp)
