@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Which batch-wide Newton counts of the strict psf_map level are mispredicted from stack to stack: 64 bench-sized stacks, every failing
+(batch, phase, surface) with its predicted -> true counts.  Round 6: all of them are the CHIEF count at surface 9 (second aspheric) of
+8 batches flipping 4 <-> 5 - what aadff_strict_psf_points_alt renders under both counts.
+Run with AADFF_STRICT_ALT=0 to see the flips (with the two-variant jobs on there is nothing left to mispredict)."""
 import os, sys, collections
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "aberration-aware-depth-from-focus_amd")]
