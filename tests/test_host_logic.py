@@ -820,3 +820,23 @@ def test_vectorised_host_reductions_equal_the_call_by_call_forms(monkeypatch):
     monkeypatch.setattr(ss, "_object_points_loop", real)
     assert torch.equal(ss._object_points(lens, pts, hf), real(lens, pts, hf))
     monkeypatch.setitem(ss._HostFast.left, "points", 0)
+
+
+def test_two_variant_words_pick_exactly_the_neighbouring_pairs():
+    """`strict_stack._two_variant_words`: a batch becomes a two-variant psf_map job (aadff_strict_psf_points_alt) when exactly ONE curved
+    surface of its chief row has two NEIGHBOURING counts on record - and only then."""
+    from aadff import strict_stack as ss
+    MS = _abi.MAX_SURF
+    curved = np.zeros(MS, dtype=bool)
+    curved[[0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11]] = True
+    bit = lambda *ns: np.uint16(sum(1 << n for n in ns))
+    seen = np.zeros((7, MS), dtype=np.uint16)
+    seen[:, :12] = bit(3)
+    seen[1, 9] = bit(4, 5)                    # the case of rf50mm: 4 <-> 5 at the second aspheric surface
+    seen[2, 9] = bit(4, 6)                    # not neighbours
+    seen[3, 9], seen[3, 8] = bit(4, 5), bit(2, 3)   # two undecided surfaces
+    seen[4, 9] = bit(4, 5, 6)                 # three counts
+    seen[5, 5] = bit(1, 2)                    # the stop: not a curved surface, ignored
+    seen[6, 0] = bit(9, 10)                   # the top of the range
+    w = ss._two_variant_words(seen, curved)
+    assert w.dtype == np.int32 and w.tolist() == [-1, 9 | 4 << 8, -1, -1, -1, -1, 0 | 9 << 8]
