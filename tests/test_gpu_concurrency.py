@@ -64,11 +64,12 @@ def test_strict_trace_is_bit_stable_beside_the_convolution(repo_root):
         assert differing == 0, f"{name} strict trace: {differing} of {launches} launches beside the convolution differ from a quiet launch"
 
 
-def test_two_variant_jobs_equal_the_single_variant_launches(repo_root, margin):
+@pytest.mark.parametrize("s_alt", [9, 3])       # the second aspheric surface (the real case) and a spherical one
+def test_two_variant_jobs_equal_the_single_variant_launches(repo_root, margin, s_alt):
     """`aadff_strict_psf_points_alt` (round 6): a batch whose chief count at one aspheric surface flips between n and n + 1 is rendered
     under both counts in ONE launch.  Checked against two ordinary launches of `aadff_strict_psf_points` (row with n + 1, row with n):
     centres bit-identical, PSF maps equal to the histogram's float atomics, the chief any-bits of both variants identical to what the
-    ordinary launches report - for a real level (counts of a seed run) with EVERY batch made a two-variant job at surface 9."""
+    ordinary launches report - for a real level (counts of a seed run) with EVERY batch made a two-variant job at one surface."""
     dev = torch.device(DEV)
     lens = Lensgroup(lp(repo_root), sensor_res=(512, 512), device=DEV, parity="strict")
     S, grid, spp, ks = 2, 5, 512, 11
@@ -78,7 +79,6 @@ def test_two_variant_jobs_equal_the_single_variant_launches(repo_root, margin):
     curved = ss._curved(lens)
     _, cnt, _ = ss._level3_batched(lens, None, a["points"], a["pset"], a["pc"], a["pm"], a["zs"], a["bt_chief"], a["bt_main"], a["tabs"], len(a["wv"]), n_surf, N, spp, ks, dev)
     cnt = np.ascontiguousarray(cnt, dtype=np.int32)                              # [B, 2, MS] true counts
-    s_alt = 9
     assert curved[s_alt] and (cnt[:, 0, s_alt] >= 2).all() and (cnt[:, 0, s_alt] < 10).all()
 
     def run(rows, alt=None):
@@ -109,14 +109,14 @@ def test_two_variant_jobs_equal_the_single_variant_launches(repo_root, margin):
         m_hi, c_hi, b_hi, v_hi = run(hi_rows)
         m_lo, c_lo, b_lo, v_lo = run(lo_rows)
         m, c, b, v, m2, c2, b2, v2 = run(hi_rows, alt)
-        print(f"two-variant jobs, shift {shift}: counts at the surface {cnt[:, 0, s_alt].tolist()}, longest list of noted rays per job {b2[:, 0, MS - 1].tolist()} of {GEO_SPP}")
+        print(f"two-variant jobs at surface {s_alt}, shift {shift}: counts at the surface {cnt[:, 0, s_alt].tolist()}, longest list of noted rays per job {b2[:, 0, MS - 1].tolist()} of {GEO_SPP}")
         assert (v2 >= 0).all(), "a two-variant job ran out of list space"
         assert torch.equal(c.view(torch.int32), c_hi.view(torch.int32)) and torch.equal(c2.view(torch.int32), c_lo.view(torch.int32))
         assert np.array_equal(b, b_hi) and np.array_equal(v, v_hi) and np.array_equal(v2 > 0, v_lo > 0)
         assert np.array_equal(b2[:, 0, :n_surf], b_lo[:, 0, 0, :n_surf]) and np.array_equal(b2[:, 1], b_lo[:, 0, 1])      # chief any / nan bits of the lower-count variant
-        margin(f"two-variant psf_map jobs (pair n*{'' if shift else ' - 1'}..): PSF maps of the n + 1 variant vs an ordinary launch, max |d| / max",
+        margin(f"two-variant psf_map jobs at surface {s_alt} (pair n*{'' if shift else ' - 1'}..): PSF maps of the n + 1 variant vs an ordinary launch, max |d| / max",
                float((m - m_hi).abs().max() / m_hi.max()), 2e-6)
-        margin(f"two-variant psf_map jobs (pair n*{'' if shift else ' - 1'}..): PSF maps of the n variant vs an ordinary launch, max |d| / max",
+        margin(f"two-variant psf_map jobs at surface {s_alt} (pair n*{'' if shift else ' - 1'}..): PSF maps of the n variant vs an ordinary launch, max |d| / max",
                float((m2 - m_lo).abs().max() / m_lo.max()), 2e-6)
         differ = int((c_hi.view(torch.int32) != c_lo.view(torch.int32)).any(-1).sum())
         print(f"two-variant jobs, shift {shift}: centres that differ between the two counts: {differ} of {B * N}")
